@@ -1,0 +1,178 @@
+/*
+ * lssvc_hip.h -- C ABI of liblssvc_hip.so, the MI355X (gfx950) kernels behind LSSVC's per-frame
+ * encode/decode hot path.
+ *
+ * The reference has no FFI registry for this path: its "operators" are the PyTorch ATen calls made
+ * by the nn.Modules under src/IntraModules and src/InterModules. Each entry
+ * point below replaces one such operator class; the reference call sites are cited per function.
+ * The host-side mirror of the reference's model API (IntraSS / LSSVC_extend) lives in Python
+ * (lssvc_amd/) and reaches these symbols through ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - All tensors are fp32, batch 1, NHWC ("pixel-major") in device memory: element (y, x, c) of a
+ *     view lives at ptr[(y * W + x) * ld + c]; ld >= C lets a view be a channel slice of a wider
+ *     buffer (that is how torch.cat / chunk along channels are made free).
+ *   - Every call enqueues work on `stream` (a hipStream_t passed as void*) and returns at once.
+ *   - Return value: 0 on success, non-zero on error; lssvc_last_error() gives the message
+ *     (thread-local). Shapes are validated on the host BEFORE any launch.
+ */
+#ifndef LSSVC_HIP_H
+#define LSSVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lssvc_view {
+    float *ptr; /* device pointer */
+    int32_t H, W, C;
+    int32_t ld; /* elements between consecutive pixels (>= C) */
+} lssvc_view;
+
+/* ---- activation / epilogue selectors ------------------------------------------------------- */
+enum { LSSVC_ACT_NONE = 0, LSSVC_ACT_LRELU = 1, LSSVC_ACT_RELU = 2 };
+enum { LSSVC_INACT_NONE = 0, LSSVC_INACT_LRELU = 1, LSSVC_INACT_SQUARE = 2 };
+/* GDN epilogues: v = conv(x^2, gamma) + beta;  out = one of
+ *   X_MUL_RSQRT : x * (1/sqrt(v))   IntraModules GDN forward      (gdn.py:29-44)
+ *   X_MUL_SQRT  : x * sqrt(v)       both IGDN flavours            (gdn.py:38-39, video_net_component.py:100-101)
+ *   X_DIV_SQRT  : x / sqrt(v)       InterModules GDN forward      (video_net_component.py:102-103) */
+enum { LSSVC_EPI_NONE = 0, LSSVC_EPI_X_MUL_RSQRT = 1, LSSVC_EPI_X_MUL_SQRT = 2, LSSVC_EPI_X_DIV_SQRT = 3 };
+
+#define LSSVC_CONV_MAX_INPUTS 3
+#define LSSVC_CONV_CK 8 /* input channels per K-chunk; each input segment is zero-padded to a multiple */
+
+/*
+ * 2-D convolution as an LDS-tiled implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * Replaces nn.Conv2d / F.conv2d (3x3 s1/s2, 7x7, 1x1, GDN's 1x1), nn.ConvTranspose2d (host rewrites
+ * it as a 2x2 or flipped 3x3 conv) and the torch.cat in front of it (up to 3 input views are read as
+ * one virtual concat), with fused bias, input activation, GDN epilogue, output activation, residual
+ * add, output scale and PixelShuffle(2) store.
+ * Reference call sites: layers.py:36-57, video_net_component.py:11-32,191-210, lssvc_modules.py:15-72.
+ *
+ * weight layout (prepared on the host, see lssvc_amd/weights.py):
+ *   w[chunk][ky][kx][m][8]  with chunk over the CK=8-padded concatenated input channels and
+ *   m over output channels zero-padded to a multiple of 16 (M_pad).
+ * With pixel_shuffle = 1 the m axis must already be permuted to (dy,dx)-major: m = q*(Cout/4) + c.
+ * bias: M_pad floats (same permutation) or NULL.
+ */
+typedef struct lssvc_conv_desc {
+    lssvc_view in[LSSVC_CONV_MAX_INPUTS];
+    int32_t n_in;
+    const float *weight;
+    const float *bias;
+    int32_t KH, KW, stride, pad_t, pad_l;
+    int32_t Cout;  /* true output channels (before pixel shuffle) */
+    int32_t M_pad; /* Cout rounded up to a multiple of 16 */
+    int32_t in_act;
+    float in_slope;
+    int32_t epilogue; /* LSSVC_EPI_* ; needs gdn_x */
+    lssvc_view gdn_x; /* same H,W,Cout as the conv result */
+    int32_t act;
+    float slope;
+    lssvc_view residual; /* added after the activation; ptr NULL = none; same shape as `out` */
+    float out_scale;     /* multiplied last; 1.0f = none */
+    int32_t pixel_shuffle; /* 0 or 1 (r = 2) */
+    lssvc_view out;      /* H_out x W_out x Cout, or 2H_out x 2W_out x Cout/4 with pixel_shuffle */
+} lssvc_conv_desc;
+
+int lssvc_conv2d(const lssvc_conv_desc *d, void *stream);
+
+/* Depthwise 3x3, stride 1, pad 1 (lssvc_modules.py:23-24). weight: [9][C], bias: [C]. */
+int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const float *bias, const lssvc_view *out,
+                    void *stream);
+
+/* F.interpolate(mode='bilinear', align_corners=False) to out->H x out->W, result times `scale`
+ * (layers.py:269,284; lssvc_modules.py:360,393,425; video_net_component.py:355-368 incl. the
+ * "*2.0" / "/2" that always follows it on flows). */
+int lssvc_resize_bilinear(const lssvc_view *in, const lssvc_view *out, float scale, void *stream);
+
+/* flow_warp = grid_sample(bilinear, border, align_corners=True) with the reference's
+ * linspace(-1,1)+flow/((size-1)/2) grid (video_net_component.py:329-352). flow: H x W x 2 (dx,dy). */
+int lssvc_flow_warp(const lssvc_view *in, const lssvc_view *flow, const lssvc_view *out, void *stream);
+
+/* F.avg_pool2d / nn.MaxPool2d, kernel 2 stride 2 (video_net_component.py:230-233, lssvc_modules.py:298). */
+int lssvc_pool2x2(const lssvc_view *in, const lssvc_view *out, int32_t is_max, void *stream);
+
+/* out = a*wa + b*wb, weights = softmax over the 2 channels of `logits` (lssvc_modules.py:133-153 with
+ * LSSVC_net.py:253-255). */
+int lssvc_softmax2_blend(const lssvc_view *a, const lssvc_view *b, const lssvc_view *logits,
+                         const lssvc_view *out, void *stream);
+
+/* out = a + b (channel-sliced views allowed) -- the residual sums outside convs. */
+int lssvc_add(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, void *stream);
+/* out = in (strided copy: materialises a torch.cat slice). */
+int lssvc_copy(const lssvc_view *in, const lssvc_view *out, void *stream);
+/* out = lrelu(in, slope) (the stand-alone nn.LeakyReLU between blocks, e.g. dmc_net.py:178). */
+int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float slope, void *stream);
+
+/* OffsetDiversity tail (lssvc_modules.py:96-110): from the up-sampled conv_offset output `om`
+ * (H x W x 96: o1[32] | o2[32] | mask[32]) and flow (H x W x 2): 32 warps of 3-channel groups of x
+ * (H x W x 48) by 40*tanh(offset)+flow, times sigmoid(mask), then the grouped (g=16) 1x1 fusion
+ * conv (fusion_w: [48][6] as in nn.Conv2d.weight, fusion_b: [48]). The reference's
+ * view(B,96,H,W) channel interleave is reproduced exactly. */
+int lssvc_offset_diversity(const lssvc_view *x, const lssvc_view *om, const lssvc_view *flow,
+                           const float *fusion_w, const float *fusion_b, const lssvc_view *out, void *stream);
+
+/* NCHW (boundary layout of the reference's tensors) <-> NHWC view. */
+int lssvc_nchw_to_nhwc(const float *src, const lssvc_view *dst, void *stream);
+int lssvc_nhwc_to_nchw(const lssvc_view *src, float *dst, void *stream);
+
+/* ---- entropy models ---------------------------------------------------------------------------
+ * Bit counts are accumulated in fp64, deterministically (per-block partials + one final pass, no
+ * float atomics): bits_out[0] = sum over elements. `workspace` must hold lssvc_reduce_workspace_bytes().
+ */
+int64_t lssvc_reduce_workspace_bytes(void);
+
+/* Quantise around a mean and price with a zero-mean Laplace(sigma) (LSSVC_net.py:154-161,
+ * dmc_net.py:370-377,429-431): q = rint(y - mean); y_hat = q + mean;
+ * bits += clamp(-log2(cdf(q+.5) - cdf(q-.5) + 1e-5), 0, 50), sigma clamped to [1e-5, 1e10].
+ * y_q / y_hat may be NULL views (ptr = NULL) when not needed. */
+int lssvc_laplace_quant_bits(const lssvc_view *y, const lssvc_view *mean, const lssvc_view *sigma,
+                             const lssvc_view *y_q, const lssvc_view *y_hat, double *bits_out,
+                             void *workspace, void *stream);
+
+/* One step of the 4-step spatial/channel checkerboard (LSSVC_net.py:288-443). For channel quarter
+ * c (C/4 channels each) only the 2x2 position mask_of_chunk[c] is touched:
+ *   q = rint(y - mean); y_q = q; y_hat = q + mean; sigma_hat = sigma; elsewhere untouched.
+ * y_q / y_hat / sigma_hat accumulate across the 4 steps (host zero-fills before step 1). */
+int lssvc_four_part_step(const lssvc_view *y, const lssvc_view *mean, const lssvc_view *sigma,
+                         const int32_t mask_of_chunk[4], const lssvc_view *y_q, const lssvc_view *y_hat,
+                         const lssvc_view *sigma_hat, void *stream);
+
+/* Laplace bits of already-quantised symbols (LSSVC_net.py:504). */
+int lssvc_laplace_bits(const lssvc_view *y_q, const lssvc_view *sigma, double *bits_out, void *workspace,
+                       void *stream);
+
+/* z_hat = rint(z); bits += clamp(-log2(BitEstimator(z_hat+.5) - BitEstimator(z_hat-.5) + 1e-5), 0, 50)
+ * (LSSVC_net.py:163-167, video_entropy_models.py:110-166). params: [11][C] rows =
+ * softplus(h1),b1,tanh(a1), softplus(h2),b2,tanh(a2), softplus(h3),b3,tanh(a3), softplus(h4),b4. */
+int lssvc_factorized_quant_bits(const lssvc_view *z, const float *params, const lssvc_view *z_hat,
+                                double *bits_out, void *workspace, void *stream);
+
+/* GaussianConditional.forward, eval mode (img_entropy_models.py:650-685): y_hat = round(y-mu)+mu,
+ * lik = .5erfc(-(.5-|v|)/s/sqrt2) - .5erfc(-(-.5-|v|)/s/sqrt2), v = (round(y-mu)+mu)-mu,
+ * s = max(scale, 0.11), lik >= 1e-9; sum_out[0] = sum ln(lik) (natural log; the caller divides
+ * by -ln2 as IntraSS.py:163 does). */
+int lssvc_gaussian_conditional(const lssvc_view *y, const lssvc_view *scale, const lssvc_view *mean,
+                               const lssvc_view *y_hat, double *sum_out, void *workspace, void *stream);
+
+/* EntropyBottleneck.forward, eval mode (img_entropy_models.py:483-554): z_hat = round(z-med)+med,
+ * lik = |sigmoid(s*u) - sigmoid(s*l)| >= 1e-9 with the 1-3-3-3-3-1 per-channel MLP.
+ * params: [58][C] rows = softplus(matrices) (3+9+9+9+3), biases (3+3+3+3+1), tanh(factors) (3*4), median. */
+int lssvc_entropy_bottleneck(const lssvc_view *z, const float *params, const lssvc_view *z_hat,
+                             double *sum_out, void *workspace, void *stream);
+
+/* sigma -> CDF-table index planes for the host coder (video_entropy_models.py:309-313,
+ * img_entropy_models.py:687-691): idx = clamp((ln max(s,1e-5) - ln smin)/step + add, 0, levels-1). */
+int lssvc_build_indexes(const lssvc_view *sigma, float log_min, float log_step, float add, int32_t levels,
+                        int32_t *idx_nhwc, void *stream);
+
+const char *lssvc_last_error(void);
+int lssvc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSSVC_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of liblssvc_hip.so (the C ABI declared in include/lssvc_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol cannot be
+resolved, importing this module raises -- loudly -- instead of silently computing elsewhere.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblssvc_hip.so")
+
+CONV_MAX_INPUTS = 3
+CONV_CK = 8
+
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+INACT_NONE, INACT_LRELU, INACT_SQUARE = 0, 1, 2
+EPI_NONE, EPI_X_MUL_RSQRT, EPI_X_MUL_SQRT, EPI_X_DIV_SQRT = 0, 1, 2, 3
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("ld", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("inp", View * CONV_MAX_INPUTS), ("n_in", C.c_int32),
+        ("weight", C.c_void_p), ("bias", C.c_void_p),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("Cout", C.c_int32), ("M_pad", C.c_int32),
+        ("in_act", C.c_int32), ("in_slope", C.c_float),
+        ("epilogue", C.c_int32), ("gdn_x", View),
+        ("act", C.c_int32), ("slope", C.c_float),
+        ("residual", View), ("out_scale", C.c_float),
+        ("pixel_shuffle", C.c_int32), ("out", View),
+    ]
+
+
+VP = C.POINTER(View)
+
+# name -> (restype, argtypes); every symbol include/lssvc_hip.h declares
+SIGNATURES = {
+    "lssvc_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "lssvc_dwconv3x3": (C.c_int, [VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
+    "lssvc_resize_bilinear": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
+    "lssvc_flow_warp": (C.c_int, [VP, VP, VP, C.c_void_p]),
+    "lssvc_pool2x2": (C.c_int, [VP, VP, C.c_int32, C.c_void_p]),
+    "lssvc_softmax2_blend": (C.c_int, [VP, VP, VP, VP, C.c_void_p]),
+    "lssvc_add": (C.c_int, [VP, VP, VP, C.c_void_p]),
+    "lssvc_copy": (C.c_int, [VP, VP, C.c_void_p]),
+    "lssvc_lrelu": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
+    "lssvc_offset_diversity": (C.c_int, [VP, VP, VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
+    "lssvc_nchw_to_nhwc": (C.c_int, [C.c_void_p, VP, C.c_void_p]),
+    "lssvc_nhwc_to_nchw": (C.c_int, [VP, C.c_void_p, C.c_void_p]),
+    "lssvc_reduce_workspace_bytes": (C.c_int64, []),
+    "lssvc_laplace_quant_bits": (C.c_int, [VP, VP, VP, VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_four_part_step": (C.c_int, [VP, VP, VP, C.POINTER(C.c_int32), VP, VP, VP, C.c_void_p]),
+    "lssvc_laplace_bits": (C.c_int, [VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_factorized_quant_bits": (C.c_int, [VP, C.c_void_p, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_gaussian_conditional": (C.c_int, [VP, VP, VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_entropy_bottleneck": (C.c_int, [VP, C.c_void_p, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_build_indexes": (C.c_int, [VP, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lssvc_last_error": (C.c_char_p, []),
+    "lssvc_version": (C.c_int, []),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "liblssvc_hip.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C lssvc_amd/csrc). There is no CPU fallback for the LSSVC hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class LssvcHipError(RuntimeError):
+    pass
+
+
+def check(status):
+    if status != 0:
+        raise LssvcHipError(lib.lssvc_last_error().decode("utf-8", "replace"))

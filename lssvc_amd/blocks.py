@@ -1,0 +1,147 @@
+"""LSSVC's NN building blocks expressed as sequences of fused HIP ops (NHWC, fp32).
+
+Each function mirrors one reference nn.Module (cited per function) but is laid out for the
+MI355X kernels: torch.cat in front of a conv becomes a multi-input conv, PixelShuffle is the conv's
+store pattern, bias / LeakyReLU / residual adds / GDN normalisation are conv epilogues, channel
+chunk() is a strided view. `W` is a weights.WeightStore, `p` the state-dict prefix of the module.
+"""
+from . import hip_ops as ops
+from .hip_ops import T
+
+
+def res_block(W, p, x, slope=0.01, start_from_relu=True, end_with_relu=False, out=None):
+    """ResBlock (layers.py:229-255, video_net_component.py:170-188): x + [lrelu]conv2(lrelu(conv1([lrelu]x)))."""
+    t = ops.conv(W, p + ".conv1", x, in_act="lrelu" if start_from_relu else None, in_slope=slope, act="lrelu", slope=slope)
+    return ops.conv(W, p + ".conv2", t, act="lrelu" if end_with_relu else None, slope=slope, residual=x, out=out)
+
+
+def residual_block(W, p, x):
+    """ResidualBlock (layers.py:122-145): lrelu(conv2(lrelu(conv1 x))) + x."""
+    t = ops.conv(W, p + ".conv1", x, act="lrelu")
+    return ops.conv(W, p + ".conv2", t, act="lrelu", residual=x)
+
+
+def residual_block_with_stride(W, p, x):
+    """ResidualBlockWithStride (layers.py:60-91): GDN(conv2(lrelu(conv1_s2 x))) + conv1x1_s2(x)."""
+    t = ops.conv(W, p + ".conv1", x, stride=2, act="lrelu")
+    t = ops.conv(W, p + ".conv2", t)
+    skip = ops.conv(W, p + ".downsample", x, stride=2, pad=0)
+    return ops.gdn(W, p + ".gdn", t, "intra", residual=skip)
+
+
+def residual_block_upsample(W, p, x):
+    """ResidualBlockUpsample (layers.py:94-119): IGDN(conv(lrelu(subpel x))) + subpel'(x)."""
+    t = ops.subpel(W, p + ".subpel_conv", x, act="lrelu")
+    t = ops.conv(W, p + ".conv", t)
+    skip = ops.subpel(W, p + ".upsample", x)
+    return ops.gdn(W, p + ".igdn", t, "intra", inverse=True, residual=skip)
+
+
+def depth_conv_block(W, p, inputs, out=None):
+    """DepthConvBlock (lssvc_modules.py:15-72). `inputs` may be a list (virtual concat) when the
+    block has a 1x1 adaptor (Cin != Cout); otherwise a single T (it is also the identity branch)."""
+    q = p + ".block.0"
+    if W.has(q + ".adaptor.weight"):
+        ident = ops.conv(W, q + ".adaptor", inputs)
+    else:
+        assert isinstance(inputs, T), "DepthConv without adaptor needs a materialised input"
+        ident = inputs
+    t = ops.conv(W, q + ".conv1.0", inputs, act="lrelu", slope=0.01)
+    t = ops.dwconv3x3(W, q + ".depth_conv", t)
+    o1 = ops.conv(W, q + ".conv2", t, residual=ident)
+    f = p + ".block.1"
+    t = ops.conv(W, f + ".conv.0", o1, act="lrelu", slope=0.1)
+    return ops.conv(W, f + ".conv.2", t, act="lrelu", slope=0.1, residual=o1, out=out)
+
+
+def pyramid_extractor(W, p, f):
+    """MultiScaleTextureExtractor / FeatureExtractor / TextureExtractor (layers.py:288-308,
+    dmc_net.py:11-31, lssvc_modules.py:157-200): conv+ResBlock at 1x, 1/2, 1/4."""
+    l1 = res_block(W, p + ".res_block1", ops.conv(W, p + ".conv1", f))
+    l2 = res_block(W, p + ".res_block2", ops.conv(W, p + ".conv2", l1, stride=2))
+    l3 = res_block(W, p + ".res_block3", ops.conv(W, p + ".conv3", l2, stride=2))
+    return l1, l2, l3
+
+
+def context_fusion(W, p, t1, t2, t3, outs=(None, None, None)):
+    """MultiScaleTextureFusion / MultiScaleContextFusion (layers.py:311-339, dmc_net.py:34-62,
+    lssvc_modules.py:203-232). `outs` lets the caller place the three results (e.g. into concat slices)."""
+    c3_up = res_block(W, p + ".res_block3_up", ops.subpel(W, p + ".conv3_up", t3))
+    c3_out = res_block(W, p + ".res_block3_out", ops.conv(W, p + ".conv3_out", t3))
+    c2_up = res_block(W, p + ".res_block2_up", ops.subpel(W, p + ".conv2_up", [c3_up, t2]))
+    c2_out = res_block(W, p + ".res_block2_out", ops.conv(W, p + ".conv2_out", [c3_up, t2]))
+    c1_out = res_block(W, p + ".res_block1_out", ops.conv(W, p + ".conv1_out", [c2_up, t1]))
+    return ops.add(t1, c1_out, out=outs[0]), ops.add(t2, c2_out, out=outs[1]), ops.add(t3, c3_out, out=outs[2])
+
+
+def res_encoder_gdn(W, p, x, c1, c2, c3, flavour):
+    """Contextual analysis transform with GDN: Intra ResEncoder (layers.py:342-367) and DMC ResEncoder
+    (dmc_net.py:65-90). The concat that feeds each bottleneck ResBlock is materialised in place: the GDN
+    writes its half of the wide buffer, the context is copied into the other half."""
+    dev = x.device
+    t = ops.conv(W, p + ".conv1", [x, c1], stride=2)
+    n = t.C
+    wide = T.empty(t.H, t.W, n + c2.C, dev)
+    ops.gdn(W, p + ".gdn1", t, flavour, out=wide.slice(0, n))
+    ops.copy(c2, wide.slice(n, n + c2.C))
+    f = res_block(W, p + ".res1", wide, slope=0.1, start_from_relu=False, end_with_relu=True)
+    t = ops.conv(W, p + ".conv2", f, stride=2)
+    n = t.C
+    wide = T.empty(t.H, t.W, n + c3.C, dev)
+    ops.gdn(W, p + ".gdn2", t, flavour, out=wide.slice(0, n))
+    ops.copy(c3, wide.slice(n, n + c3.C))
+    f = res_block(W, p + ".res2", wide, slope=0.1, start_from_relu=False, end_with_relu=True)
+    t = ops.gdn(W, p + ".gdn3", ops.conv(W, p + ".conv3", f, stride=2), flavour)
+    return ops.conv(W, p + ".conv4", t, stride=2)
+
+
+def res_decoder_gdn(W, p, y_hat, c2, c3, flavour):
+    """Contextual synthesis transform with IGDN (layers.py:370-395, dmc_net.py:93-118)."""
+    dev = y_hat.device
+    t = ops.gdn(W, p + ".gdn1", ops.subpel(W, p + ".up1", y_hat), flavour, inverse=True)
+    t = ops.subpel(W, p + ".up2", t)
+    n = t.C
+    wide = T.empty(t.H, t.W, n + c3.C, dev)
+    ops.gdn(W, p + ".gdn2", t, flavour, inverse=True, out=wide.slice(0, n))
+    ops.copy(c3, wide.slice(n, n + c3.C))
+    f = res_block(W, p + ".res1", wide, slope=0.1, start_from_relu=False, end_with_relu=True)
+    t = ops.subpel(W, p + ".up3", f)
+    n = t.C
+    wide = T.empty(t.H, t.W, n + c2.C, dev)
+    ops.gdn(W, p + ".gdn3", t, flavour, inverse=True, out=wide.slice(0, n))
+    ops.copy(c2, wide.slice(n, n + c2.C))
+    f = res_block(W, p + ".res2", wide, slope=0.1, start_from_relu=False, end_with_relu=True)
+    return ops.subpel(W, p + ".up4", f)
+
+
+def recon_generation(W, p, res, ctx1):
+    """ReconGeneration(res, ctx1) -> (feature, recon) (layers.py:398-411 / dmc_net.py:143-156; the callers
+    pass (res_hat, context1), IntraSS.py:161, dmc_net.py:452, so the concat order is res first)."""
+    f = ops.conv(W, p + ".feature_conv.0", [res, ctx1])
+    f = res_block(W, p + ".feature_conv.1", f)
+    f = res_block(W, p + ".feature_conv.2", f)
+    return f, ops.conv(W, p + ".recon_conv", f)
+
+
+def spynet(W, p, im1, im2):
+    """ME_Spynet / ME_Spynet_DCVC (video_net_component.py:213-248,292-326)."""
+    levels = 4
+    l1, l2 = [im1], [im2]
+    for i in range(levels - 1):
+        l1.append(ops.pool2x2(l1[i], is_max=False))
+        l2.append(ops.pool2x2(l2[i], is_max=False))
+    coarse = l2[levels - 1]
+    flow = T.zeros(coarse.H // 2, coarse.W // 2, 2, im1.device)
+    for lvl in range(levels):
+        a, b = l1[levels - 1 - lvl], l2[levels - 1 - lvl]
+        x = T.empty(a.H, a.W, 8, im1.device)          # cat(im1, warp(im2, up), up): 3 + 3 + 2 channels
+        up = ops.resize(flow, flow.H * 2, flow.W * 2, scale=2.0, out=x.slice(6, 8))
+        ops.copy(a, x.slice(0, 3))
+        ops.flow_warp(b, up, out=x.slice(3, 6))
+        m = "%s.moduleBasic.%d" % (p, lvl)
+        t = ops.conv(W, m + ".conv1", x, act="relu")
+        t = ops.conv(W, m + ".conv2", t, act="relu")
+        t = ops.conv(W, m + ".conv3", t, act="relu")
+        t = ops.conv(W, m + ".conv4", t, act="relu")
+        flow = ops.conv(W, m + ".conv5", t, residual=up)
+    return flow

@@ -1,0 +1,322 @@
+// entropy.hip -- quantisation + likelihood / bit-count kernels of LSSVC's entropy models (gfx950).
+//
+// Every kernel evaluates the per-element CDF difference in fp32 exactly as the reference's ATen op
+// sequence does (-ffp-contract=off), then accumulates in fp64: lane -> wavefront (DPP shuffles) ->
+// workgroup (LDS) -> one partial per workgroup in a workspace; a second single-workgroup pass sums
+// the partials in index order. No float atomics: the result is bit-reproducible run to run, which
+// the encoder/decoder symmetry of write_stream=1 relies on.
+#include "common.h"
+
+namespace lssvc {
+
+constexpr float kLn2f = 0.6931471805599453f;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// blockDim = 256. Returns the workgroup total in thread 0.
+__device__ __forceinline__ double block_sum(double v) {
+    __shared__ double part[4];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) t = part[0] + part[1] + part[2] + part[3];
+    return t;
+}
+
+__global__ void reduce_final_kernel(const double *__restrict__ partials, int n, double *__restrict__ out) {
+    // fixed order: thread t sums partials t, t+256, ... then the block tree is fixed too
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    const double t = block_sum(v);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+static inline unsigned reduce_blocks(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > kReduceMaxBlocks) b = kReduceMaxBlocks;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ---- Laplace -------------------------------------------------------------------------------------
+// torch.distributions.Laplace(0, s).cdf(v) = 0.5 - 0.5 * sign(v) * expm1(-|v| / s)
+__device__ __forceinline__ float laplace_cdf(float v, float s) {
+    const float sg = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+    return 0.5f - 0.5f * sg * expm1f(-fabsf(v) / s);
+}
+__device__ __forceinline__ float laplace_bits_of(float q, float sigma) {
+    const float s = fminf(fmaxf(sigma, 1e-5f), 1e10f);
+    const float probs = laplace_cdf(q + 0.5f, s) - laplace_cdf(q - 0.5f, s);
+    float b = -1.0f * logf(probs + 1e-5f) / kLn2f;
+    return fminf(fmaxf(b, 0.f), 50.f);
+}
+
+// mode 0: quantise y around mean, write y_q / y_hat (if given), price; mode 1: y already holds symbols
+__global__ void laplace_kernel(V y, V mean, V sigma, V y_q, V y_hat, int mode, long long total, double *partials) {
+    double acc = 0.0;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % y.C);
+        const size_t pix = (size_t)(idx / y.C);
+        float q;
+        if (mode == 0) {
+            const float mu = mean.p[pix * mean.ld + c];
+            q = rintf(y.p[pix * y.ld + c] - mu);
+            if (y_q.p) y_q.p[pix * y_q.ld + c] = q;
+            if (y_hat.p) y_hat.p[pix * y_hat.ld + c] = q + mu;
+        } else {
+            q = y.p[pix * y.ld + c];
+        }
+        acc += (double)laplace_bits_of(q, sigma.p[pix * sigma.ld + c]);
+    }
+    const double t = block_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// ---- 4-step checkerboard -------------------------------------------------------------------------
+__global__ void four_part_kernel(V y, V mean, V sigma, int m0, int m1, int m2, int m3, V y_q, V y_hat, V s_hat,
+                                 long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % y.C);
+    const size_t pix = (size_t)(idx / y.C);
+    const int x = (int)(pix % y.W), yy = (int)(pix / y.W);
+    const int chunk = c / (y.C >> 2);
+    const int m = chunk == 0 ? m0 : (chunk == 1 ? m1 : (chunk == 2 ? m2 : m3));
+    if ((yy & 1) != (m >> 1) || (x & 1) != (m & 1)) return;
+    const float mu = mean.p[pix * mean.ld + c];
+    const float q = rintf(y.p[pix * y.ld + c] - mu);
+    y_q.p[pix * y_q.ld + c] = q;
+    y_hat.p[pix * y_hat.ld + c] = q + mu;
+    s_hat.p[pix * s_hat.ld + c] = sigma.p[pix * sigma.ld + c];
+}
+
+// ---- BitEstimator (factorised prior of the P-frame hyper latents) --------------------------------
+// params [11][C]: sp_h1,b1,ta1, sp_h2,b2,ta2, sp_h3,b3,ta3, sp_h4,b4
+__device__ __forceinline__ float bit_estimator(float x, const float *__restrict__ P, int C, int c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        x = x * P[(3 * i) * C + c] + P[(3 * i + 1) * C + c];
+        x = x + tanhf(x) * P[(3 * i + 2) * C + c];
+    }
+    x = x * P[9 * C + c] + P[10 * C + c];
+    return 1.f / (1.f + expf(-x));
+}
+__global__ void factorized_kernel(V z, const float *__restrict__ P, V z_hat, long long total, double *partials) {
+    double acc = 0.0;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % z.C);
+        const size_t pix = (size_t)(idx / z.C);
+        const float q = rintf(z.p[pix * z.ld + c]);
+        if (z_hat.p) z_hat.p[pix * z_hat.ld + c] = q;
+        const float prob = bit_estimator(q + 0.5f, P, z.C, c) - bit_estimator(q - 0.5f, P, z.C, c);
+        float b = -1.0f * logf(prob + 1e-5f) / kLn2f;
+        acc += (double)fminf(fmaxf(b, 0.f), 50.f);
+    }
+    const double t = block_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// ---- GaussianConditional (I-frame y) --------------------------------------------------------------
+__global__ void gaussian_kernel(V y, V scale, V mean, V y_hat, long long total, double *partials) {
+    const float kC = -0.70710678118654752440f;  // float(-(2 ** -0.5))
+    double acc = 0.0;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % y.C);
+        const size_t pix = (size_t)(idx / y.C);
+        const float mu = mean.p[pix * mean.ld + c];
+        const float out = rintf(y.p[pix * y.ld + c] - mu) + mu;
+        if (y_hat.p) y_hat.p[pix * y_hat.ld + c] = out;
+        const float v = fabsf(out - mu);
+        const float s = fmaxf(scale.p[pix * scale.ld + c], 0.11f);
+        const float upper = 0.5f * erfcf(kC * ((0.5f - v) / s));
+        const float lower = 0.5f * erfcf(kC * ((-0.5f - v) / s));
+        const float lik = fmaxf(upper - lower, 1e-9f);
+        acc += (double)logf(lik);
+    }
+    const double t = block_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// ---- EntropyBottleneck (I-frame z) ----------------------------------------------------------------
+// params [59][C]: m0[3] m1[3][3] m2[3][3] m3[3][3] m4[3] | b0[3] b1[3] b2[3] b3[3] b4[1] | f0[3] f1[3] f2[3] f3[3] | median
+__device__ __forceinline__ float eb_logits(float v, const float *__restrict__ P, int C, int c) {
+    auto R = [&](int row) { return P[row * C + c]; };
+    float l[3], n[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float t = R(j) * v + R(33 + j);
+        l[j] = t + R(46 + j) * tanhf(t);
+    }
+#pragma unroll
+    for (int layer = 1; layer <= 3; ++layer) {
+        const int mb = 3 + (layer - 1) * 9, bb = 33 + 3 * layer, fb = 46 + 3 * layer;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float t = R(mb + 3 * j) * l[0];
+            t = fmaf(R(mb + 3 * j + 1), l[1], t);
+            t = fmaf(R(mb + 3 * j + 2), l[2], t);
+            t = t + R(bb + j);
+            n[j] = t + R(fb + j) * tanhf(t);
+        }
+        l[0] = n[0]; l[1] = n[1]; l[2] = n[2];
+    }
+    float t = R(30) * l[0];
+    t = fmaf(R(31), l[1], t);
+    t = fmaf(R(32), l[2], t);
+    return t + R(45);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void bottleneck_kernel(V z, const float *__restrict__ P, V z_hat, long long total, double *partials) {
+    double acc = 0.0;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % z.C);
+        const size_t pix = (size_t)(idx / z.C);
+        const float med = P[58 * z.C + c];
+        const float out = rintf(z.p[pix * z.ld + c] - med) + med;
+        if (z_hat.p) z_hat.p[pix * z_hat.ld + c] = out;
+        const float lower = eb_logits(out - 0.5f, P, z.C, c);
+        const float upper = eb_logits(out + 0.5f, P, z.C, c);
+        const float sum = lower + upper;
+        const float sg = -((sum > 0.f) ? 1.f : ((sum < 0.f) ? -1.f : 0.f));
+        const float lik = fmaxf(fabsf(sigmoidf_(sg * upper) - sigmoidf_(sg * lower)), 1e-9f);
+        acc += (double)logf(lik);
+    }
+    const double t = block_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// ---- sigma -> table index --------------------------------------------------------------------------
+__global__ void build_indexes_kernel(V sigma, float log_min, float log_step, float add, int levels, int32_t *idx_out,
+                                     long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % sigma.C);
+    const size_t pix = (size_t)(idx / sigma.C);
+    const float s = fmaxf(sigma.p[pix * sigma.ld + c], 1e-5f);
+    float v = (logf(s) - log_min) / log_step + add;
+    v = fminf(fmaxf(v, 0.f), (float)(levels - 1));
+    idx_out[pix * sigma.C + c] = (int32_t)v;
+}
+
+}  // namespace lssvc
+
+using namespace lssvc;
+
+extern "C" int64_t lssvc_reduce_workspace_bytes(void) { return (int64_t)kReduceMaxBlocks * sizeof(double); }
+
+static int finish_reduce(unsigned blocks, void *workspace, double *out, hipStream_t st, const char *what) {
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, (const double *)workspace, (int)blocks, out);
+    return launch_status(what);
+}
+static V opt(const lssvc_view *v) { return (v && v->ptr) ? mk(v) : mk_null(); }
+
+extern "C" int lssvc_laplace_quant_bits(const lssvc_view *y, const lssvc_view *mean, const lssvc_view *sigma,
+                                        const lssvc_view *y_q, const lssvc_view *y_hat, double *bits_out, void *workspace,
+                                        void *stream) {
+    LSSVC_CHECK(view_ok(y) && view_ok(mean) && view_ok(sigma) && bits_out && workspace, "laplace_quant_bits: bad arguments");
+    LSSVC_CHECK(same_shape(y, mean) && same_shape(y, sigma), "laplace_quant_bits: shape mismatch");
+    LSSVC_CHECK((!y_q || !y_q->ptr || same_shape(y, y_q)) && (!y_hat || !y_hat->ptr || same_shape(y, y_hat)),
+                "laplace_quant_bits: output shape mismatch");
+    const long long total = (long long)y->H * y->W * y->C;
+    const unsigned blocks = reduce_blocks(total);
+    hipLaunchKernelGGL(laplace_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mk(y), mk(mean), mk(sigma), opt(y_q),
+                       opt(y_hat), 0, total, (double *)workspace);
+    if (int e = launch_status("laplace_quant_bits")) return e;
+    return finish_reduce(blocks, workspace, bits_out, (hipStream_t)stream, "laplace_quant_bits/reduce");
+}
+
+extern "C" int lssvc_laplace_bits(const lssvc_view *y_q, const lssvc_view *sigma, double *bits_out, void *workspace,
+                                  void *stream) {
+    LSSVC_CHECK(view_ok(y_q) && view_ok(sigma) && bits_out && workspace, "laplace_bits: bad arguments");
+    LSSVC_CHECK(same_shape(y_q, sigma), "laplace_bits: shape mismatch");
+    const long long total = (long long)y_q->H * y_q->W * y_q->C;
+    const unsigned blocks = reduce_blocks(total);
+    hipLaunchKernelGGL(laplace_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mk(y_q), mk_null(), mk(sigma),
+                       mk_null(), mk_null(), 1, total, (double *)workspace);
+    if (int e = launch_status("laplace_bits")) return e;
+    return finish_reduce(blocks, workspace, bits_out, (hipStream_t)stream, "laplace_bits/reduce");
+}
+
+extern "C" int lssvc_four_part_step(const lssvc_view *y, const lssvc_view *mean, const lssvc_view *sigma,
+                                    const int32_t mask_of_chunk[4], const lssvc_view *y_q, const lssvc_view *y_hat,
+                                    const lssvc_view *sigma_hat, void *stream) {
+    LSSVC_CHECK(view_ok(y) && view_ok(mean) && view_ok(sigma) && view_ok(y_q) && view_ok(y_hat) && view_ok(sigma_hat) && mask_of_chunk,
+                "four_part_step: bad arguments");
+    LSSVC_CHECK(y->C % 4 == 0 && same_shape(y, mean) && same_shape(y, sigma) && same_shape(y, y_q) && same_shape(y, y_hat) &&
+                    same_shape(y, sigma_hat), "four_part_step: shape mismatch");
+    for (int i = 0; i < 4; ++i) LSSVC_CHECK(mask_of_chunk[i] >= 0 && mask_of_chunk[i] < 4, "four_part_step: mask %d", mask_of_chunk[i]);
+    const long long total = (long long)y->H * y->W * y->C;
+    hipLaunchKernelGGL(four_part_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mk(y), mk(mean),
+                       mk(sigma), mask_of_chunk[0], mask_of_chunk[1], mask_of_chunk[2], mask_of_chunk[3], mk(y_q), mk(y_hat),
+                       mk(sigma_hat), total);
+    return launch_status("four_part_step");
+}
+
+extern "C" int lssvc_factorized_quant_bits(const lssvc_view *z, const float *params, const lssvc_view *z_hat, double *bits_out,
+                                           void *workspace, void *stream) {
+    LSSVC_CHECK(view_ok(z) && params && bits_out && workspace, "factorized_quant_bits: bad arguments");
+    LSSVC_CHECK(!z_hat || !z_hat->ptr || same_shape(z, z_hat), "factorized_quant_bits: z_hat shape mismatch");
+    const long long total = (long long)z->H * z->W * z->C;
+    const unsigned blocks = reduce_blocks(total);
+    hipLaunchKernelGGL(factorized_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mk(z), params, opt(z_hat), total,
+                       (double *)workspace);
+    if (int e = launch_status("factorized_quant_bits")) return e;
+    return finish_reduce(blocks, workspace, bits_out, (hipStream_t)stream, "factorized_quant_bits/reduce");
+}
+
+extern "C" int lssvc_gaussian_conditional(const lssvc_view *y, const lssvc_view *scale, const lssvc_view *mean,
+                                          const lssvc_view *y_hat, double *sum_out, void *workspace, void *stream) {
+    LSSVC_CHECK(view_ok(y) && view_ok(scale) && view_ok(mean) && sum_out && workspace, "gaussian_conditional: bad arguments");
+    LSSVC_CHECK(same_shape(y, scale) && same_shape(y, mean) && (!y_hat || !y_hat->ptr || same_shape(y, y_hat)),
+                "gaussian_conditional: shape mismatch");
+    const long long total = (long long)y->H * y->W * y->C;
+    const unsigned blocks = reduce_blocks(total);
+    hipLaunchKernelGGL(gaussian_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mk(y), mk(scale), mk(mean), opt(y_hat),
+                       total, (double *)workspace);
+    if (int e = launch_status("gaussian_conditional")) return e;
+    return finish_reduce(blocks, workspace, sum_out, (hipStream_t)stream, "gaussian_conditional/reduce");
+}
+
+extern "C" int lssvc_entropy_bottleneck(const lssvc_view *z, const float *params, const lssvc_view *z_hat, double *sum_out,
+                                        void *workspace, void *stream) {
+    LSSVC_CHECK(view_ok(z) && params && sum_out && workspace, "entropy_bottleneck: bad arguments");
+    LSSVC_CHECK(!z_hat || !z_hat->ptr || same_shape(z, z_hat), "entropy_bottleneck: z_hat shape mismatch");
+    const long long total = (long long)z->H * z->W * z->C;
+    const unsigned blocks = reduce_blocks(total);
+    hipLaunchKernelGGL(bottleneck_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mk(z), params, opt(z_hat), total,
+                       (double *)workspace);
+    if (int e = launch_status("entropy_bottleneck")) return e;
+    return finish_reduce(blocks, workspace, sum_out, (hipStream_t)stream, "entropy_bottleneck/reduce");
+}
+
+extern "C" int lssvc_build_indexes(const lssvc_view *sigma, float log_min, float log_step, float add, int32_t levels,
+                                   int32_t *idx_nhwc, void *stream) {
+    LSSVC_CHECK(view_ok(sigma) && idx_nhwc && levels > 0 && log_step > 0.f, "build_indexes: bad arguments");
+    const long long total = (long long)sigma->H * sigma->W * sigma->C;
+    hipLaunchKernelGGL(build_indexes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mk(sigma),
+                       log_min, log_step, add, levels, idx_nhwc, total);
+    return launch_status("build_indexes");
+}
+
+// ---- error plumbing ---------------------------------------------------------------------------------
+namespace lssvc {
+char *err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+}  // namespace lssvc
+extern "C" const char *lssvc_last_error(void) { return lssvc::err_buf(); }
+extern "C" int lssvc_version(void) { return 1; }

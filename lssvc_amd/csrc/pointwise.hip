@@ -1,0 +1,425 @@
+// pointwise.hip -- the HBM-bound kernels of the LSSVC hot path (gfx950): depthwise 3x3, bilinear
+// resize, flow warp, 2x2 pooling, softmax-2 blend, adds/copies, the fused OffsetDiversity tail and
+// the NCHW<->NHWC boundary transposes. All work on NHWC views; one thread handles 4 consecutive
+// channels of one pixel (16-byte accesses) whenever the views allow it, so a wave reads/writes
+// contiguous 1-KiB runs when C >= 64 and whole pixels otherwise.
+//
+// Compiled with -ffp-contract=off: the reference evaluates these as separate ATen ops (mul, add, ...),
+// so no FMA contraction is allowed if results are to track the fp32 CPU oracle.
+#include "common.h"
+
+namespace lssvc {
+
+__device__ __forceinline__ float4 ld4(const V &v, size_t pix, int c, bool vec) {
+    const float *s = v.p + pix * v.ld + c;
+    if (vec) return *reinterpret_cast<const float4 *>(s);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.x = s[0];
+    if (c + 1 < v.C) r.y = s[1];
+    if (c + 2 < v.C) r.z = s[2];
+    if (c + 3 < v.C) r.w = s[3];
+    return r;
+}
+__device__ __forceinline__ void st4(const V &v, size_t pix, int c, bool vec, float4 r) {
+    float *d = v.p + pix * v.ld + c;
+    if (vec) {
+        *reinterpret_cast<float4 *>(d) = r;
+        return;
+    }
+    d[0] = r.x;
+    if (c + 1 < v.C) d[1] = r.y;
+    if (c + 2 < v.C) d[2] = r.z;
+    if (c + 3 < v.C) d[3] = r.w;
+}
+
+// Generic launch geometry: total = H*W*ceil(C/4) items, 256 threads per block.
+struct Items {
+    long long total;
+    int cg;  // channel groups of 4
+};
+static inline Items items_of(const lssvc_view *v) {
+    Items it;
+    it.cg = (v->C + 3) / 4;
+    it.total = (long long)v->H * v->W * it.cg;
+    return it;
+}
+static inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
+
+// ------------------------------------------------------------------------------------------------
+// depthwise 3x3, stride 1, zero pad 1; weight [9][C]
+__global__ void dwconv3x3_kernel(V in, const float *__restrict__ w, const float *__restrict__ bias, V out, int cg,
+                                 long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const long long pix = idx / cg;
+    const int x = (int)(pix % in.W), y = (int)(pix / in.W);
+    const int c = g * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        if (yy < 0 || yy >= in.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + kx - 1;
+            if (xx < 0 || xx >= in.W) continue;
+            const float4 v = *reinterpret_cast<const float4 *>(in.p + ((size_t)yy * in.W + xx) * in.ld + c);
+            const float4 k = *reinterpret_cast<const float4 *>(w + (ky * 3 + kx) * in.C + c);
+            acc.x = fmaf(v.x, k.x, acc.x);
+            acc.y = fmaf(v.y, k.y, acc.y);
+            acc.z = fmaf(v.z, k.z, acc.z);
+            acc.w = fmaf(v.w, k.w, acc.w);
+        }
+    }
+    const float4 b = *reinterpret_cast<const float4 *>(bias + c);
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    *reinterpret_cast<float4 *>(out.p + (size_t)pix * out.ld + c) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=False (ATen area_pixel_compute_source_index + guard_index_and_lambda)
+__device__ __forceinline__ void src_index(float scale, int dst, int size, int &i0, int &i1, float &l0, float &l1) {
+    float real = scale * (dst + 0.5f) - 0.5f;
+    if (real < 0.f) real = 0.f;
+    int idx = (int)real;
+    if (idx > size - 1) idx = size - 1;
+    float lam = real - (float)idx;
+    lam = fminf(fmaxf(lam, 0.f), 1.f);
+    i0 = idx;
+    i1 = idx + (idx < size - 1 ? 1 : 0);
+    l1 = lam;
+    l0 = 1.f - lam;
+}
+
+__global__ void resize_bilinear_kernel(V in, V out, float sy, float sx, float post, int cg, long long total, int vin,
+                                       int vout) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const long long pix = idx / cg;
+    const int x = (int)(pix % out.W), y = (int)(pix / out.W);
+    const int c = g * 4;
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    src_index(sy, y, in.H, y0, y1, hy0, hy1);
+    src_index(sx, x, in.W, x0, x1, wx0, wx1);
+    const float4 a = ld4(in, (size_t)y0 * in.W + x0, c, vin);
+    const float4 b = ld4(in, (size_t)y0 * in.W + x1, c, vin);
+    const float4 d = ld4(in, (size_t)y1 * in.W + x0, c, vin);
+    const float4 e = ld4(in, (size_t)y1 * in.W + x1, c, vin);
+    float4 r;
+    r.x = hy0 * (wx0 * a.x + wx1 * b.x) + hy1 * (wx0 * d.x + wx1 * e.x);
+    r.y = hy0 * (wx0 * a.y + wx1 * b.y) + hy1 * (wx0 * d.y + wx1 * e.y);
+    r.z = hy0 * (wx0 * a.z + wx1 * b.z) + hy1 * (wx0 * d.z + wx1 * e.z);
+    r.w = hy0 * (wx0 * a.w + wx1 * b.w) + hy1 * (wx0 * d.w + wx1 * e.w);
+    if (post != 1.0f) { r.x *= post; r.y *= post; r.z *= post; r.w *= post; }
+    st4(out, (size_t)pix, c, vout, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// flow warp = grid_sample(bilinear, border, align_corners=True) on the reference's normalised grid.
+struct Bilin {
+    int x0, x1, y0, y1;
+    float nw, ne, sw, se;
+};
+// linspace(-1, 1, n)[i] as ATen's CPU kernel computes it (two-sided, fp32 step)
+__device__ __forceinline__ float linspace_m1_1(int i, int n) {
+    const float step = 2.0f / (float)(n - 1);
+    return (i < n / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+__device__ __forceinline__ Bilin warp_coords(int x, int y, float fx, float fy, int W, int H) {
+    // torch_warp: grid = linspace + flow / ((size-1)/2)        (video_net_component.py:333-342)
+    const float gx = linspace_m1_1(x, W) + fx / ((float)(((double)W - 1.0) / 2.0));
+    const float gy = linspace_m1_1(y, H) + fy / ((float)(((double)H - 1.0) / 2.0));
+    // grid_sample, align_corners=True: ((g + 1) * (size-1)/2), border clip, floor + lerp weights
+    float ix = (gx + 1.f) * ((float)(W - 1) / 2.f);
+    float iy = (gy + 1.f) * ((float)(H - 1) / 2.f);
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float w = ix - xw, e = 1.f - w, n = iy - yn, s = 1.f - n;
+    Bilin b;
+    b.nw = s * e; b.ne = s * w; b.sw = n * e; b.se = n * w;
+    b.x0 = (int)xw; b.y0 = (int)yn;
+    b.x1 = min(b.x0 + 1, W - 1);  // weight is exactly 0 whenever the +1 neighbour would fall outside
+    b.y1 = min(b.y0 + 1, H - 1);
+    return b;
+}
+
+__global__ void flow_warp_kernel(V in, V flow, V out, int cg, long long total, int vin, int vout) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const long long pix = idx / cg;
+    const int x = (int)(pix % out.W), y = (int)(pix / out.W);
+    const int c = g * 4;
+    const float *f = flow.p + (size_t)pix * flow.ld;
+    const Bilin b = warp_coords(x, y, f[0], f[1], in.W, in.H);
+    const float4 nw = ld4(in, (size_t)b.y0 * in.W + b.x0, c, vin);
+    const float4 ne = ld4(in, (size_t)b.y0 * in.W + b.x1, c, vin);
+    const float4 sw = ld4(in, (size_t)b.y1 * in.W + b.x0, c, vin);
+    const float4 se = ld4(in, (size_t)b.y1 * in.W + b.x1, c, vin);
+    float4 r;
+    r.x = nw.x * b.nw + ne.x * b.ne + sw.x * b.sw + se.x * b.se;
+    r.y = nw.y * b.nw + ne.y * b.ne + sw.y * b.sw + se.y * b.se;
+    r.z = nw.z * b.nw + ne.z * b.ne + sw.z * b.sw + se.z * b.se;
+    r.w = nw.w * b.nw + ne.w * b.ne + sw.w * b.sw + se.w * b.se;
+    st4(out, (size_t)pix, c, vout, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void pool2x2_kernel(V in, V out, int is_max, int cg, long long total, int vin, int vout) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const long long pix = idx / cg;
+    const int x = (int)(pix % out.W), y = (int)(pix / out.W);
+    const int c = g * 4;
+    const size_t p00 = (size_t)(2 * y) * in.W + 2 * x;
+    const float4 a = ld4(in, p00, c, vin), b = ld4(in, p00 + 1, c, vin);
+    const float4 d = ld4(in, p00 + in.W, c, vin), e = ld4(in, p00 + in.W + 1, c, vin);
+    float4 r;
+    if (is_max) {
+        r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x));
+        r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y));
+        r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z));
+        r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w));
+    } else {  // ATen avg_pool2d: running sum in window order, then / 4
+        r.x = (a.x + b.x + d.x + e.x) / 4.f;
+        r.y = (a.y + b.y + d.y + e.y) / 4.f;
+        r.z = (a.z + b.z + d.z + e.z) / 4.f;
+        r.w = (a.w + b.w + d.w + e.w) / 4.f;
+    }
+    st4(out, (size_t)pix, c, vout, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void softmax2_blend_kernel(V a, V b, V logits, V out, int cg, long long total, int vec) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const long long pix = idx / cg;
+    const int c = g * 4;
+    const float *l = logits.p + (size_t)pix * logits.ld;
+    const float m = fmaxf(l[0], l[1]);
+    const float e0 = expf(l[0] - m), e1 = expf(l[1] - m);
+    const float sum = e0 + e1;
+    const float w0 = e0 / sum, w1 = e1 / sum;
+    const float4 p = ld4(a, (size_t)pix, c, vec), q = ld4(b, (size_t)pix, c, vec);
+    float4 r;
+    r.x = p.x * w0 + q.x * w1;
+    r.y = p.y * w0 + q.y * w1;
+    r.z = p.z * w0 + q.z * w1;
+    r.w = p.w * w0 + q.w * w1;
+    st4(out, (size_t)pix, c, vec, r);
+}
+
+// mode 0: out = a + b ; 1: out = a ; 2: out = lrelu(a)
+__global__ void binary_kernel(V a, V b, V out, int mode, float slope, int cg, long long total, int vec) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const long long pix = idx / cg;
+    const int c = g * 4;
+    float4 r = ld4(a, (size_t)pix, c, vec);
+    if (mode == 0) {
+        const float4 q = ld4(b, (size_t)pix, c, vec);
+        r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    } else if (mode == 2) {
+        r.x = r.x > 0.f ? r.x : r.x * slope;
+        r.y = r.y > 0.f ? r.y : r.y * slope;
+        r.z = r.z > 0.f ? r.z : r.z * slope;
+        r.w = r.w > 0.f ? r.w : r.w * slope;
+    }
+    st4(out, (size_t)pix, c, vec, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// OffsetDiversity tail. One thread = one pixel x one fusion group G (slots n = 2G, 2G+1):
+//   slot n: x channel group (n % 16) (3 channels), offset channels (2n, 2n+1) of cat(o1,o2) = om[0:64],
+//   mask channel om[64+n]; warped*mask values land in the virtual 96-channel tensor at n*3+k;
+//   grouped 1x1 conv, group G: inputs 6G..6G+5 -> outputs 3G..3G+2.
+__global__ void offset_diversity_kernel(V x, V om, V flow, const float *__restrict__ fw, const float *__restrict__ fb,
+                                        V out, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int G = (int)(idx & 15);
+    const long long pix = idx >> 4;
+    const int px = (int)(pix % x.W), py = (int)(pix / x.W);
+    const float *o = om.p + (size_t)pix * om.ld;
+    const float *f = flow.p + (size_t)pix * flow.ld;
+    const float f0 = f[0], f1 = f[1];
+    float v[6];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 2 * G + t;
+        // flow.repeat(1, 32, 1, 1): offset channel j gets flow[j % 2]
+        const float dx = 40.f * tanhf(o[2 * n]) + f0;
+        const float dy = 40.f * tanhf(o[2 * n + 1]) + f1;
+        const float mk = 1.f / (1.f + expf(-o[64 + n]));
+        const Bilin b = warp_coords(px, py, dx, dy, x.W, x.H);
+        const int cb = (n & 15) * 3;
+        const float *nw = x.p + ((size_t)b.y0 * x.W + b.x0) * x.ld + cb;
+        const float *ne = x.p + ((size_t)b.y0 * x.W + b.x1) * x.ld + cb;
+        const float *sw = x.p + ((size_t)b.y1 * x.W + b.x0) * x.ld + cb;
+        const float *se = x.p + ((size_t)b.y1 * x.W + b.x1) * x.ld + cb;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float s = nw[k] * b.nw + ne[k] * b.ne + sw[k] * b.sw + se[k] * b.se;
+            v[t * 3 + k] = s * mk;
+        }
+    }
+    float *dst = out.p + (size_t)pix * out.ld + 3 * G;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float *wr = fw + (3 * G + j) * 6;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc = fmaf(wr[t], v[t], acc);
+        dst[j] = acc + fb[3 * G + j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// boundary layout changes: 32 pixels x 32 channels tiles through LDS so both sides stay coalesced
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, V dst) {
+    __shared__ float tile[32][33];
+    const long long hw = (long long)dst.H * dst.W;
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r;
+        const long long p = p0 + tx;
+        tile[r][tx] = (c < dst.C && p < hw) ? src[(size_t)c * hw + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long long p = p0 + r;
+        const int c = c0 + tx;
+        if (c < dst.C && p < hw) dst.p[(size_t)p * dst.ld + c] = tile[tx][r];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(V src, float *__restrict__ dst) {
+    __shared__ float tile[32][33];
+    const long long hw = (long long)src.H * src.W;
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long long p = p0 + r;
+        const int c = c0 + tx;
+        tile[r][tx] = (c < src.C && p < hw) ? src.p[(size_t)p * src.ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r;
+        const long long p = p0 + tx;
+        if (c < src.C && p < hw) dst[(size_t)c * hw + p] = tile[tx][r];
+    }
+}
+
+}  // namespace lssvc
+
+using namespace lssvc;
+
+extern "C" int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const float *bias, const lssvc_view *out,
+                               void *stream) {
+    LSSVC_CHECK(view_ok(in) && view_ok(out) && weight && bias, "dwconv3x3: bad arguments");
+    LSSVC_CHECK(same_shape(in, out), "dwconv3x3: in %dx%dx%d vs out %dx%dx%d", in->H, in->W, in->C, out->H, out->W, out->C);
+    LSSVC_CHECK(vec4_ok(in) && vec4_ok(out), "dwconv3x3: views must be 4-channel aligned (C=%d ld=%d)", in->C, in->ld);
+    const Items it = items_of(out);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), weight,
+                       bias, mk(out), it.cg, it.total);
+    return launch_status("dwconv3x3");
+}
+
+extern "C" int lssvc_resize_bilinear(const lssvc_view *in, const lssvc_view *out, float scale, void *stream) {
+    LSSVC_CHECK(view_ok(in) && view_ok(out), "resize_bilinear: bad views");
+    LSSVC_CHECK(in->C == out->C, "resize_bilinear: C %d vs %d", in->C, out->C);
+    const Items it = items_of(out);
+    const float sy = (float)in->H / (float)out->H, sx = (float)in->W / (float)out->W;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in),
+                       mk(out), sy, sx, scale, it.cg, it.total, (int)vec4_ok(in), (int)vec4_ok(out));
+    return launch_status("resize_bilinear");
+}
+
+extern "C" int lssvc_flow_warp(const lssvc_view *in, const lssvc_view *flow, const lssvc_view *out, void *stream) {
+    LSSVC_CHECK(view_ok(in) && view_ok(flow) && view_ok(out), "flow_warp: bad views");
+    LSSVC_CHECK(flow->C == 2 && same_hw(flow, out) && same_shape(in, out), "flow_warp: in %dx%dx%d flow %dx%dx%d out %dx%dx%d",
+                in->H, in->W, in->C, flow->H, flow->W, flow->C, out->H, out->W, out->C);
+    LSSVC_CHECK(in->H > 1 && in->W > 1, "flow_warp: needs H,W > 1");
+    const Items it = items_of(out);
+    hipLaunchKernelGGL(flow_warp_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(flow),
+                       mk(out), it.cg, it.total, (int)vec4_ok(in), (int)vec4_ok(out));
+    return launch_status("flow_warp");
+}
+
+extern "C" int lssvc_pool2x2(const lssvc_view *in, const lssvc_view *out, int32_t is_max, void *stream) {
+    LSSVC_CHECK(view_ok(in) && view_ok(out), "pool2x2: bad views");
+    LSSVC_CHECK(in->C == out->C && out->H == in->H / 2 && out->W == in->W / 2, "pool2x2: in %dx%dx%d out %dx%dx%d", in->H,
+                in->W, in->C, out->H, out->W, out->C);
+    const Items it = items_of(out);
+    hipLaunchKernelGGL(pool2x2_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(out),
+                       (int)is_max, it.cg, it.total, (int)vec4_ok(in), (int)vec4_ok(out));
+    return launch_status("pool2x2");
+}
+
+extern "C" int lssvc_softmax2_blend(const lssvc_view *a, const lssvc_view *b, const lssvc_view *logits,
+                                    const lssvc_view *out, void *stream) {
+    LSSVC_CHECK(view_ok(a) && view_ok(b) && view_ok(logits) && view_ok(out), "softmax2_blend: bad views");
+    LSSVC_CHECK(same_shape(a, b) && same_shape(a, out) && same_hw(a, logits) && logits->C == 2, "softmax2_blend: shape mismatch");
+    const Items it = items_of(out);
+    const int vec = vec4_ok(a) && vec4_ok(b) && vec4_ok(out);
+    hipLaunchKernelGGL(softmax2_blend_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(a), mk(b),
+                       mk(logits), mk(out), it.cg, it.total, vec);
+    return launch_status("softmax2_blend");
+}
+
+static int binary(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, int mode, float slope, void *stream,
+                  const char *what) {
+    LSSVC_CHECK(view_ok(a) && view_ok(out) && (mode != 0 || view_ok(b)), "%s: bad views", what);
+    LSSVC_CHECK(same_shape(a, out) && (mode != 0 || same_shape(a, b)), "%s: shape mismatch", what);
+    const Items it = items_of(out);
+    const int vec = vec4_ok(a) && vec4_ok(out) && (mode != 0 || vec4_ok(b));
+    hipLaunchKernelGGL(binary_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(a),
+                       mode == 0 ? mk(b) : mk_null(), mk(out), mode, slope, it.cg, it.total, vec);
+    return launch_status(what);
+}
+extern "C" int lssvc_add(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, void *stream) {
+    return binary(a, b, out, 0, 0.f, stream, "add");
+}
+extern "C" int lssvc_copy(const lssvc_view *in, const lssvc_view *out, void *stream) {
+    return binary(in, nullptr, out, 1, 0.f, stream, "copy");
+}
+extern "C" int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float slope, void *stream) {
+    return binary(in, nullptr, out, 2, slope, stream, "lrelu");
+}
+
+extern "C" int lssvc_offset_diversity(const lssvc_view *x, const lssvc_view *om, const lssvc_view *flow,
+                                      const float *fusion_w, const float *fusion_b, const lssvc_view *out, void *stream) {
+    LSSVC_CHECK(view_ok(x) && view_ok(om) && view_ok(flow) && view_ok(out) && fusion_w && fusion_b, "offset_diversity: bad arguments");
+    LSSVC_CHECK(x->C == 48 && om->C == 96 && flow->C == 2 && out->C == 48, "offset_diversity: channels x=%d om=%d flow=%d out=%d",
+                x->C, om->C, flow->C, out->C);
+    LSSVC_CHECK(same_hw(x, om) && same_hw(x, flow) && same_hw(x, out) && x->H > 1 && x->W > 1, "offset_diversity: size mismatch");
+    const long long total = (long long)x->H * x->W * 16;
+    hipLaunchKernelGGL(offset_diversity_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mk(x), mk(om),
+                       mk(flow), fusion_w, fusion_b, mk(out), total);
+    return launch_status("offset_diversity");
+}
+
+extern "C" int lssvc_nchw_to_nhwc(const float *src, const lssvc_view *dst, void *stream) {
+    LSSVC_CHECK(src && view_ok(dst), "nchw_to_nhwc: bad arguments");
+    const long long hw = (long long)dst->H * dst->W;
+    dim3 grid((unsigned)((hw + 31) / 32), (unsigned)((dst->C + 31) / 32));
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, mk(dst));
+    return launch_status("nchw_to_nhwc");
+}
+extern "C" int lssvc_nhwc_to_nchw(const lssvc_view *src, float *dst, void *stream) {
+    LSSVC_CHECK(dst && view_ok(src), "nhwc_to_nchw: bad arguments");
+    const long long hw = (long long)src->H * src->W;
+    dim3 grid((unsigned)((hw + 31) / 32), (unsigned)((src->C + 31) / 32));
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, mk(src), dst);
+    return launch_status("nhwc_to_nchw");
+}

@@ -1,0 +1,288 @@
+"""Host-side operator layer: NHWC tensor views over torch device memory + thin wrappers that fill
+the C-ABI descriptors of include/lssvc_hip.h and enqueue the HIP kernels on torch's current stream.
+
+PyTorch is used here only as the device allocator / stream provider (plumbing); every FLOP of
+the hot path runs in liblssvc_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, View, ConvDesc
+
+_NULL_VIEW = View(None, 0, 0, 0, 0)
+
+# optional op log: list of (kind, name, macs) appended by conv() when enabled (bench / profiling)
+OP_LOG = None
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class T:
+    """An H x W x C fp32 view (batch 1) with pixel pitch `ld` into a flat torch buffer."""
+    __slots__ = ("buf", "H", "W", "C", "ld", "off", "_v")
+
+    def __init__(self, buf, H, W, Cc, ld, off=0):
+        self.buf, self.H, self.W, self.C, self.ld, self.off = buf, H, W, Cc, ld, off
+        self._v = View(buf.data_ptr() + 4 * off, H, W, Cc, ld)
+
+    @staticmethod
+    def empty(H, W, Cc, device):
+        return T(torch.empty(H * W * Cc, dtype=torch.float32, device=device), H, W, Cc, Cc)
+
+    @staticmethod
+    def zeros(H, W, Cc, device):
+        return T(torch.zeros(H * W * Cc, dtype=torch.float32, device=device), H, W, Cc, Cc)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    @property
+    def v(self):
+        return self._v
+
+    @property
+    def ref(self):
+        return C.byref(self._v)
+
+    def slice(self, c0, c1):
+        assert 0 <= c0 < c1 <= self.C
+        return T(self.buf, self.H, self.W, c1 - c0, self.ld, self.off + c0)
+
+    def chunk(self, n):
+        step = self.C // n
+        return [self.slice(i * step, (i + 1) * step) for i in range(n)]
+
+    def like(self, Cc=None):
+        return T.empty(self.H, self.W, self.C if Cc is None else Cc, self.device)
+
+    # ---- boundary layout (the reference hands NCHW tensors across its model API) -------------------
+    @staticmethod
+    def from_nchw(x):
+        assert x.dim() == 4 and x.shape[0] == 1 and x.dtype == torch.float32 and x.is_cuda, \
+            "expected a (1,C,H,W) fp32 device tensor, got %s %s %s" % (tuple(x.shape), x.dtype, x.device)
+        x = x.contiguous()
+        t = T.empty(x.shape[2], x.shape[3], x.shape[1], x.device)
+        check(lib.lssvc_nchw_to_nhwc(C.c_void_p(x.data_ptr()), t.ref, stream_ptr()))
+        return t
+
+    def to_nchw(self):
+        out = torch.empty(1, self.C, self.H, self.W, dtype=torch.float32, device=self.device)
+        check(lib.lssvc_nhwc_to_nchw(self.ref, C.c_void_p(out.data_ptr()), stream_ptr()))
+        return out
+
+    def torch_hwc(self):
+        """Debug/test helper: a dense (H,W,C) torch copy."""
+        full = self.buf.view(-1)[self.off:self.off + (self.H * self.W - 1) * self.ld + self.C]
+        if self.ld == self.C:
+            return full.view(self.H, self.W, self.C).clone()
+        idx = (torch.arange(self.H * self.W, device=self.device)[:, None] * self.ld
+               + torch.arange(self.C, device=self.device)[None, :])
+        return self.buf.view(-1)[self.off + idx].view(self.H, self.W, self.C)
+
+
+_ACT = {None: _lib.ACT_NONE, "lrelu": _lib.ACT_LRELU, "relu": _lib.ACT_RELU}
+_INACT = {None: _lib.INACT_NONE, "lrelu": _lib.INACT_LRELU, "square": _lib.INACT_SQUARE}
+
+
+def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=None, in_slope=0.01, epilogue=0,
+                 gdn_x=None, act=None, slope=0.01, residual=None, out_scale=1.0, pixel_shuffle=False, name=""):
+    w_dev, b_dev, cout, m_pad = prepared
+    d = ConvDesc()
+    for i, t in enumerate(inputs):
+        d.inp[i] = t.v
+    d.n_in = len(inputs)
+    d.weight = w_dev.data_ptr()
+    d.bias = b_dev.data_ptr() if b_dev is not None else None
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l = KH, KW, stride, pad_t, pad_l
+    d.Cout, d.M_pad = cout, m_pad
+    d.in_act, d.in_slope = _INACT[in_act], in_slope
+    d.epilogue = epilogue
+    d.gdn_x = gdn_x.v if gdn_x is not None else _NULL_VIEW
+    d.act, d.slope = _ACT[act], slope
+    d.residual = residual.v if residual is not None else _NULL_VIEW
+    d.out_scale = out_scale
+    d.pixel_shuffle = 1 if pixel_shuffle else 0
+    d.out = out.v
+    check(lib.lssvc_conv2d(C.byref(d), stream_ptr()))
+    if OP_LOG is not None:
+        hout, wout = (out.H // 2, out.W // 2) if pixel_shuffle else (out.H, out.W)
+        OP_LOG.append(("conv%dx%ds%d" % (KH, KW, stride), name, hout * wout * cout * KH * KW * sum(t.C for t in inputs),
+                       hout, wout, sum(t.C for t in inputs), cout))
+    return out
+
+
+def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slope=0.01, residual=None,
+         pixel_shuffle=False, out_scale=1.0, out=None, pad=None):
+    """nn.Conv2d (+ optional fused pieces). `inputs`: a T or a list of up to 3 T's read as torch.cat(dim=1)."""
+    if isinstance(inputs, T):
+        inputs = [inputs]
+    w_dev, b_dev, cout, m_pad, KH, KW = W.conv(name, [t.C for t in inputs], pixel_shuffle)
+    if pad is None:
+        pad = KH // 2
+    x = inputs[0]
+    hout = (x.H + 2 * pad - KH) // stride + 1
+    wout = (x.W + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = T.empty(hout * 2, wout * 2, cout // 4, x.device) if pixel_shuffle else T.empty(hout, wout, cout, x.device)
+    return _conv_launch(inputs, (w_dev, b_dev, cout, m_pad), KH, KW, stride, pad, pad, out, in_act=in_act,
+                        in_slope=in_slope, act=act, slope=slope, residual=residual, out_scale=out_scale,
+                        pixel_shuffle=pixel_shuffle, name=name)
+
+
+def subpel(W, name, inputs, **kw):
+    """subpel_conv3x3 / subpel_conv1x1: conv -> PixelShuffle(2) fused in the store; `name` is the nn.Sequential."""
+    return conv(W, name + ".0", inputs, pixel_shuffle=True, **kw)
+
+
+def conv_t(W, name, x, stride, *, act=None, slope=0.01, out=None):
+    """nn.ConvTranspose2d(k=3, padding=1 [, stride=2, output_padding=1]) via its equivalent conv."""
+    w_dev, b_dev, cout, m_pad, KH, KW, pad, ps = W.conv_t(name, stride)
+    if out is None:
+        out = T.empty(x.H * 2, x.W * 2, cout // 4, x.device) if ps else T.empty(x.H, x.W, cout, x.device)
+    return _conv_launch([x], (w_dev, b_dev, cout, m_pad), KH, KW, 1, pad, pad, out, act=act, slope=slope,
+                        pixel_shuffle=ps, name=name)
+
+
+_GDN_EPI = {("intra", False): _lib.EPI_X_MUL_RSQRT, ("intra", True): _lib.EPI_X_MUL_SQRT,
+            ("inter", False): _lib.EPI_X_DIV_SQRT, ("inter", True): _lib.EPI_X_MUL_SQRT}
+
+
+def gdn(W, name, x, flavour, inverse=False, *, residual=None, act=None, slope=0.01, out=None):
+    """GDN / IGDN as a 1x1 conv on x^2 with the normalisation fused into the epilogue."""
+    w_dev, b_dev, cout, m_pad, _, _ = W.gdn(name, flavour)
+    if out is None:
+        out = x.like()
+    return _conv_launch([x], (w_dev, b_dev, cout, m_pad), 1, 1, 1, 0, 0, out, in_act="square",
+                        epilogue=_GDN_EPI[(flavour, inverse)], gdn_x=x, act=act, slope=slope, residual=residual,
+                        name=name)
+
+
+def dwconv3x3(W, name, x, out=None):
+    w_dev, b_dev = W.dwconv(name)
+    if out is None:
+        out = x.like()
+    check(lib.lssvc_dwconv3x3(x.ref, C.c_void_p(w_dev.data_ptr()), C.c_void_p(b_dev.data_ptr()), out.ref, stream_ptr()))
+    return out
+
+
+def resize(x, H, W_, scale=1.0, out=None):
+    if out is None:
+        out = T.empty(int(H), int(W_), x.C, x.device)
+    check(lib.lssvc_resize_bilinear(x.ref, out.ref, scale, stream_ptr()))
+    return out
+
+
+def flow_warp(x, flow, out=None):
+    if out is None:
+        out = x.like()
+    check(lib.lssvc_flow_warp(x.ref, flow.ref, out.ref, stream_ptr()))
+    return out
+
+
+def pool2x2(x, is_max, out=None):
+    if out is None:
+        out = T.empty(x.H // 2, x.W // 2, x.C, x.device)
+    check(lib.lssvc_pool2x2(x.ref, out.ref, 1 if is_max else 0, stream_ptr()))
+    return out
+
+
+def softmax2_blend(a, b, logits, out=None):
+    if out is None:
+        out = a.like()
+    check(lib.lssvc_softmax2_blend(a.ref, b.ref, logits.ref, out.ref, stream_ptr()))
+    return out
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = a.like()
+    check(lib.lssvc_add(a.ref, b.ref, out.ref, stream_ptr()))
+    return out
+
+
+def copy(a, out):
+    check(lib.lssvc_copy(a.ref, out.ref, stream_ptr()))
+    return out
+
+
+def cat(parts):
+    """Materialise torch.cat(dim=1) (only where a fused multi-input conv cannot absorb it)."""
+    total = sum(p.C for p in parts)
+    out = T.empty(parts[0].H, parts[0].W, total, parts[0].device)
+    a = 0
+    for p in parts:
+        copy(p, out.slice(a, a + p.C))
+        a += p.C
+    return out
+
+
+def lrelu(x, slope, out=None):
+    if out is None:
+        out = x.like()
+    check(lib.lssvc_lrelu(x.ref, out.ref, slope, stream_ptr()))
+    return out
+
+
+def offset_diversity_tail(x, om, flow, fusion_w, fusion_b, out=None):
+    if out is None:
+        out = x.like()
+    check(lib.lssvc_offset_diversity(x.ref, om.ref, flow.ref, C.c_void_p(fusion_w.data_ptr()),
+                                     C.c_void_p(fusion_b.data_ptr()), out.ref, stream_ptr()))
+    return out
+
+
+# ---- entropy ----------------------------------------------------------------------------------------
+class BitSlots:
+    """A small device array of fp64 accumulators + the reduction workspace. One D2H copy per frame."""
+
+    def __init__(self, device, n=16):
+        self.vals = torch.zeros(n, dtype=torch.float64, device=device)
+        self.ws = torch.empty(int(lib.lssvc_reduce_workspace_bytes()) // 8, dtype=torch.float64, device=device)
+
+    def slot(self, i):
+        return C.c_void_p(self.vals.data_ptr() + 8 * i)
+
+    @property
+    def wsp(self):
+        return C.c_void_p(self.ws.data_ptr())
+
+    def fetch(self):
+        return self.vals.cpu().tolist()     # the per-frame device->host sync (reference: .item(), IntraSS.py:166)
+
+
+def _opt(t):
+    return t.ref if t is not None else C.byref(_NULL_VIEW)
+
+
+def laplace_quant_bits(y, mean, sigma, slots, slot, y_q=None, y_hat=None):
+    check(lib.lssvc_laplace_quant_bits(y.ref, mean.ref, sigma.ref, _opt(y_q), _opt(y_hat), slots.slot(slot), slots.wsp,
+                                       stream_ptr()))
+
+
+def laplace_bits(y_q, sigma, slots, slot):
+    check(lib.lssvc_laplace_bits(y_q.ref, sigma.ref, slots.slot(slot), slots.wsp, stream_ptr()))
+
+
+def four_part_step(y, mean, sigma, mask_of_chunk, y_q, y_hat, sigma_hat):
+    arr = (C.c_int32 * 4)(*mask_of_chunk)
+    check(lib.lssvc_four_part_step(y.ref, mean.ref, sigma.ref, arr, y_q.ref, y_hat.ref, sigma_hat.ref, stream_ptr()))
+
+
+def factorized_quant_bits(z, params, slots, slot, z_hat=None):
+    check(lib.lssvc_factorized_quant_bits(z.ref, C.c_void_p(params.data_ptr()), _opt(z_hat), slots.slot(slot), slots.wsp,
+                                          stream_ptr()))
+
+
+def gaussian_conditional(y, scale, mean, slots, slot, y_hat=None):
+    check(lib.lssvc_gaussian_conditional(y.ref, scale.ref, mean.ref, _opt(y_hat), slots.slot(slot), slots.wsp,
+                                         stream_ptr()))
+
+
+def entropy_bottleneck(z, params, slots, slot, z_hat=None):
+    check(lib.lssvc_entropy_bottleneck(z.ref, C.c_void_p(params.data_ptr()), _opt(z_hat), slots.slot(slot), slots.wsp,
+                                       stream_ptr()))

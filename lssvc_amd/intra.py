@@ -1,0 +1,180 @@
+"""IntraSS -- MI355X-native drop-in for the reference's I-frame scalable codec.
+
+Mirrors the public surface test.py uses (test.py:545-547, 212, 220-223):
+    IntraSS.from_state_dict(sd) -> .to(device) -> .eval() -> .set_scale_information(...) -> .encode_decode(...)
+Reference: src/models/IntraSS.py:74-336 (EL) and src/models/priors.py:112-452 (`IntraNoAR`, BL).
+The whole estimate-mode forward (IntraSS.py:137-172) runs as HIP kernels; tensors cross the API as
+NCHW fp32 torch tensors exactly like the reference's.
+"""
+import math
+
+import torch
+
+from . import hip_ops as ops
+from .hip_ops import T
+from . import blocks as B
+from .weights import WeightStore, strip_module_prefix, validate
+
+_CDF_BUFFERS = ("._offset", "._quantized_cdf", "._cdf_length")
+
+
+class _HostModel:
+    """Small shared shell: device placement, eval(), scale information (IntraSS.py:229-232, LSSVC_net.py:266-269)."""
+
+    def __init__(self):
+        self.device = None
+        self.W = None
+        self.shape_hr = (256, 256)
+        self.scale_factor = 2.0
+        self.pad_size = (0, 0, 0, 0)
+        self.training = False
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("lssvc_amd models run only on an MI355X HIP device (got %s); "
+                               "there is no CPU fallback" % device)
+        self.device = device
+        self.W = WeightStore(self._sd, device)
+        self.slots = ops.BitSlots(device)
+        return self
+
+    def cuda(self, index=0):
+        return self.to("cuda:%d" % index)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def set_scale_information(self, scale, shape_hr, pad_size):
+        self.scale_factor = scale
+        self.shape_hr = (int(shape_hr[0]), int(shape_hr[1]))
+        self.pad_size = tuple(pad_size)
+        if any(int(v) != 0 for v in self.pad_size):
+            # test.py:212-213 always passes (0,0,0,0); the de-pad path is a no-op there.
+            raise NotImplementedError("non-zero inter-layer pad_size is not supported")
+
+    def _require_device(self):
+        if self.W is None:
+            raise RuntimeError("call .to('cuda:N') before encode_decode()")
+
+
+def _lrelu_conv_seq(W, p, x, layout, out=None):
+    """nn.Sequential of convs / subpel convs with LeakyReLU(0.01) between them; the activation is
+    fused into the producing conv. layout: [(index, 'conv'|'subpel', stride), ...]."""
+    last = len(layout) - 1
+    for i, (idx, kind, stride) in enumerate(layout):
+        act = "lrelu" if i < last else None
+        o = out if i == last else None
+        if kind == "conv":
+            x = ops.conv(W, "%s.%d" % (p, idx), x, stride=stride, act=act, out=o)
+        else:
+            x = ops.subpel(W, "%s.%d" % (p, idx), x, act=act, out=o)
+    return x
+
+
+class IntraSS(_HostModel):
+    def __init__(self, state_dict):
+        super().__init__()
+        self._sd = state_dict
+        self.N_bl = state_dict["base_layer_model.g_s.0.conv1.weight"].shape[0]
+
+    @classmethod
+    def from_state_dict(cls, state_dict, base_layer_model_path=None):
+        """IntraSS.from_state_dict (IntraSS.py:190-214): strip 'module.', drop the scale table, strict load."""
+        sd = strip_module_prefix(dict(state_dict))
+        if base_layer_model_path is not None:
+            bl = torch.load(base_layer_model_path, map_location="cpu")
+            bl = bl.get("state_dict", bl)
+            for k, v in bl.items():
+                sd["base_layer_model." + k] = v
+        sd.pop("gaussian_conditional.scale_table", None)
+        validate(sd, "intra_ss", resizable=_CDF_BUFFERS)
+        return cls(sd)
+
+    # ---------------------------------------------------------------------------------------------
+    def _bl_forward(self, x_bl):
+        """IntraNoAR.get_layer_information (priors.py:368-388)."""
+        W, p = self.W, "base_layer_model"
+        g = p + ".g_a"
+        t = B.residual_block_with_stride(W, g + ".0", x_bl)
+        t = B.residual_block(W, g + ".1", t)
+        t = B.residual_block_with_stride(W, g + ".2", t)
+        t = B.residual_block(W, g + ".3", t)
+        t = B.residual_block_with_stride(W, g + ".4", t)
+        t = B.residual_block(W, g + ".5", t)
+        y = ops.conv(W, g + ".6", t, stride=2)
+        z = _lrelu_conv_seq(W, p + ".h_a", y, [(0, "conv", 1), (2, "conv", 1), (4, "conv", 2), (6, "conv", 1), (8, "conv", 2)])
+        z_hat = z.like()
+        ops.entropy_bottleneck(z, W.entropy_bottleneck(p + ".entropy_bottleneck"), self.slots, 1, z_hat=z_hat)
+        params = _lrelu_conv_seq(W, p + ".h_s", z_hat,
+                                 [(0, "conv", 1), (2, "subpel", 1), (4, "conv", 1), (6, "subpel", 1), (8, "conv", 1)])
+        scales, means = params.chunk(2)
+        y_hat = y.like()
+        ops.gaussian_conditional(y, scales, means, self.slots, 0, y_hat=y_hat)
+        g = p + ".g_s"
+        t = B.residual_block(W, g + ".0", y_hat)
+        t = B.residual_block_upsample(W, g + ".1", t)
+        t = B.residual_block(W, g + ".2", t)
+        t = B.residual_block_upsample(W, g + ".3", t)
+        t = B.residual_block(W, g + ".4", t)
+        t = B.residual_block_upsample(W, g + ".5", t)
+        t = B.residual_block(W, g + ".6", t)
+        x_hat = ops.subpel(W, g + ".7", t)
+        return x_hat, y_hat
+
+    def forward(self, x_bl, x_el):
+        """IntraSS.forward (IntraSS.py:137-172)."""
+        self._require_device()
+        W = self.W
+        H, Wd = self.shape_hr
+        xb, xe = T.from_nchw(x_bl), T.from_nchw(x_el)
+        assert (xe.H, xe.W) == (H, Wd), "x_el is %dx%d but shape_hr is %dx%d" % (xe.H, xe.W, H, Wd)
+        x_hat_bl, y_hat_bl = self._bl_forward(xb)
+
+        # multi_scale_context_mining (IntraSS.py:119-122)
+        t = ops.conv(W, "texture_resampler.conv_adaptor.0", x_hat_bl, act="lrelu")
+        t = ops.conv(W, "texture_resampler.conv_adaptor.2", t)
+        tex = ops.resize(t, H, Wd)
+        t1, t2, t3 = B.pyramid_extractor(W, "texture_extractor", tex)
+        c1, c2, c3 = B.context_fusion(W, "context_fusion_net", t1, t2, t3)
+
+        y = B.res_encoder_gdn(W, "g_a", xe, c1, c2, c3, "intra")
+        z = _lrelu_conv_seq(W, "h_a", y, [(0, "conv", 1), (2, "conv", 2), (4, "conv", 2)])
+        z_hat = z.like()
+        ops.entropy_bottleneck(z, W.entropy_bottleneck("entropy_bottleneck"), self.slots, 3, z_hat=z_hat)
+
+        # PriorFusion input cat(hyper 192, layer 96, context_params 192) is written in place (layers.py:489-492)
+        fused = T.empty(y.H, y.W, 480, self.device)
+        _lrelu_conv_seq(W, "h_s", z_hat, [(0, "subpel", 1), (2, "subpel", 1), (4, "conv", 1)], out=fused.slice(0, 192))
+        t = ops.conv(W, "layer_prior_resampler.conv_adaptor.0", y_hat_bl, act="lrelu")
+        t = ops.conv(W, "layer_prior_resampler.conv_adaptor.2", t)
+        ops.resize(t, H // 16, Wd // 16, out=fused.slice(192, 288))
+        t = ops.conv(W, "prior_fusion_net.context_parameters.0", c3, stride=2, act="lrelu", slope=0.1)
+        ops.conv(W, "prior_fusion_net.context_parameters.2", t, stride=2, out=fused.slice(288, 480))
+        t = ops.conv(W, "prior_fusion_net.params_net.0", fused, act="lrelu")
+        t = ops.conv(W, "prior_fusion_net.params_net.2", t, act="lrelu")
+        params = ops.conv(W, "prior_fusion_net.params_net.4", t)
+        scales, means = params.chunk(2)
+        y_hat = y.like()
+        ops.gaussian_conditional(y, scales, means, self.slots, 2, y_hat=y_hat)
+
+        res_hat = B.res_decoder_gdn(W, "g_s", y_hat, c2, c3, "intra")
+        feature, x_hat = B.recon_generation(W, "recon_net", res_hat, c1)
+
+        out = {"x_hat_bl": x_hat_bl.to_nchw(), "x_hat_el": x_hat.to_nchw(), "feature_el": feature.to_nchw()}
+        s = self.slots.fetch()
+        out["bit_bl"] = (s[0] + s[1]) / (-math.log(2))
+        out["bit_el"] = (s[2] + s[3]) / (-math.log(2))
+        return out
+
+    def encode_decode(self, x_bl, x_el, bin_path_bl, bin_path_el,
+                      pic_height_bl=None, pic_width_bl=None, pic_height_el=None, pic_width_el=None):
+        """IntraSS.encode_decode (IntraSS.py:245-302). bin_path None <=> estimate mode."""
+        if bin_path_bl is None:
+            return self.forward(x_bl, x_el)
+        raise NotImplementedError("write_stream=1 (real bitstream) is not built yet in lssvc_amd; use estimate mode")
+
+    def update(self, force=False):
+        """Only needed for write_stream=1 (test.py:561-564)."""
+        raise NotImplementedError("update() builds CDF tables for write_stream=1, which is not built yet")

@@ -1,0 +1,198 @@
+"""Checkpoint handling: strict validation against the reference state-dict layout and one-time
+re-layout of every tensor into what the HIP kernels consume.
+
+Layouts produced here (see include/lssvc_hip.h):
+  conv     OIHW fp32  ->  [chunk][ky][kx][m][8]   (input channels of every concatenated input segment
+                           zero-padded to a multiple of 8, output channels padded to 16; for a
+                           sub-pixel conv the output axis is permuted to (dy,dx)-major so that the
+                           kernel's PixelShuffle store is a plain float4 per lane)
+  convT    (Cin,Cout,3,3) -> an equivalent plain conv: stride 1 = flipped 3x3; stride 2 (pad 1,
+                           output_padding 1) = 2x2 conv producing the 4 output phases + pixel shuffle
+  GDN      beta/gamma de-reparametrised once (gdn.py:31-33 / video_net_component.py:86-93) into a
+           1x1 conv (weight gamma, bias beta) applied to x^2 with a fused x*rsqrt / x*sqrt / x/sqrt epilogue
+  depthwise (C,1,3,3) -> [9][C]
+  BitEstimator / EntropyBottleneck parameters -> [rows][C] tables with softplus / tanh pre-applied
+"""
+import torch
+import torch.nn.functional as F
+
+from .synth import load_manifest
+
+CK = 8
+
+
+class CheckpointError(RuntimeError):
+    pass
+
+
+def strip_module_prefix(sd):
+    """'module.' prefix removal (IntraSS.py:193-198, LSSVC_net.py:141-149) and optional 'state_dict' unwrap."""
+    if "state_dict" in sd and not torch.is_tensor(sd["state_dict"]):
+        sd = sd["state_dict"]
+    return {(k[7:] if k[:7] == "module." else k): v for k, v in sd.items()}
+
+
+def validate(sd, manifest_name, ignore=(), resizable=()):
+    """Same contract as nn.Module.load_state_dict(strict=True): every expected key present with the
+    expected shape, nothing unexpected. `resizable` keys (CDF buffers) may have any shape."""
+    want = {e["key"]: tuple(e["shape"]) for e in load_manifest(manifest_name)}
+    missing = [k for k in want if k not in sd]
+    unexpected = [k for k in sd if k not in want and k not in ignore]
+    bad = [k for k in want if k in sd and not any(k.endswith(r) for r in resizable) and tuple(sd[k].shape) != want[k]]
+    if missing or unexpected or bad:
+        raise CheckpointError("Error(s) in loading state_dict: missing %s; unexpected %s; size mismatch %s"
+                              % (missing[:5], unexpected[:5], bad[:5]))
+
+
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def layout_conv(w, bias, splits, pixel_shuffle):
+    """w: (Cout, Cin, KH, KW) cpu fp32 -> (w_prepared, bias_prepared, Cout, M_pad)."""
+    cout, cin, kh, kw = w.shape
+    assert sum(splits) == cin, (splits, cin)
+    if pixel_shuffle:
+        cps = cout // 4
+        w = w.reshape(cps, 4, cin, kh, kw).permute(1, 0, 2, 3, 4).reshape(cout, cin, kh, kw)
+        if bias is not None:
+            bias = bias.reshape(cps, 4).t().reshape(cout)
+    m_pad = _pad_to(cout, 16)
+    segs, a = [], 0
+    for c in splits:
+        s = w[:, a:a + c]
+        segs.append(F.pad(s, (0, 0, 0, 0, 0, _pad_to(c, CK) - c)))
+        a += c
+    wp = torch.cat(segs, dim=1)
+    wp = F.pad(wp, (0, 0, 0, 0, 0, 0, 0, m_pad - cout))
+    nchunk = wp.shape[1] // CK
+    wp = wp.reshape(m_pad, nchunk, CK, kh, kw).permute(1, 3, 4, 0, 2).contiguous()
+    bp = torch.zeros(m_pad, dtype=torch.float32)
+    if bias is not None:
+        bp[:cout] = bias
+    return wp, bp, cout, m_pad
+
+
+def conv_t_as_conv(w, bias, stride):
+    """ConvTranspose2d(k=3, padding=1[, stride=2, output_padding=1]) weight (Cin, Cout, 3, 3) ->
+    (equivalent conv weight OIHW, bias, KH, pad, pixel_shuffle)."""
+    cin, cout = w.shape[0], w.shape[1]
+    if stride == 1:
+        return w.flip(2, 3).permute(1, 0, 2, 3).contiguous(), bias, 1, False
+    # out[2i+a, 2j+b] = sum_{dy,dx in {0,1}} in[i+dy, j+dx] * w[:, :, ky(a,dy), kx(b,dx)]
+    tap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}            # (phase, delta) -> kernel index; (0,1) has none
+    w2 = torch.zeros(4, cout, cin, 2, 2, dtype=w.dtype)
+    for a in (0, 1):
+        for b in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    if (a, dy) in tap and (b, dx) in tap:
+                        w2[a * 2 + b, :, :, dy, dx] = w[:, :, tap[(a, dy)], tap[(b, dx)]].t()
+    # rows are (q, co)-major == the kernel's pixel-shuffle order m = q*Cout + co (no further permutation)
+    w2 = w2.reshape(4 * cout, cin, 2, 2)
+    b2 = bias.repeat(4)
+    return w2.contiguous(), b2.contiguous(), 0, True
+
+
+_REPARAM_OFFSET = 2 ** -18
+_PEDESTAL = _REPARAM_OFFSET ** 2
+_BETA_BOUND = (1e-6 + _REPARAM_OFFSET ** 2) ** 0.5
+
+
+class WeightStore:
+    """Lazily prepared, cached device copies of one model's tensors."""
+
+    def __init__(self, sd, device):
+        self.sd = {k: (v.detach().to("cpu", torch.float32) if v.is_floating_point() else v.detach().cpu())
+                   for k, v in sd.items()}
+        self.device = device
+        self._cache = {}
+
+    def has(self, key):
+        return key in self.sd
+
+    def raw(self, key):
+        return self.sd[key]
+
+    def _dev(self, t):
+        return t.contiguous().to(self.device)
+
+    def conv(self, name, splits, pixel_shuffle=False):
+        key = ("conv", name, tuple(splits), pixel_shuffle)
+        if key not in self._cache:
+            w = self.sd[name + ".weight"]
+            b = self.sd.get(name + ".bias")
+            wp, bp, cout, m_pad = layout_conv(w, b, splits, pixel_shuffle)
+            self._cache[key] = (self._dev(wp), self._dev(bp), cout, m_pad, w.shape[2], w.shape[3])
+        return self._cache[key]
+
+    def conv_t(self, name, stride):
+        key = ("convT", name, stride)
+        if key not in self._cache:
+            w, b, pad, ps = conv_t_as_conv(self.sd[name + ".weight"], self.sd[name + ".bias"], stride)
+            wp, bp, cout, m_pad = layout_conv(w, b, [w.shape[1]], False)  # rows already in shuffle order
+            self._cache[key] = (self._dev(wp), self._dev(bp), cout, m_pad, w.shape[2], w.shape[3], pad, ps)
+        return self._cache[key]
+
+    def dwconv(self, name):
+        key = ("dw", name)
+        if key not in self._cache:
+            w = self.sd[name + ".weight"]                      # (C,1,3,3)
+            self._cache[key] = (self._dev(w.reshape(w.shape[0], 9).t()), self._dev(self.sd[name + ".bias"]))
+        return self._cache[key]
+
+    def gdn(self, name, flavour):
+        """flavour 'intra' (gdn.py + others.py reparam buffers) | 'inter' (video_net_component.py constants)."""
+        key = ("gdn", name, flavour)
+        if key not in self._cache:
+            beta, gamma = self.sd[name + ".beta"], self.sd[name + ".gamma"]
+            if flavour == "intra":
+                beta = torch.max(beta, self.sd[name + ".beta_reparam.lower_bound.bound"]) ** 2 \
+                    - self.sd[name + ".beta_reparam.pedestal"]
+                gamma = torch.max(gamma, self.sd[name + ".gamma_reparam.lower_bound.bound"]) ** 2 \
+                    - self.sd[name + ".gamma_reparam.pedestal"]
+            else:
+                beta = torch.max(beta, torch.ones_like(beta) * _BETA_BOUND) ** 2 - _PEDESTAL
+                gamma = torch.max(gamma, torch.ones_like(gamma) * _REPARAM_OFFSET) ** 2 - _PEDESTAL
+            c = gamma.shape[0]
+            wp, bp, cout, m_pad = layout_conv(gamma.reshape(c, c, 1, 1), beta, [c], False)
+            self._cache[key] = (self._dev(wp), self._dev(bp), cout, m_pad, 1, 1)
+        return self._cache[key]
+
+    def vector(self, key):
+        k = ("vec", key)
+        if k not in self._cache:
+            self._cache[k] = self._dev(self.sd[key].reshape(-1))
+        return self._cache[k]
+
+    def bit_estimator(self, name):
+        """[11][C]: softplus(h_i), b_i, tanh(a_i) for i=1..3, softplus(h_4), b_4 (video_entropy_models.py:110-129)."""
+        key = ("be", name)
+        if key not in self._cache:
+            rows = []
+            for i in (1, 2, 3):
+                rows += [F.softplus(self.sd["%s.f%d.h" % (name, i)]), self.sd["%s.f%d.b" % (name, i)],
+                         torch.tanh(self.sd["%s.f%d.a" % (name, i)])]
+            rows += [F.softplus(self.sd[name + ".f4.h"]), self.sd[name + ".f4.b"]]
+            self._cache[key] = self._dev(torch.stack([r.reshape(-1) for r in rows], 0))
+        return self._cache[key]
+
+    def entropy_bottleneck(self, name):
+        """[59][C]: softplus(matrices) 3+9+9+9+3, biases 3+3+3+3+1, tanh(factors) 3x4, median
+        (img_entropy_models.py:483-502, 432-434)."""
+        key = ("eb", name)
+        if key not in self._cache:
+            rows = []
+            for i in range(5):
+                m = F.softplus(self.sd["%s._matrices.%d" % (name, i)])      # (C, f_out, f_in)
+                rows += [m[:, j, k] for j in range(m.shape[1]) for k in range(m.shape[2])]
+            for i in range(5):
+                b = self.sd["%s._biases.%d" % (name, i)]
+                rows += [b[:, j, 0] for j in range(b.shape[1])]
+            for i in range(4):
+                f = torch.tanh(self.sd["%s._factors.%d" % (name, i)])
+                rows += [f[:, j, 0] for j in range(f.shape[1])]
+            rows.append(self.sd[name + ".quantiles"][:, 0, 1])
+            assert len(rows) == 59
+            self._cache[key] = self._dev(torch.stack(rows, 0))
+        return self._cache[key]

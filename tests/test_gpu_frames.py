@@ -1,0 +1,66 @@
+"""Frame-level parity on the GPU: replay every golden case (test.py's frame loop) through the HIP
+models via the reference's own API and compare with the reference's stored outputs.
+Bars (BASELINE.json north_star): |dPSNR| <= 1e-4 dB, |d bpp| <= 1e-5 per frame."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, load_case, replay
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nets(m):
+    from lssvc_amd import IntraSS, LSSVC_extend
+    from lssvc_amd.synth import synth_state_dict
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", m["seed"], m["gain"])).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", m["seed"], m["gain"]))
+    pnet.to(DEV).eval()
+    return inet, pnet
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_frames_match_reference(case):
+    z, m = load_case(case)
+    inet, pnet = _nets(m)
+
+    def i_fn(xb, xe, hr):
+        inet.set_scale_information(m["scale"], hr, (0, 0, 0, 0))
+        return inet.encode_decode(xb, xe, None, None, m["h"], m["w"], m["H"], m["W"])
+
+    def p_fn(xb, xe, dpb, hr, s):
+        pnet.set_scale_information(s, hr, (0, 0, 0, 0))
+        return pnet.encode_decode(xb, xe, dpb, None, None, m["W"], m["H"], m["w"], m["h"])
+
+    for t, r, raw, dpb, p_bl, p_el in replay(case, i_fn, p_fn, device=DEV):
+        bits = z["f%d_bits" % t]
+        d_bpp_bl = abs(r["bit_bl"] - bits[0]) / (m["h"] * m["w"])
+        d_bpp_el = abs(r["bit_el"] - bits[1]) / (m["H"] * m["W"])
+        assert d_bpp_bl <= 1e-5 and d_bpp_el <= 1e-5, (t, r["bit_bl"], bits[0], r["bit_el"], bits[1])
+        want_psnr = z["f%d_psnr" % t]
+        assert abs(p_bl - want_psnr[0]) <= 1e-4 and abs(p_el - want_psnr[1]) <= 1e-4, (t, p_bl, p_el, want_psnr)
+        np.testing.assert_allclose(raw["x_hat_bl"].cpu().numpy(), z["f%d_x_hat_bl" % t], atol=2e-4, rtol=0)
+        want = z["f%d_x_hat_el" % t]
+        got = raw["x_hat_el"].cpu().numpy()
+        if want.shape != got.shape:
+            got = got[:, :, ::2, ::2]
+        np.testing.assert_allclose(got, want, atol=2e-4, rtol=0)
+        fe = dpb["ref_feature_el"].cpu()
+        np.testing.assert_allclose(fe[:, :, ::8, ::8].numpy(), z["f%d_feature_el" % t], atol=5e-4, rtol=1e-4)
+        assert fe.double().abs().sum().item() == pytest.approx(z["f%d_feature_el_sum" % t][1], rel=1e-5)
+        if t > 0:
+            np.testing.assert_allclose(r["mv_hat"].cpu()[:, :, ::2, ::2].numpy(), z["f%d_mv_hat" % t], atol=2e-4, rtol=0)
+            np.testing.assert_allclose(r["warp_frame"].cpu()[:, :, ::2, ::2].numpy(), z["f%d_warp_frame" % t],
+                                       atol=2e-4, rtol=0)
+            np.testing.assert_allclose(dpb["ref_feature_bl"].cpu()[:, :, ::4, ::4].numpy(), z["f%d_feature_bl" % t],
+                                       atol=5e-4, rtol=1e-4)
+
+
+def test_rejects_cpu_device():
+    from lssvc_amd import IntraSS
+    from lssvc_amd.synth import synth_state_dict
+    net = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, 0.6))
+    with pytest.raises(RuntimeError):
+        net.to("cpu")

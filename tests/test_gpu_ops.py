@@ -1,0 +1,280 @@
+"""GPU parity of every HIP kernel against the CPU oracle's building blocks (fp32 torch CPU) on
+seeded inputs, called through the C ABI (ctypes). Tolerances are stated per test: convolutions
+differ from the CPU only in fp32 summation order; the pointwise kernels replay the reference's
+ATen op order and are held to a few ulp."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lssvc_amd import hip_ops
+    return hip_ops
+
+
+def nhwc(hip, x):
+    return hip.T.from_nchw(x.to(DEV))
+
+
+def back(t):
+    return t.to_nchw().cpu()
+
+
+class FakeW:
+    """Minimal WeightStore over an ad-hoc dict."""
+
+    def __new__(cls, sd):
+        from lssvc_amd.weights import WeightStore
+        return WeightStore(sd, torch.device(DEV))
+
+
+def close(got, want, rtol=2e-5, atol=2e-5):
+    scale = max(1.0, want.abs().max().item())
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=rtol, atol=atol * scale)
+
+
+CONV_CASES = [
+    # cins, cout, k, stride, H, W
+    ([64], 64, 3, 1, 40, 56),
+    ([48], 48, 3, 1, 33, 47),
+    ([3], 64, 3, 1, 24, 40),
+    ([3, 64], 64, 3, 2, 32, 48),
+    ([64, 64], 48, 3, 1, 20, 36),
+    ([8], 32, 7, 1, 24, 24),
+    ([32], 64, 7, 1, 18, 30),
+    ([16], 2, 7, 1, 16, 32),
+    ([64], 64, 1, 1, 17, 19),
+    ([128, 256], 384, 1, 1, 8, 8),
+    ([192], 192, 3, 1, 9, 15),
+    ([3], 192, 1, 2, 64, 64),
+    ([170], 149, 3, 1, 8, 8),
+    ([64], 3, 3, 1, 32, 32),
+]
+
+
+@pytest.mark.parametrize("cins,cout,k,stride,H,W", CONV_CASES)
+def test_conv_plain(hip, cins, cout, k, stride, H, W):
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, k, stride)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    w = torch.randn(cout, sum(cins), k, k, generator=g) / math.sqrt(sum(cins) * k * k)
+    b = torch.randn(cout, generator=g)
+    pad = k // 2 if not (k == 1 and stride == 2) else 0
+    want = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=pad)
+    Wt = FakeW({"c.weight": w, "c.bias": b})
+    got = back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], stride=stride, pad=pad))
+    close(got, want)
+
+
+def test_conv_fused_epilogues(hip):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 64, 24, 40, generator=g)
+    r = torch.randn(1, 48, 24, 40, generator=g)
+    w = torch.randn(48, 64, 3, 3, generator=g) / 24
+    b = torch.randn(48, generator=g)
+    Wt = FakeW({"c.weight": w, "c.bias": b})
+    want = F.leaky_relu(F.conv2d(F.leaky_relu(x, 0.1), w, b, padding=1), 0.1) + r
+    got = back(hip.conv(Wt, "c", nhwc(hip, x), in_act="lrelu", in_slope=0.1, act="lrelu", slope=0.1,
+                        residual=nhwc(hip, r)))
+    close(got, want)
+    want = 1.5 * F.relu(F.conv2d(x, w, b, padding=1))
+    got = back(hip.conv(Wt, "c", nhwc(hip, x), act="relu", out_scale=1.5))
+    close(got, want)
+
+
+@pytest.mark.parametrize("cin,cps,k", [(64, 64, 3), (192, 3, 3), (128, 64, 1), (64, 2, 3), (96, 48, 3)])
+def test_subpel(hip, cin, cps, k):
+    g = torch.Generator().manual_seed(cin + cps)
+    x = torch.randn(1, cin, 12, 20, generator=g)
+    w = torch.randn(cps * 4, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cps * 4, generator=g)
+    want = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, w, b, padding=k // 2), 2), 0.01)
+    Wt = FakeW({"s.0.weight": w, "s.0.bias": b})
+    got = back(hip.subpel(Wt, "s", nhwc(hip, x), act="lrelu"))
+    close(got, want)
+
+
+@pytest.mark.parametrize("stride,cin,cout", [(2, 64, 128), (2, 128, 2), (1, 144, 192), (2, 96, 144)])
+def test_conv_transpose(hip, stride, cin, cout):
+    g = torch.Generator().manual_seed(stride * 100 + cout)
+    x = torch.randn(1, cin, 9, 15, generator=g)
+    w = torch.randn(cin, cout, 3, 3, generator=g) / math.sqrt(cin * 9 / stride ** 2)
+    b = torch.randn(cout, generator=g)
+    want = F.conv_transpose2d(x, w, b, stride=stride, padding=1, output_padding=stride - 1)
+    Wt = FakeW({"t.weight": w, "t.bias": b})
+    got = back(hip.conv_t(Wt, "t", nhwc(hip, x), stride))
+    close(got, want)
+
+
+@pytest.mark.parametrize("flavour,inverse", [("intra", False), ("intra", True), ("inter", False), ("inter", True)])
+def test_gdn(hip, flavour, inverse):
+    from lssvc_oracle.blocks import Params, gdn_intra, gdn_inter
+    from lssvc_amd.synth import _make
+    c = 64
+    sd = {"g.beta": _make({"key": "g.beta", "shape": [c], "kind": "gdn_beta"}, 3, 1.0),
+          "g.gamma": _make({"key": "g.gamma", "shape": [c, c], "kind": "gdn_gamma"}, 3, 1.0),
+          "g.beta_reparam.pedestal": torch.tensor([2.0 ** -36]), "g.gamma_reparam.pedestal": torch.tensor([2.0 ** -36]),
+          "g.beta_reparam.lower_bound.bound": torch.tensor([(1e-6 + 2.0 ** -36) ** 0.5]),
+          "g.gamma_reparam.lower_bound.bound": torch.tensor([2.0 ** -18])}
+    x = torch.randn(1, c, 20, 28, generator=torch.Generator().manual_seed(5)) * 2
+    r = torch.randn(1, c, 20, 28, generator=torch.Generator().manual_seed(6))
+    fn = gdn_intra if flavour == "intra" else gdn_inter
+    want = fn(x, Params(sd), "g", inverse=inverse) + r
+    got = back(hip.gdn(FakeW(sd), "g", nhwc(hip, x), flavour, inverse=inverse, residual=nhwc(hip, r)))
+    close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_dwconv(hip):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 48, 19, 23, generator=g)
+    w = torch.randn(48, 1, 3, 3, generator=g) / 3
+    b = torch.randn(48, generator=g)
+    want = F.conv2d(x, w, b, padding=1, groups=48)
+    got = back(hip.dwconv3x3(FakeW({"d.weight": w, "d.bias": b}), "d", nhwc(hip, x)))
+    close(got, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("c,hin,win,hout,wout,scale", [(64, 16, 24, 32, 48, 1.0), (2, 16, 24, 32, 48, 2.0),
+                                                      (2, 32, 48, 16, 24, 0.5), (64, 128, 128, 192, 192, 1.0),
+                                                      (96, 8, 8, 12, 12, 1.0), (3, 17, 23, 40, 31, 1.0)])
+def test_resize(hip, c, hin, win, hout, wout, scale):
+    x = torch.randn(1, c, hin, win, generator=torch.Generator().manual_seed(c + hin))
+    want = F.interpolate(x, size=(hout, wout), mode="bilinear", align_corners=False) * scale
+    got = back(hip.resize(nhwc(hip, x), hout, wout, scale=scale))
+    close(got, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("c,H,W,mag", [(3, 32, 48, 3.0), (64, 24, 40, 8.0), (48, 64, 64, 50.0), (96, 8, 12, 1.0)])
+def test_flow_warp(hip, c, H, W, mag):
+    from lssvc_oracle.blocks import flow_warp
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(1, c, H, W, generator=g)
+    flow = torch.randn(1, 2, H, W, generator=g) * mag
+    want = flow_warp(x, flow)
+    got = back(hip.flow_warp(nhwc(hip, x), nhwc(hip, flow)))
+    # bilinear weights carry the coordinate rounding of a [-1,1]-normalised fp32 grid: ~1e-7 * size
+    close(got, want, rtol=0, atol=3e-5)
+
+
+def test_pool_blend_add(hip):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 32, 48, generator=g)
+    close(back(hip.pool2x2(nhwc(hip, x), is_max=False)), F.avg_pool2d(x, 2, 2), rtol=1e-6, atol=1e-7)
+    y = torch.randn(1, 32, 16, 24, generator=g)
+    close(back(hip.pool2x2(nhwc(hip, y), is_max=True)), F.max_pool2d(y, 2, 2), rtol=0, atol=0)
+    a, b = torch.randn(1, 48, 16, 24, generator=g), torch.randn(1, 48, 16, 24, generator=g)
+    l = torch.randn(1, 2, 16, 24, generator=g) * 3
+    wm = torch.softmax(l, dim=1)
+    close(back(hip.softmax2_blend(nhwc(hip, a), nhwc(hip, b), nhwc(hip, l))), a * wm[:, 0:1] + b * wm[:, 1:2],
+          rtol=1e-6, atol=1e-6)
+    close(back(hip.add(nhwc(hip, a), nhwc(hip, b))), a + b, rtol=0, atol=0)
+    close(back(hip.lrelu(nhwc(hip, a), 0.1)), F.leaky_relu(a, 0.1), rtol=0, atol=0)
+    parts = [nhwc(hip, a), nhwc(hip, y[:, :, :16, :24].contiguous()), nhwc(hip, x[:, :, :16, :24].contiguous())]
+    close(back(hip.cat(parts)), torch.cat([a, y[:, :, :16, :24], x[:, :, :16, :24]], 1), rtol=0, atol=0)
+
+
+def test_layout_roundtrip(hip):
+    x = torch.randn(1, 37, 19, 45)
+    t = nhwc(hip, x)
+    assert torch.equal(t.torch_hwc().cpu(), x[0].permute(1, 2, 0))
+    assert torch.equal(back(t), x)
+
+
+def test_offset_diversity(hip):
+    from lssvc_oracle.blocks import Params
+    from lssvc_oracle.inter import offset_diversity
+    from lssvc_amd.synth import synth_state_dict
+    from lssvc_amd.inter import LSSVC_extend
+    sd = synth_state_dict("lssvc_extend", 0, 0.6)
+    net = LSSVC_extend()
+    net.load_dict(sd)
+    net.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    H, W = 32, 48
+    x = torch.randn(1, 48, H, W, generator=g)
+    c1 = torch.randn(1, 48, H, W, generator=g)
+    wf = torch.rand(1, 3, H, W, generator=g)
+    mv = torch.randn(1, 2, H, W, generator=g) * 2
+    want = offset_diversity(x, torch.cat((c1, wf, mv), 1), mv, Params(sd, "align."))
+    got = back(net._offset_diversity(nhwc(hip, x), [nhwc(hip, c1), nhwc(hip, wf), nhwc(hip, mv)], nhwc(hip, mv)))
+    close(got, want, rtol=0, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------- entropy kernels
+def test_laplace_and_factorized_bits(hip):
+    from lssvc_oracle.blocks import Params
+    from lssvc_oracle import entropy as E
+    from lssvc_amd.synth import synth_state_dict
+    sd = synth_state_dict("lssvc_extend", 1, 0.6)
+    Wt = FakeW(sd)
+    g = torch.Generator().manual_seed(4)
+    y = torch.randn(1, 128, 9, 15, generator=g) * 6
+    mu = torch.randn(1, 128, 9, 15, generator=g)
+    sg = torch.exp(torch.randn(1, 128, 9, 15, generator=g) * 2.5) * 0.5 - 0.05      # includes sigma <= 0 -> clamp
+    slots = hip.BitSlots(torch.device(DEV))
+    yq, yh = hip.T.empty(9, 15, 128, DEV), hip.T.empty(9, 15, 128, DEV)
+    hip.laplace_quant_bits(nhwc(hip, y), nhwc(hip, mu), nhwc(hip, sg), slots, 0, y_q=yq, y_hat=yh)
+    q = torch.round(y - mu)
+    assert torch.equal(back(yq), q) and torch.equal(back(yh), q + mu)
+    hip.laplace_bits(yq, nhwc(hip, sg), slots, 1)
+    z = torch.randn(1, 128, 5, 7, generator=g) * 4
+    zh = hip.T.empty(5, 7, 128, DEV)
+    hip.factorized_quant_bits(nhwc(hip, z), Wt.bit_estimator("bit_estimator_z"), slots, 2, z_hat=zh)
+    assert torch.equal(back(zh), torch.round(z))
+    s = slots.fetch()
+    want = E.laplace_bits(q, sg).item()
+    assert s[0] == pytest.approx(want, rel=2e-6) and s[1] == pytest.approx(want, rel=2e-6)
+    assert s[2] == pytest.approx(E.factorized_bits(torch.round(z), Params(sd, "bit_estimator_z.")).item(), rel=2e-6)
+
+
+def test_gaussian_and_bottleneck(hip):
+    from lssvc_oracle.blocks import Params
+    from lssvc_oracle import entropy as E
+    from lssvc_amd.synth import synth_state_dict
+    sd = synth_state_dict("intra_ss", 1, 0.6)
+    Wt = FakeW(sd)
+    g = torch.Generator().manual_seed(8)
+    y = torch.randn(1, 96, 8, 12, generator=g) * 5
+    mu = torch.randn(1, 96, 8, 12, generator=g)
+    sc = torch.exp(torch.randn(1, 96, 8, 12, generator=g) * 2) * 0.3 - 0.02
+    slots = hip.BitSlots(torch.device(DEV))
+    yh = hip.T.empty(8, 12, 96, DEV)
+    hip.gaussian_conditional(nhwc(hip, y), nhwc(hip, sc), nhwc(hip, mu), slots, 0, y_hat=yh)
+    y_hat, lik = E.gaussian_conditional(y, sc, mu)
+    assert torch.equal(back(yh), y_hat)
+    z = torch.randn(1, 64, 4, 6, generator=g) * 3
+    zh = hip.T.empty(4, 6, 64, DEV)
+    hip.entropy_bottleneck(nhwc(hip, z), Wt.entropy_bottleneck("entropy_bottleneck"), slots, 1, z_hat=zh)
+    z_hat, zlik = E.entropy_bottleneck(z, Params(sd, "entropy_bottleneck."))
+    assert torch.equal(back(zh), z_hat)
+    s = slots.fetch()
+    assert s[0] == pytest.approx(torch.log(lik).double().sum().item(), rel=1e-5)
+    assert s[1] == pytest.approx(torch.log(zlik).double().sum().item(), rel=1e-5)
+
+
+def test_four_part_step_schedule(hip):
+    """The kernel + host schedule reproduce the reference's (chunk, mask) pairing on fixed sigma/mu."""
+    from lssvc_amd.inter import MASK_OF_CHUNK
+    g = torch.Generator().manual_seed(3)
+    H, W, C = 6, 10, 128
+    y = torch.randn(1, C, H, W, generator=g) * 4
+    yq, yh, sh = hip.T.zeros(H, W, C, DEV), hip.T.zeros(H, W, C, DEV), hip.T.zeros(H, W, C, DEV)
+    want_q, want_h, want_s = torch.zeros_like(y), torch.zeros_like(y), torch.zeros_like(y)
+    pos = ((0, 0), (0, 1), (1, 0), (1, 1))
+    for step in range(4):
+        mu = torch.randn(1, C, H, W, generator=g)
+        sg = torch.rand(1, C, H, W, generator=g) + 0.1
+        hip.four_part_step(nhwc(hip, y), nhwc(hip, mu), nhwc(hip, sg), MASK_OF_CHUNK[step], yq, yh, sh)
+        for c in range(4):
+            r, cc = pos[MASK_OF_CHUNK[step][c]]
+            sl = (slice(None), slice(c * 32, (c + 1) * 32), slice(r, None, 2), slice(cc, None, 2))
+            q = torch.round(y[sl] - mu[sl])
+            want_q[sl], want_h[sl], want_s[sl] = q, q + mu[sl], sg[sl]
+    assert torch.equal(back(yq), want_q) and torch.equal(back(yh), want_h) and torch.equal(back(sh), want_s)

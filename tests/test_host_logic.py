@@ -1,0 +1,117 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/lssvc_hip.h declares,
+the weight re-layouts are equivalent re-orderings, checkpoints are validated strictly."""
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lssvc_amd import _lib
+    header = open(os.path.join(ROOT, "include", "lssvc_hip.h")).read()
+    declared = set(re.findall(r"\b(lssvc_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(_lib.lib, name) is not None
+    assert _lib.lib.lssvc_version() == 1
+    assert _lib.lib.lssvc_reduce_workspace_bytes() >= 8 * 256
+
+
+def test_argument_validation_without_gpu():
+    """Shape errors are caught on the host before any launch, with a readable message."""
+    import ctypes as C
+    from lssvc_amd import _lib
+    d = _lib.ConvDesc()
+    d.n_in = 5
+    assert _lib.lib.lssvc_conv2d(C.byref(d), None) != 0
+    assert b"n_in" in _lib.lib.lssvc_last_error()
+    with pytest.raises(_lib.LssvcHipError):
+        _lib.check(_lib.lib.lssvc_conv2d(C.byref(d), None))
+
+
+def _unlayout(wp, cout, splits, kh, kw):
+    """Invert weights.layout_conv: [chunk][ky][kx][m][8] -> (Cout, Cin, KH, KW)."""
+    nchunk = wp.shape[0]
+    w = wp.permute(3, 0, 4, 1, 2).reshape(wp.shape[3], nchunk * 8, kh, kw)[:cout]
+    segs, a = [], 0
+    for c in splits:
+        segs.append(w[:, a:a + c])
+        a += (c + 7) // 8 * 8
+    return torch.cat(segs, 1)
+
+
+def test_conv_layout_roundtrip():
+    from lssvc_amd.weights import layout_conv
+    w = torch.randn(51, 3 + 48, 3, 3)
+    b = torch.randn(51)
+    wp, bp, cout, m_pad = layout_conv(w, b, [3, 48], False)
+    assert wp.shape == (1 + 6, 3, 3, 64, 8) and m_pad == 64 and cout == 51
+    assert torch.equal(_unlayout(wp, 51, [3, 48], 3, 3), w) and torch.equal(bp[:51], b) and bp[51:].abs().sum() == 0
+
+
+def test_pixel_shuffle_permutation():
+    from lssvc_amd.weights import layout_conv
+    w = torch.randn(32, 16, 3, 3)
+    b = torch.randn(32)
+    x = torch.randn(1, 16, 6, 7)
+    wp, bp, cout, m_pad = layout_conv(w, b, [16], True)
+    wq = _unlayout(wp, 32, [16], 3, 3)
+    y = F.conv2d(x, wq, bp[:32], padding=1)                       # channels are (q, c)-major: m = q*8 + c
+    y = y.reshape(1, 4, 8, 6, 7)
+    out = torch.zeros(1, 8, 12, 14)
+    for q in range(4):
+        out[:, :, (q >> 1)::2, (q & 1)::2] = y[:, q]
+    assert torch.allclose(out, F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2), atol=1e-6)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv_transpose_rewrite(stride):
+    from lssvc_amd.weights import conv_t_as_conv
+    w = torch.randn(10, 6, 3, 3)
+    b = torch.randn(6)
+    x = torch.randn(1, 10, 5, 7)
+    want = F.conv_transpose2d(x, w, b, stride=stride, padding=1, output_padding=stride - 1)
+    w2, b2, pad, ps = conv_t_as_conv(w, b, stride)
+    if stride == 1:
+        got = F.conv2d(x, w2, b2, padding=pad)
+    else:
+        y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w2, b2)             # 2x2 taps read (i..i+1, j..j+1), zero beyond the edge
+        y = y.reshape(1, 4, 6, 5, 7)
+        got = torch.zeros(1, 6, 10, 14)
+        for q in range(4):
+            got[:, :, (q >> 1)::2, (q & 1)::2] = y[:, q]
+    assert torch.allclose(got, want, atol=1e-5)
+
+
+def test_strict_checkpoint_validation():
+    from lssvc_amd.synth import synth_state_dict
+    from lssvc_amd.weights import validate, CheckpointError, strip_module_prefix
+    sd = synth_state_dict("lssvc_extend", 0, 0.6)
+    validate(strip_module_prefix({"module." + k: v for k, v in sd.items()}), "lssvc_extend")
+    bad = dict(sd)
+    bad.pop("align.fusion.weight")
+    with pytest.raises(CheckpointError):
+        validate(bad, "lssvc_extend")
+    bad = dict(sd)
+    bad["extra.weight"] = torch.zeros(1)
+    with pytest.raises(CheckpointError):
+        validate(bad, "lssvc_extend")
+    bad = dict(sd)
+    bad["align.fusion.weight"] = torch.zeros(48, 6, 3, 3)
+    with pytest.raises(CheckpointError):
+        validate(bad, "lssvc_extend")
+
+
+def test_synth_is_order_independent_and_seeded():
+    from lssvc_amd.synth import synth_state_dict, synth_clip
+    a, b = synth_state_dict("intra_ss", 3, 0.6), synth_state_dict("intra_ss", 3, 0.6)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = synth_state_dict("intra_ss", 4, 0.6)
+    assert not torch.equal(a["g_a.conv1.weight"], c["g_a.conv1.weight"])
+    clip = synth_clip(2, 64, 64, seed=1)
+    assert clip.dtype == torch.uint8 and clip.shape == (2, 3, 64, 64) and torch.equal(clip, synth_clip(2, 64, 64, seed=1))
