@@ -80,7 +80,8 @@ __global__ void dwconv3x3_kernel(V in, const float *__restrict__ w, const float 
 // ------------------------------------------------------------------------------------------------
 // bilinear resize, align_corners=False (ATen area_pixel_compute_source_index + guard_index_and_lambda)
 __device__ __forceinline__ void src_index(float scale, int dst, int size, int &i0, int &i1, float &l0, float &l1) {
-    float real = scale * (dst + 0.5f) - 0.5f;
+    // ATen's CPU kernel is built with FMA contraction: scale * (dst + 0.5) - 0.5 is one fused op there.
+    float real = fmaf(scale, (float)dst + 0.5f, -0.5f);
     if (real < 0.f) real = 0.f;
     int idx = (int)real;
     if (idx > size - 1) idx = size - 1;
@@ -108,11 +109,17 @@ __global__ void resize_bilinear_kernel(V in, V out, float sy, float sx, float po
     const float4 b = ld4(in, (size_t)y0 * in.W + x1, c, vin);
     const float4 d = ld4(in, (size_t)y1 * in.W + x0, c, vin);
     const float4 e = ld4(in, (size_t)y1 * in.W + x1, c, vin);
+    // separable form of ATen's upsample_generic kernel: t = a*w0; t += b*w1 (contracted to an FMA on the CPU)
+    auto lerp2 = [&](float a_, float b_, float d_, float e_) {
+        const float top = fmaf(b_, wx1, a_ * wx0);
+        const float bot = fmaf(e_, wx1, d_ * wx0);
+        return fmaf(bot, hy1, top * hy0);
+    };
     float4 r;
-    r.x = hy0 * (wx0 * a.x + wx1 * b.x) + hy1 * (wx0 * d.x + wx1 * e.x);
-    r.y = hy0 * (wx0 * a.y + wx1 * b.y) + hy1 * (wx0 * d.y + wx1 * e.y);
-    r.z = hy0 * (wx0 * a.z + wx1 * b.z) + hy1 * (wx0 * d.z + wx1 * e.z);
-    r.w = hy0 * (wx0 * a.w + wx1 * b.w) + hy1 * (wx0 * d.w + wx1 * e.w);
+    r.x = lerp2(a.x, b.x, d.x, e.x);
+    r.y = lerp2(a.y, b.y, d.y, e.y);
+    r.z = lerp2(a.z, b.z, d.z, e.z);
+    r.w = lerp2(a.w, b.w, d.w, e.w);
     if (post != 1.0f) { r.x *= post; r.y *= post; r.z *= post; r.w *= post; }
     st4(out, (size_t)pix, c, vout, r);
 }
