@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the LSSVC hot path on MI355X: encoded frames/s on BASELINE.json configs[1]
+(two-layer x2, EL 1080p padded to 1152x1920, BL 576x960, 32-frame GOP = 1 I + 31 P, estimate mode).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one GOP (32 frames) per rank. GOPs are independent (each restarts from an I-frame), so
+ranks shard GOPs with no data-path collective ("weak" scaling: one GOP per GPU per step); the only
+communication is the barrier / max-reduce of the timing. Inputs (padded EL + BL frames) are resident
+in HBM before the timed region. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GOP = 32
+HEIGHT, WIDTH, RATIO = 1080, 1920, 2.0
+GAIN = 0.55                       # synthetic-weight gain at which a 32-frame GOP stays numerically stable
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = 64 FLOP/clk/SIMD
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_inputs(device, seed, frames):
+    from lssvc_amd.synth import synth_clip
+    from lssvc_amd.preprocess import make_layers
+    clip = synth_clip(frames, HEIGHT, WIDTH, seed=seed)
+    x_els, x_bls = [], []
+    for t in range(frames):
+        rgb = (clip[t:t + 1].to(device).float() / 255.0)
+        x_bl, x_el, pad = make_layers(rgb, RATIO)
+        x_els.append(x_el.contiguous())
+        x_bls.append(x_bl.contiguous())
+    return x_bls, x_els, pad
+
+
+def encode_gop(inet, pnet, x_bls, x_els, shape_hr):
+    """test.py's frame loop (test.py:182-250) for one GOP: I-frame, then P-frames chained through the DPB."""
+    bits = []
+    dpb = None
+    for t in range(len(x_els)):
+        inet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
+        pnet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
+        if t == 0:
+            r = inet.encode_decode(x_bls[t], x_els[t], None, None)
+            dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None,
+                   "ref_feature_el": r["feature_el"]}
+        else:
+            r = pnet.encode_decode(x_bls[t], x_els[t], dpb)
+            dpb = r["dpb"]
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        bits.append((r["bit_bl"], r["bit_el"]))
+    return bits, dpb
+
+
+def roofline_from_log(op_log):
+    """Group the conv launches of one GOP by kernel instantiation; dominant = largest total time."""
+    groups = {}
+    for e in op_log:
+        ms = e["events"][0].elapsed_time(e["events"][1])
+        g = groups.setdefault(e["variant"], {"ms": 0.0, "macs": 0, "launches": 0})
+        g["ms"] += ms
+        g["macs"] += e["macs"]
+        g["launches"] += 1
+    table = []
+    for v, g in groups.items():
+        table.append({"kernel": "conv_mfma_kernel<%d,%d>" % (v // 16, v % 16), "launches": g["launches"],
+                      "total_ms": round(g["ms"], 3), "avg_us": round(1e3 * g["ms"] / g["launches"], 2),
+                      "gflop_per_launch": round(2e-9 * g["macs"] / g["launches"], 3),
+                      "tflops": round(2e-9 * g["macs"] / g["ms"], 2) if g["ms"] > 0 else 0.0})
+    table.sort(key=lambda r: -r["total_ms"])
+    dom = table[0]
+    roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches": dom["launches"], "avg_launch_us": dom["avg_us"], "gflop_per_launch": dom["gflop_per_launch"],
+            "conv_time_ms_per_gop": round(sum(r["total_ms"] for r in table), 2),
+            "conv_tflop_per_gop": round(sum(r["gflop_per_launch"] * r["launches"] for r in table) * 1e-3, 3)}
+    return roof, table
+
+
+def cpu_baseline():
+    """The CPU oracle (a port of the reference's PyTorch CPU path, pinned bit-exact to it) timed on this
+    box's host cores on a bounded sample: 1 I + 1 P frame at EL 384x640 / BL 192x320 = 1/9 of the
+    1152x1920 workload's pixels; conv work is linear in pixels, so frames/s is scaled by 1/9."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from lssvc_oracle.intra import intra_forward
+    from lssvc_oracle.inter import inter_forward
+    from lssvc_amd.synth import synth_state_dict, synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    H, W = 384, 640
+    sd_i, sd_p = synth_state_dict("intra_ss", 0, GAIN), synth_state_dict("lssvc_extend", 0, GAIN)
+    clip = synth_clip(2, H, W, seed=0).float() / 255.0
+    x_bl = imresize_bicubic(clip, (H // 2, W // 2)).clamp_(0, 1)
+    with torch.no_grad():
+        t0 = time.time()
+        o = intra_forward(sd_i, x_bl[0:1], clip[0:1], (H, W))
+        t_i = time.time() - t0
+        dpb = {"ref_frame_bl": o["x_hat_bl"].clamp_(0, 1), "ref_frame_el": o["x_hat_el"].clamp_(0, 1),
+               "ref_feature_bl": None, "ref_feature_el": o["feature_el"]}
+        t0 = time.time()
+        inter_forward(sd_p, x_bl[1:2], clip[1:2], dpb, (H, W), RATIO)
+        t_p = time.time() - t0
+    scale = (H * W) / (1152.0 * 1920.0)
+    fps = GOP / (t_i + (GOP - 1) * t_p) * scale
+    return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 I-frame (%.2f s) + 1 P-frame (%.2f s) at EL 384x640 / BL 192x320 (1/9 of the pixels), "
+                      "GOP-32 mix (1 I + 31 P), scaled by 1/9; torch %s CPU fp32" % (t_i, t_p, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=GOP, help="frames per GOP (default 32 = BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events in the last timed step")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (got world=%d, --gpus=%d)" % (world, args.gpus)
+
+    from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
+    from lssvc_amd.synth import synth_state_dict
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, GAIN)).to(device).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", 0, GAIN))
+    pnet.to(device).eval()
+
+    t0 = time.time()
+    x_bls, x_els, pad = build_inputs(device, seed=rank, frames=args.frames)   # each rank codes its own GOP
+    shape_hr = pad["HR_padded_size"]
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("inputs ready in %.1f s: EL %s BL %s, %d frames/GOP" % (time.time() - t0, tuple(x_els[0].shape),
+                                                                     tuple(x_bls[0].shape), args.frames))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for w in range(args.warmup):
+            t0 = time.time()
+            encode_gop(inet, pnet, x_bls, x_els, shape_hr)
+            torch.cuda.synchronize()
+            if rank == 0:
+                log("warmup GOP %d: %.2f s" % (w, time.time() - t0))
+        sync_all()
+        t_start = time.time()
+        bits = None
+        for k in range(args.steps):
+            if k == args.steps - 1 and rank == 0 and not args.no_events:
+                hip_ops.OP_LOG = []
+            bits, _ = encode_gop(inet, pnet, x_bls, x_els, shape_hr)
+        sync_all()
+        dt = time.time() - t_start
+    op_log, hip_ops.OP_LOG = hip_ops.OP_LOG, None
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        frames = world * args.frames * args.steps
+        out = {
+            "metric": "encoded frames/sec, LSSVC two-layer x2 (BL 540p + EL 1080p), GOP 32 (1 I + 31 P), estimate mode",
+            "value": round(frames / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: LSSVC two-layer x2, EL 1152x1920 (1080p padded) / BL 576x960, "
+                                   "%d-frame GOP per GPU per step, write_stream=0" % args.frames,
+                       "frames_per_step_per_gpu": args.frames, "weights": "seeded synthetic (lssvc_amd.synth, gain %.2f)" % GAIN,
+                       "parallelism": "gop-shard x%d (no data-path collective)" % world},
+        }
+        pel = HEIGHT * WIDTH
+        out["bpp_check"] = {"i_frame_bpp_el": round(bits[0][1] / pel, 5),
+                            "p_frame_bpp_el_mean": round(sum(b[1] for b in bits[1:]) / max(1, len(bits) - 1) / pel, 5)}
+        if op_log:
+            roof, table = roofline_from_log(op_log)
+            out["roofline"] = roof
+            out["roofline_by_kernel"] = table[:6]
+        else:
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle on a bounded sample ...")
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

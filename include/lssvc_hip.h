@@ -79,6 +79,11 @@ typedef struct lssvc_conv_desc {
 
 int lssvc_conv2d(const lssvc_conv_desc *d, void *stream);
 
+/* Which template instantiation lssvc_conv2d picks for a conv-space output of Hout x Wout x M_pad at
+ * `stride`: returns MF*16 + RPW (kernel name conv_mfma_kernel<MF,RPW>; tile = 4*RPW rows x 16 cols x
+ * 16*MF channels). Lets profilers attribute launches to kernels; no GPU work. */
+int lssvc_conv2d_variant(int32_t Hout, int32_t Wout, int32_t M_pad, int32_t stride);
+
 /* Depthwise 3x3, stride 1, pad 1 (lssvc_modules.py:23-24). weight: [9][C], bias: [C]. */
 int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const float *bias, const lssvc_view *out,
                     void *stream);
@@ -160,7 +165,7 @@ int lssvc_gaussian_conditional(const lssvc_view *y, const lssvc_view *scale, con
 
 /* EntropyBottleneck.forward, eval mode (img_entropy_models.py:483-554): z_hat = round(z-med)+med,
  * lik = |sigmoid(s*u) - sigmoid(s*l)| >= 1e-9 with the 1-3-3-3-3-1 per-channel MLP.
- * params: [58][C] rows = softplus(matrices) (3+9+9+9+3), biases (3+3+3+3+1), tanh(factors) (3*4), median. */
+ * params: [59][C] rows = softplus(matrices) (3+9+9+9+3), biases (3+3+3+3+1), tanh(factors) (3*4), median. */
 int lssvc_entropy_bottleneck(const lssvc_view *z, const float *params, const lssvc_view *z_hat,
                              double *sum_out, void *workspace, void *stream);
 

@@ -269,9 +269,29 @@ static long long grid_blocks(const ConvP &p, int MF, int RPW) {
     return (long long)((p.Wout + 15) / 16) * ((p.Hout + TH - 1) / TH) * ((p.M_pad / 16 + MF - 1) / MF);
 }
 
+// Tile choice: MF = 16-channel fragments per workgroup (prefer 4, or 3 when the channel count divides
+// by 48 but not 64); RPW = pixel rows per wave: 4 (16x16 pixel tile) for stride 1, 2 for stride 2
+// (the halo patch doubles), halved further while the grid would not fill the 256 CUs twice over.
+static void pick_variant(const ConvP &p, int &MF, int &RPW) {
+    const int frags = p.M_pad / 16;
+    MF = frags >= 4 ? 4 : frags;
+    if (frags % 4 != 0 && frags % 3 == 0) MF = 3;
+    RPW = (p.stride == 2) ? 2 : 4;
+    while (RPW > 1 && (p.Hout <= 2 * RPW || grid_blocks(p, MF, RPW) < 512)) RPW >>= 1;
+}
+
 }  // namespace lssvc
 
 using namespace lssvc;
+
+extern "C" int lssvc_conv2d_variant(int32_t Hout, int32_t Wout, int32_t M_pad, int32_t stride) {
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.Hout = Hout; p.Wout = Wout; p.M_pad = M_pad; p.stride = stride;
+    int MF, RPW;
+    pick_variant(p, MF, RPW);
+    return MF * 16 + RPW;
+}
 
 extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     LSSVC_CHECK(d != nullptr, "conv2d: null descriptor");
@@ -332,12 +352,8 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-    const int frags = p.M_pad / 16;
-    int MF = frags >= 4 ? 4 : frags;
-    if (frags % 4 != 0 && frags % 3 == 0) MF = 3;
-    int RPW = (d->stride == 2 || d->KH > 3) ? 2 : 4;
-    if (d->KH > 3 && d->stride == 1) RPW = 4;  // 7x7 s1: 22x22 patch still fits
-    while (RPW > 1 && (p.Hout <= 2 * RPW || grid_blocks(p, MF, RPW) < 512)) RPW >>= 1;
+    int MF, RPW;
+    pick_variant(p, MF, RPW);
 
 #define LSSVC_CONV_CASE(mf, rpw) \
     if (MF == mf && RPW == rpw) return launch<mf, rpw>(p, st);

@@ -108,11 +108,20 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
     d.out_scale = out_scale
     d.pixel_shuffle = 1 if pixel_shuffle else 0
     d.out = out.v
+    if OP_LOG is None:
+        check(lib.lssvc_conv2d(C.byref(d), stream_ptr()))
+        return out
+    # profiling mode (bench.py): bracket the launch with HIP events on the launch stream and log the
+    # algorithmic MACs (true Cin/Cout, no padding) and the kernel instantiation that ran
+    hout, wout = (out.H // 2, out.W // 2) if pixel_shuffle else (out.H, out.W)
+    cin = sum(t.C for t in inputs)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib.lssvc_conv2d(C.byref(d), stream_ptr()))
-    if OP_LOG is not None:
-        hout, wout = (out.H // 2, out.W // 2) if pixel_shuffle else (out.H, out.W)
-        OP_LOG.append(("conv%dx%ds%d" % (KH, KW, stride), name, hout * wout * cout * KH * KW * sum(t.C for t in inputs),
-                       hout, wout, sum(t.C for t in inputs), cout))
+    e1.record()
+    OP_LOG.append({"kind": "conv%dx%ds%d" % (KH, KW, stride), "name": name, "macs": hout * wout * cout * KH * KW * cin,
+                   "hout": hout, "wout": wout, "cin": cin, "cout": cout,
+                   "variant": lib.lssvc_conv2d_variant(hout, wout, m_pad, stride), "events": (e0, e1)})
     return out
 
 

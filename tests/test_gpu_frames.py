@@ -64,3 +64,46 @@ def test_rejects_cpu_device():
     net = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, 0.6))
     with pytest.raises(RuntimeError):
         net.to("cpu")
+
+
+def test_gop_drift_vs_oracle():
+    """Errors feed forward through the DPB: code an 8-frame GOP (1 I + 7 P) and hold every frame to the
+    per-frame bars against the CPU oracle run on the same inputs (closed loop on both sides)."""
+    from lssvc_amd import IntraSS, LSSVC_extend
+    from lssvc_amd.synth import synth_state_dict, synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic, psnr
+    from lssvc_oracle.intra import intra_forward
+    from lssvc_oracle.inter import inter_forward
+    H = W = 128
+    n, gain = 8, 0.55
+    sd_i, sd_p = synth_state_dict("intra_ss", 5, gain), synth_state_dict("lssvc_extend", 5, gain)
+    inet = IntraSS.from_state_dict(sd_i).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(sd_p)
+    pnet.to(DEV).eval()
+    clip = synth_clip(n, H, W, seed=5).float() / 255.0
+    x_bl = imresize_bicubic(clip, (H // 2, W // 2)).clamp_(0, 1)
+    dg = do = None
+    with torch.no_grad():
+        for t in range(n):
+            xb, xe = x_bl[t:t + 1], clip[t:t + 1]
+            inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+            pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+            if t == 0:
+                g = inet.encode_decode(xb.to(DEV), xe.to(DEV), None, None)
+                o = intra_forward(sd_i, xb, xe, (H, W))
+                dg = {"ref_frame_bl": g["x_hat_bl"], "ref_frame_el": g["x_hat_el"], "ref_feature_bl": None,
+                      "ref_feature_el": g["feature_el"]}
+                do = {"ref_frame_bl": o["x_hat_bl"], "ref_frame_el": o["x_hat_el"], "ref_feature_bl": None,
+                      "ref_feature_el": o["feature_el"]}
+            else:
+                g = pnet.encode_decode(xb.to(DEV), xe.to(DEV), dg)
+                o = inter_forward(sd_p, xb, xe, do, (H, W), 2.0)
+                dg, do = g["dpb"], o["dpb"]
+            for d in (dg, do):
+                d["ref_frame_bl"].clamp_(0, 1)
+                d["ref_frame_el"].clamp_(0, 1)
+            assert abs(g["bit_bl"] - o["bit_bl"]) / (H * W / 4) <= 1e-5, (t, g["bit_bl"], o["bit_bl"])
+            assert abs(g["bit_el"] - o["bit_el"]) / (H * W) <= 1e-5, (t, g["bit_el"], o["bit_el"])
+            assert abs(psnr(xe, dg["ref_frame_el"].cpu()) - psnr(xe, do["ref_frame_el"])) <= 1e-4, t
+            assert abs(psnr(xb, dg["ref_frame_bl"].cpu()) - psnr(xb, do["ref_frame_bl"])) <= 1e-4, t

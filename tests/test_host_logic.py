@@ -115,3 +115,24 @@ def test_synth_is_order_independent_and_seeded():
     assert not torch.equal(a["g_a.conv1.weight"], c["g_a.conv1.weight"])
     clip = synth_clip(2, 64, 64, seed=1)
     assert clip.dtype == torch.uint8 and clip.shape == (2, 3, 64, 64) and torch.equal(clip, synth_clip(2, 64, 64, seed=1))
+
+
+@pytest.mark.parametrize("case", ["x2_128_ipp", "x1_5_192_ip", "x2_128x256_ip"])
+def test_bl_frame_generation_matches_reference(case):
+    """preprocess.imresize_bicubic reproduces the reference's imresize on the golden clips
+    (the fixtures' x_bl were produced by src/utils/core.py:imresize on x_el)."""
+    import numpy as np
+    from helpers import load_case
+    from lssvc_amd.preprocess import imresize_bicubic
+    z, m = load_case(case)
+    x_el = torch.from_numpy(z["x_el_u8"]).float() / 255.0
+    got = imresize_bicubic(x_el, (m["h"], m["w"])).clamp_(0, 1)
+    np.testing.assert_allclose(got.numpy(), z["x_bl"], atol=1e-6, rtol=0)
+
+
+def test_interlayer_padding_1080p():
+    from lssvc_amd.preprocess import interlayer_padding
+    p = interlayer_padding(1080, 1920, 2.0)
+    assert p["HR_padded_size"] == (1152, 1920) and p["LR_padded_size"] == (576, 960) and p["LR_size"] == (540, 960)
+    p = interlayer_padding(1080, 1920, 1.5)
+    assert p["HR_padded_size"][0] % 96 == 0 and p["LR_padded_size"][0] % 64 == 0
