@@ -81,6 +81,19 @@ def roofline_from_log(op_log):
                       "gflop_per_launch": round(2e-9 * g["macs"] / g["launches"], 3),
                       "tflops": round(2e-9 * g["macs"] / g["ms"], 2) if g["ms"] > 0 else 0.0})
     table.sort(key=lambda r: -r["total_ms"])
+    if os.environ.get("LSSVC_BENCH_SIGNATURES"):      # per-signature breakdown for kernel work (not part of the JSON line)
+        sig = {}
+        for e in op_log:
+            k = (e["kind"], e["cin"], e["cout"], e["hout"], e["wout"], e["variant"])
+            g = sig.setdefault(k, [0.0, 0, 0])
+            g[0] += e["events"][0].elapsed_time(e["events"][1])
+            g[1] += e["macs"]
+            g[2] += 1
+        with open(os.environ["LSSVC_BENCH_SIGNATURES"], "w") as f:
+            tot = sum(g[0] for g in sig.values())
+            for k, g in sorted(sig.items(), key=lambda kv: -kv[1][0]):
+                f.write("%-10s cin %4d cout %4d @%4dx%-4d <%d,%d> n=%4d  %8.2f ms (%4.1f%%)  %6.1f TF\n" % (
+                    k[0], k[1], k[2], k[3], k[4], k[5] // 16, k[5] % 16, g[2], g[0], 100 * g[0] / tot, 2e-9 * g[1] / g[0]))
     dom = table[0]
     roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,

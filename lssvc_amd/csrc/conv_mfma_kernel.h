@@ -1,0 +1,387 @@
+// conv_mfma_kernel.h -- the kernel template behind lssvc_conv2d (see conv_mfma.hip for the design notes).
+// Instantiated per (kernel size, stride, vector-addressable inputs) in conv_inst_*.hip so the
+// translation units build in parallel.
+#pragma once
+#include "common.h"
+
+namespace lssvc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvP {
+    V in[LSSVC_CONV_MAX_INPUTS];
+    int n_in;
+    const float *w;
+    const float *bias;
+    int KH, KW, stride, pad_t, pad_l;
+    int Cout, M_pad;
+    int in_act;
+    float in_slope;
+    int epilogue;
+    V gdn_x;
+    int act;
+    float slope;
+    V res;
+    float out_scale;
+    int pixel_shuffle;
+    V out;
+    int Hout, Wout;  // conv-space output size (before pixel shuffle)
+    int tiles_x, tiles_y, m_tiles;
+    int in_vec[LSSVC_CONV_MAX_INPUTS];
+    int debug;       // perf-experiment switches (LSSVC_CONV_DEBUG): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger
+    int out_vec, res_vec, gdn_vec;
+};
+
+constexpr int CP = 12;  // LDS row pitch in floats (CK=8 + 4 pad)
+
+// One K "phase" = one 8-channel chunk x RPP kernel rows. Small kernels (<=3x3) take all rows in one
+// phase (the whole KSxKS filter slab of the chunk sits in LDS); 7x7 takes one kernel row per phase.
+template <int KS>
+struct PhaseRows {
+    static constexpr int value = (KS <= 3) ? KS : 1;
+};
+
+struct KState {
+    int seg, c0, ky, kc;
+};
+
+template <int MF, int RPW, int KS, int S, bool VEC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
+    constexpr int TM = 16 * MF;
+    constexpr int TH = 4 * RPW;
+    constexpr int PH = (TH - 1) * S + KS, PW = 15 * S + KS;      // LDS halo patch, pixels
+    constexpr int RPP = PhaseRows<KS>::value;                     // kernel rows per phase
+    constexpr int PATCH_ITEMS = PH * PW * 2;                      // float4 items
+    constexpr int W_ITEMS = RPP * KS * TM * 2;
+    constexpr int NP = (PATCH_ITEMS + 255) / 256;                 // prefetch registers (float4) per thread
+    constexpr int NW = (W_ITEMS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float patch[PH * PW * CP];
+    __shared__ __attribute__((aligned(16))) float wts[RPP * KS * TM * CP];
+
+    // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so
+    // remap (bijectively) to give each XCD a contiguous run of tiles: neighbouring pixel tiles share
+    // halos and the M tiles of one pixel tile share the whole input patch through that XCD's L2.
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mt = bid % p.m_tiles;
+    const int pt = bid / p.m_tiles;
+    const int tx = pt % p.tiles_x, ty = pt / p.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * 16, m0 = mt * TM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;  // row of A / column of B
+    const int lg = lane >> 4;  // k group
+
+    f32x4 acc[MF][RPW];
+#pragma unroll
+    for (int a = 0; a < MF; ++a)
+#pragma unroll
+        for (int b = 0; b < RPW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int gy0 = oy0 * S - p.pad_t, gx0 = ox0 * S - p.pad_l;
+
+    float4 preg[NP], wreg[NW];
+    const bool sq = p.in_act == LSSVC_INACT_SQUARE;
+    const float in_slope = p.in_act == LSSVC_INACT_LRELU ? p.in_slope : 1.0f;
+
+    // Loop-invariant staging geometry, computed once: for every float4 this thread stages, the source
+    // pixel (or -1 when it falls in the zero padding / past the tile) and the weight row offset.
+    int ppix[NP];   // input pixel index gy*W + gx, or -1
+    int woff[NW];   // float offset inside one (chunk, ky) weight slab, or -1
+    int wlds[NW];   // float offset inside the LDS weight tile
+    {
+        const int Hin = p.in[0].H, Win = p.in[0].W;     // all inputs share H, W
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            const int pix = idx >> 1;
+            const int py = pix / PW, px = pix - py * PW;
+            const int gy = gy0 + py, gx = gx0 + px;
+            const bool ok = idx < PATCH_ITEMS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+            ppix[i] = ok ? gy * Win + gx : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int idx = tid + i * 256;
+            const int tap = idx / (TM * 2);          // 0 .. RPP*KS-1
+            const int r = idx - tap * (TM * 2);
+            const int m = r >> 1, half = r & 1;
+            const bool ok = idx < W_ITEMS && (m0 + m) < p.M_pad;
+            woff[i] = ok ? (tap * p.M_pad + m0 + m) * 8 + half * 4 : -1;
+            wlds[i] = (tap * TM + m) * CP + half * 4;
+        }
+    }
+    const int half4 = (tid & 1) * 4;     // idx & 1 == tid & 1 for every item (256 is even)
+
+    // global -> registers (issued before the MFMA phase of the previous step; no wait here)
+    // VEC: every input view is 16-byte addressable (C, ld multiples of 4). Loads are then unconditional
+    // (out-of-range items read pixel 0 / channel 0 and are zeroed when written to LDS), which keeps the
+    // prefetch free of branches so no wait lands between the loads and the MFMA phase.
+    bool pvalid_c = true;   // does this thread's channel quad exist in the current chunk?
+    auto load_patch = [&](const KState &k) {
+        const V X = p.in[k.seg];
+        const int c = k.c0 + half4;
+        if constexpr (VEC) {
+            pvalid_c = c < X.C;
+            const int cc = pvalid_c ? c : 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int pp = ppix[i] >= 0 ? ppix[i] : 0;
+                preg[i] = *reinterpret_cast<const float4 *>(X.p + (size_t)pp * X.ld + cc);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ppix[i] >= 0 && c < X.C) {
+                    const float *src = X.p + (size_t)ppix[i] * X.ld + c;
+                    v.x = src[0];
+                    if (c + 1 < X.C) v.y = src[1];
+                    if (c + 2 < X.C) v.z = src[2];
+                    if (c + 3 < X.C) v.w = src[3];
+                }
+                preg[i] = v;
+            }
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < PATCH_ITEMS) {
+                float4 v = preg[i];
+                if constexpr (VEC) {
+                    if (ppix[i] < 0 || !pvalid_c) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                // input activation, branch-free: v * g with g = v (square) or (v > 0 ? 1 : slope); "none" is
+                // slope 1 (x * 1.0f is exact). Zero padding stays zero under all three.
+                v.x *= sq ? v.x : (v.x > 0.f ? 1.0f : in_slope);
+                v.y *= sq ? v.y : (v.y > 0.f ? 1.0f : in_slope);
+                v.z *= sq ? v.z : (v.z > 0.f ? 1.0f : in_slope);
+                v.w *= sq ? v.w : (v.w > 0.f ? 1.0f : in_slope);
+                *reinterpret_cast<float4 *>(patch + ((tid >> 1) + i * 128) * CP + half4) = v;
+            }
+        }
+    };
+    auto load_w = [&](const KState &k) {
+        const float *wsrc = p.w + ((size_t)(k.kc * KS + k.ky) * KS) * p.M_pad * 8;   // rows ky .. ky+RPP-1 are contiguous
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            wreg[i] = *reinterpret_cast<const float4 *>(wsrc + (woff[i] >= 0 ? woff[i] : 0));
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if (tid + i * 256 < W_ITEMS)
+                *reinterpret_cast<float4 *>(wts + wlds[i]) = woff[i] >= 0 ? wreg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto advance = [&](KState k) {
+        k.ky += RPP;
+        if (k.ky >= KS) {
+            k.ky = 0;
+            k.c0 += LSSVC_CONV_CK;
+            ++k.kc;
+            if (k.c0 >= p.in[k.seg].C) {
+                k.c0 = 0;
+                ++k.seg;
+            }
+        }
+        return k;
+    };
+
+    // ---- software-pipelined K loop. Per phase: issue the global loads of phase i+1 into registers,
+    //      run the MFMAs of phase i out of LDS, barrier, write the registers to LDS, barrier. Loads and
+    //      their LDS stores sit in the same iteration, so no prefetch register is live across the
+    //      back-edge and the only vmcnt wait is the one in front of the ds_writes, after the MFMAs. ------
+    KState cur{0, 0, 0, 0};
+    load_patch(cur);
+    load_w(cur);
+    // Two workgroups share each SIMD's matrix pipe. Started together they stay in lockstep (both stage,
+    // then both issue MFMAs) and the pipe idles during every staging step; delaying the workgroup whose
+    // first wave sits in an odd wave slot by about half a phase makes one stage while the other computes.
+    // Pure scheduling: results do not depend on it.
+    {
+        __shared__ int odd_slot;
+        if (tid == 0) odd_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1;   // HW_REG_HW_ID.wave_id
+        __syncthreads();
+        if (odd_slot && !(p.debug & 8)) __builtin_amdgcn_s_sleep(64);
+    }
+    store_patch();
+    store_w();
+    __syncthreads();
+    while (true) {
+        const KState nxt = advance(cur);
+        const bool more = nxt.seg < p.n_in;
+        if (more && !(p.debug & 1)) {
+            load_w(nxt);
+            if (nxt.ky == 0) load_patch(nxt);
+        }
+        // taps of this phase, with the LDS fragment reads of tap t+1 issued before the MFMAs of tap t
+        // (two fragment register sets); sched_barrier keeps the compiler from sinking the reads back
+        // down to their first use, which would expose the LDS latency once per tap.
+        constexpr int NT = RPP * KS;
+        float2 fa[2][MF], fb[2][RPW];
+        auto read_frags = [&](int t, float2 (&a)[MF], float2 (&b)[RPW]) {
+            const int ry = t / KS, kx = t - ry * KS;
+            const int ky = cur.ky + ry;
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+                a[f] = *reinterpret_cast<const float2 *>(wts + (t * TM + f * 16 + li) * CP + 2 * lg);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave * RPW + r;
+                b[r] = *reinterpret_cast<const float2 *>(patch + ((row * S + ky) * PW + li * S + kx) * CP + 2 * lg);
+            }
+        };
+        read_frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) read_frags(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+                    acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t & 1][f].x, fb[t & 1][r].x, acc[f][r], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+                    acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t & 1][f].y, fb[t & 1][r].y, acc[f][r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!more) break;
+        if (!(p.debug & 4)) __syncthreads();  // every wave has finished reading this phase's LDS tiles
+        if (!(p.debug & 2)) {
+            if (nxt.ky == 0) store_patch();
+            store_w();
+        }
+        if (!(p.debug & 4)) __syncthreads();
+        cur = nxt;
+    }
+
+    // ---- fused epilogue: bias -> GDN -> activation -> residual -> scale -> (pixel-shuffle) store ----
+    const int ox = ox0 + li;
+    const int cps = p.Cout >> 2;  // channels after pixel shuffle
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int oy = oy0 + wave * RPW + r;
+        if (oy >= p.Hout || ox >= p.Wout) continue;
+        const size_t opix = (size_t)oy * p.Wout + ox;
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int mb = m0 + f * 16 + 4 * lg;
+            if (mb >= p.Cout) continue;
+            float v[4] = {acc[f][r][0], acc[f][r][1], acc[f][r][2], acc[f][r][3]};
+            const bool full = (mb + 3 < p.Cout);
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4 *>(p.bias + mb);  // bias is M_pad long
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (p.epilogue != LSSVC_EPI_NONE) {
+                float x[4] = {0.f, 0.f, 0.f, 0.f};
+                const float *xs = p.gdn_x.p + opix * p.gdn_x.ld + mb;
+                if (full && p.gdn_vec) {
+                    const float4 t = *reinterpret_cast<const float4 *>(xs);
+                    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (mb + j < p.Cout) x[j] = xs[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sq = sqrtf(v[j]);
+                    if (p.epilogue == LSSVC_EPI_X_MUL_RSQRT) v[j] = x[j] * (1.0f / sq);
+                    else if (p.epilogue == LSSVC_EPI_X_MUL_SQRT) v[j] = x[j] * sq;
+                    else v[j] = x[j] / sq;
+                }
+            }
+            if (p.act == LSSVC_ACT_LRELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+            } else if (p.act == LSSVC_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            }
+            if (p.res.p) {
+                const float *rs = p.res.p + opix * p.res.ld + mb;
+                if (full && p.res_vec) {
+                    const float4 t = *reinterpret_cast<const float4 *>(rs);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (mb + j < p.Cout) v[j] += rs[j];
+                }
+            }
+            if (p.out_scale != 1.0f) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
+            }
+            if (!p.pixel_shuffle) {
+                float *dst = p.out.p + opix * p.out.ld + mb;
+                if (full && p.out_vec) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (mb + j < p.Cout) dst[j] = v[j];
+                }
+            } else {
+                // m = q*cps + c, q = dy*2+dx  (weights were permuted on the host)
+                if (full && p.out_vec && (cps & 3) == 0) {
+                    const int q = mb / cps, c = mb - q * cps;
+                    float *dst = p.out.p + ((size_t)(2 * oy + (q >> 1)) * p.out.W + 2 * ox + (q & 1)) * p.out.ld + c;
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = mb + j;
+                        if (m >= p.Cout) break;
+                        const int q = m / cps, c = m - q * cps;
+                        p.out.p[((size_t)(2 * oy + (q >> 1)) * p.out.W + 2 * ox + (q & 1)) * p.out.ld + c] = v[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MF, int RPW, int KS, int S, bool VEC>
+static int launch(const ConvP &p, hipStream_t st) {
+    const int TH = 4 * RPW;
+    ConvP q = p;
+    q.tiles_x = (p.Wout + 15) / 16;
+    q.tiles_y = (p.Hout + TH - 1) / TH;
+    q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
+    const long long blocks = (long long)q.tiles_x * q.tiles_y * q.m_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return fail("conv2d: bad grid %lld", blocks);
+    hipLaunchKernelGGL((conv_mfma_kernel<MF, RPW, KS, S, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, q);
+    return launch_status("conv2d");
+}
+
+template <int KS, int S, bool VEC>
+int dispatch_tile(const ConvP &p, int MF, int RPW, hipStream_t st) {
+#define LSSVC_CONV_CASE(mf, rpw) \
+    if (MF == mf && RPW == rpw) return launch<mf, rpw, KS, S, VEC>(p, st);
+    LSSVC_CONV_CASE(1, 1) LSSVC_CONV_CASE(1, 2) LSSVC_CONV_CASE(1, 4)
+    LSSVC_CONV_CASE(2, 1) LSSVC_CONV_CASE(2, 2) LSSVC_CONV_CASE(2, 4)
+    LSSVC_CONV_CASE(3, 1) LSSVC_CONV_CASE(3, 2) LSSVC_CONV_CASE(3, 4)
+    LSSVC_CONV_CASE(4, 1) LSSVC_CONV_CASE(4, 2) LSSVC_CONV_CASE(4, 4)
+#undef LSSVC_CONV_CASE
+    return fail("conv2d: no kernel for MF=%d RPW=%d", MF, RPW);
+}
+
+
+// one explicit instantiation per (KS, S, VEC), defined in conv_inst_*.hip
+#define LSSVC_DECLARE_CONV(KS, S)                                                             \
+    extern template int dispatch_tile<KS, S, true>(const ConvP &, int, int, hipStream_t);  \
+    extern template int dispatch_tile<KS, S, false>(const ConvP &, int, int, hipStream_t);
+LSSVC_DECLARE_CONV(1, 1) LSSVC_DECLARE_CONV(1, 2) LSSVC_DECLARE_CONV(2, 1)
+LSSVC_DECLARE_CONV(3, 1) LSSVC_DECLARE_CONV(3, 2) LSSVC_DECLARE_CONV(7, 1)
+#undef LSSVC_DECLARE_CONV
+
+}  // namespace lssvc
