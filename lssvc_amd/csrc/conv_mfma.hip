@@ -70,6 +70,7 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         p.in_vec[i] = vec4_ok(&d->in[i]);
     }
     p.n_in = d->n_in;
+    for (int i = 0; i < d->n_in; ++i) p.n_chunks += (d->in[i].C + LSSVC_CONV_CK - 1) / LSSVC_CONV_CK;
     p.w = d->weight;
     p.bias = d->bias;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;

@@ -28,6 +28,7 @@ struct ConvP {
     int Hout, Wout;  // conv-space output size (before pixel shuffle)
     int tiles_x, tiles_y, m_tiles;
     int in_vec[LSSVC_CONV_MAX_INPUTS];
+    int n_chunks;    // total 8-channel chunks over all input segments
     int debug;       // perf-experiment switches (LSSVC_CONV_DEBUG): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger
     int out_vec, res_vec, gdn_vec;
 };
@@ -51,12 +52,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
     constexpr int TH = 4 * RPW;
     constexpr int PH = (TH - 1) * S + KS, PW = 15 * S + KS;      // LDS halo patch, pixels
     constexpr int RPP = PhaseRows<KS>::value;                     // kernel rows per phase
-    constexpr int PATCH_ITEMS = PH * PW * 2;                      // float4 items
-    constexpr int W_ITEMS = RPP * KS * TM * 2;
+    // 1x1 convs have one tap per chunk, far too little MFMA work per barrier: they take KCH channel
+    // chunks per phase instead, each in its own LDS patch plane ("tap" t of the phase = chunk t).
+    constexpr int KCH = 1;   // (KS == 1 && S == 1) ? 4 : 1 measured slower: 1x1 convs are prologue/epilogue-bound, not barrier-bound
+    constexpr int NT = RPP * KS * KCH;                            // (tap | chunk) units per phase
+    constexpr int PLANE_ITEMS = PH * PW * 2;                      // float4 items per patch plane
+    constexpr int PATCH_ITEMS = PLANE_ITEMS * KCH;
+    constexpr int W_ITEMS = NT * TM * 2;
     constexpr int NP = (PATCH_ITEMS + 255) / 256;                 // prefetch registers (float4) per thread
     constexpr int NW = (W_ITEMS + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float patch[PH * PW * CP];
-    __shared__ __attribute__((aligned(16))) float wts[RPP * KS * TM * CP];
+    __shared__ __attribute__((aligned(16))) float patch[KCH * PH * PW * CP];
+    __shared__ __attribute__((aligned(16))) float wts[NT * TM * CP];
 
     // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so
     // remap (bijectively) to give each XCD a contiguous run of tiles: neighbouring pixel tiles share
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = tid + i * 256;
-            const int pix = idx >> 1;
+            const int pix = (idx % PLANE_ITEMS) >> 1;
             const int py = pix / PW, px = pix - py * PW;
             const int gy = gy0 + py, gx = gx0 + px;
             const bool ok = idx < PATCH_ITEMS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
@@ -123,28 +129,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
     // VEC: every input view is 16-byte addressable (C, ld multiples of 4). Loads are then unconditional
     // (out-of-range items read pixel 0 / channel 0 and are zeroed when written to LDS), which keeps the
     // prefetch free of branches so no wait lands between the loads and the MFMA phase.
-    bool pvalid_c = true;   // does this thread's channel quad exist in the current chunk?
+    int c_left = 0;   // channels of the segment at and after the chunk held in preg (validity of each quad)
     auto load_patch = [&](const KState &k) {
         const V X = p.in[k.seg];
-        const int c = k.c0 + half4;
+        c_left = X.C - k.c0;
         if constexpr (VEC) {
-            pvalid_c = c < X.C;
-            const int cc = pvalid_c ? c : 0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
+                const int cq = ((tid + i * 256) / PLANE_ITEMS) * 8 + half4;      // channel quad inside the phase
                 const int pp = ppix[i] >= 0 ? ppix[i] : 0;
-                preg[i] = *reinterpret_cast<const float4 *>(X.p + (size_t)pp * X.ld + cc);
+                preg[i] = *reinterpret_cast<const float4 *>(X.p + (size_t)pp * X.ld + (cq < c_left ? k.c0 + cq : 0));
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
+                const int cq = ((tid + i * 256) / PLANE_ITEMS) * 8 + half4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ppix[i] >= 0 && c < X.C) {
-                    const float *src = X.p + (size_t)ppix[i] * X.ld + c;
+                if (ppix[i] >= 0 && cq < c_left) {
+                    const float *src = X.p + (size_t)ppix[i] * X.ld + k.c0 + cq;
                     v.x = src[0];
-                    if (c + 1 < X.C) v.y = src[1];
-                    if (c + 2 < X.C) v.z = src[2];
-                    if (c + 3 < X.C) v.w = src[3];
+                    if (cq + 1 < c_left) v.y = src[1];
+                    if (cq + 2 < c_left) v.z = src[2];
+                    if (cq + 3 < c_left) v.w = src[3];
                 }
                 preg[i] = v;
             }
@@ -157,7 +163,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
             if (idx < PATCH_ITEMS) {
                 float4 v = preg[i];
                 if constexpr (VEC) {
-                    if (ppix[i] < 0 || !pvalid_c) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int cq = (idx / PLANE_ITEMS) * 8 + half4;
+                    if (ppix[i] < 0 || cq >= c_left) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 // input activation, branch-free: v * g with g = v (square) or (v > 0 ? 1 : slope); "none" is
                 // slope 1 (x * 1.0f is exact). Zero padding stays zero under all three.
@@ -171,9 +178,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
     };
     auto load_w = [&](const KState &k) {
         const float *wsrc = p.w + ((size_t)(k.kc * KS + k.ky) * KS) * p.M_pad * 8;   // rows ky .. ky+RPP-1 are contiguous
+        // with KCH > 1 "tap" t is chunk kc+t: chunks past the end of the tensor are clamped to a valid
+        // address (their patch plane is all zeros, so the product vanishes whatever is read)
+        const int t_max = KCH > 1 ? p.n_chunks - k.kc - 1 : NT;
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-            wreg[i] = *reinterpret_cast<const float4 *>(wsrc + (woff[i] >= 0 ? woff[i] : 0));
+        for (int i = 0; i < NW; ++i) {
+            int o = woff[i] >= 0 ? woff[i] : 0;
+            if (KCH > 1 && (tid + i * 256) / (TM * 2) > t_max) o = 0;
+            wreg[i] = *reinterpret_cast<const float4 *>(wsrc + o);
+        }
     };
     auto store_w = [&]() {
 #pragma unroll
@@ -185,8 +198,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
         k.ky += RPP;
         if (k.ky >= KS) {
             k.ky = 0;
-            k.c0 += LSSVC_CONV_CK;
-            ++k.kc;
+            const int left = (p.in[k.seg].C - k.c0 + LSSVC_CONV_CK - 1) / LSSVC_CONV_CK;   // chunks left in this segment
+            k.kc += left < KCH ? left : KCH;
+            k.c0 += LSSVC_CONV_CK * KCH;
             if (k.c0 >= p.in[k.seg].C) {
                 k.c0 = 0;
                 ++k.seg;
@@ -225,10 +239,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
         // taps of this phase, with the LDS fragment reads of tap t+1 issued before the MFMAs of tap t
         // (two fragment register sets); sched_barrier keeps the compiler from sinking the reads back
         // down to their first use, which would expose the LDS latency once per tap.
-        constexpr int NT = RPP * KS;
         float2 fa[2][MF], fb[2][RPW];
         auto read_frags = [&](int t, float2 (&a)[MF], float2 (&b)[RPW]) {
-            const int ry = t / KS, kx = t - ry * KS;
+            const int plane = KCH > 1 ? t : 0;
+            const int tt = KCH > 1 ? 0 : t;
+            const int ry = tt / KS, kx = tt - ry * KS;
             const int ky = cur.ky + ry;
 #pragma unroll
             for (int f = 0; f < MF; ++f)
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int row = wave * RPW + r;
-                b[r] = *reinterpret_cast<const float2 *>(patch + ((row * S + ky) * PW + li * S + kx) * CP + 2 * lg);
+                b[r] = *reinterpret_cast<const float2 *>(patch + (plane * PH * PW + (row * S + ky) * PW + li * S + kx) * CP + 2 * lg);
             }
         };
         read_frags(0, fa[0], fb[0]);
