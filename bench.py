@@ -70,13 +70,15 @@ def roofline_from_log(op_log):
     groups = {}
     for e in op_log:
         ms = e["events"][0].elapsed_time(e["events"][1])
-        g = groups.setdefault(e["variant"], {"ms": 0.0, "macs": 0, "launches": 0})
+        name = "conv_mfma_kernel<%d, %d, %d, %d, %s>" % (e["variant"] // 16, e["variant"] % 16, e["ks"], e["stride"],
+                                                         "true" if e["vec"] else "false")
+        g = groups.setdefault(name, {"ms": 0.0, "macs": 0, "launches": 0})
         g["ms"] += ms
         g["macs"] += e["macs"]
         g["launches"] += 1
     table = []
     for v, g in groups.items():
-        table.append({"kernel": "conv_mfma_kernel<%d,%d>" % (v // 16, v % 16), "launches": g["launches"],
+        table.append({"kernel": v, "launches": g["launches"],
                       "total_ms": round(g["ms"], 3), "avg_us": round(1e3 * g["ms"] / g["launches"], 2),
                       "gflop_per_launch": round(2e-9 * g["macs"] / g["launches"], 3),
                       "tflops": round(2e-9 * g["macs"] / g["ms"], 2) if g["ms"] > 0 else 0.0})
@@ -96,11 +98,26 @@ def roofline_from_log(op_log):
                     k[0], k[1], k[2], k[3], k[4], k[5] // 16, k[5] % 16, g[2], g[0], 100 * g[0] / tot, 2e-9 * g[1] / g[0]))
     dom = table[0]
     roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
             "launches": dom["launches"], "avg_launch_us": dom["avg_us"], "gflop_per_launch": dom["gflop_per_launch"],
             "conv_time_ms_per_gop": round(sum(r["total_ms"] for r in table), 2),
             "conv_tflop_per_gop": round(sum(r["gflop_per_launch"] * r["launches"] for r in table) * 1e-3, 3)}
     return roof, table
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    separate runs, gfx950 FETCH correction applied) -- bench.py cannot run the profiler on itself."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            for rec in json.load(f):
+                if rec["kernel"].replace("lssvc::", "") == kernel:
+                    return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch_corrected"], "source": "profiles/pmc_traffic.json",
+                            "collected_on": rec.get("command")}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline():

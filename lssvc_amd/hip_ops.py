@@ -121,7 +121,9 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
     e1.record()
     OP_LOG.append({"kind": "conv%dx%ds%d" % (KH, KW, stride), "name": name, "macs": hout * wout * cout * KH * KW * cin,
                    "hout": hout, "wout": wout, "cin": cin, "cout": cout,
-                   "variant": lib.lssvc_conv2d_variant(hout, wout, m_pad, stride), "events": (e0, e1)})
+                   "variant": lib.lssvc_conv2d_variant(hout, wout, m_pad, stride), "ks": KH, "stride": stride,
+                   "vec": all(t.C % 4 == 0 and t.ld % 4 == 0 and t.v.ptr % 16 == 0 for t in inputs),
+                   "events": (e0, e1)})
     return out
 
 
