@@ -174,6 +174,36 @@ int lssvc_entropy_bottleneck(const lssvc_view *z, const float *params, const lss
 int lssvc_build_indexes(const lssvc_view *sigma, float log_min, float log_step, float add, int32_t levels,
                         int32_t *idx_nhwc, void *stream);
 
+/* ---- host entropy coder (write_stream = 1) ------------------------------------------------------
+ * Replaces the reference's pybind11 modules MLCodec_rans (BufferedRansEncoder / RansDecoder,
+ * src/cpp/rans/rans_interface.cpp:85-261) and MLCodec_CXX (pmf_to_quantized_cdf, src/cpp/ops/ops.cpp:24-91).
+ * Runs on the host; symbols / indexes are flat int32 planes (NCHW order, as the reference flattens them). */
+typedef struct lssvc_cdf_table {
+    const int32_t *cdfs;    /* [n_cdfs][stride] quantised CDFs (16-bit precision) */
+    int32_t n_cdfs, stride;
+    const int32_t *sizes;   /* [n_cdfs] entries used per row (pmf length + 2) */
+    const int32_t *offsets; /* [n_cdfs] symbol value of table slot 0 */
+} lssvc_cdf_table;
+
+void *lssvc_rans_encoder_new(void);
+void lssvc_rans_encoder_free(void *enc);
+void lssvc_rans_encoder_reset(void *enc);
+/* append n symbols to the pending list (BufferedRansEncoder.encode_with_indexes) */
+int lssvc_rans_encode_with_indexes(void *enc, const int32_t *symbols, const int32_t *indexes, int64_t n,
+                                   const lssvc_cdf_table *table);
+/* entropy-code everything pending; returns the stream length in bytes, lssvc_rans_encoder_bytes() its data */
+int64_t lssvc_rans_encoder_flush(void *enc);
+const uint8_t *lssvc_rans_encoder_bytes(void *enc);
+
+void *lssvc_rans_decoder_new(void);
+void lssvc_rans_decoder_free(void *dec);
+int lssvc_rans_decoder_set_stream(void *dec, const uint8_t *bytes, int64_t n);
+/* decode n symbols; the cursor persists across calls (RansDecoder.decode_stream) */
+int lssvc_rans_decode_stream(void *dec, const int32_t *indexes, int64_t n, const lssvc_cdf_table *table, int32_t *out);
+
+/* cdf_out has n + 1 entries */
+int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, uint32_t *cdf_out);
+
 const char *lssvc_last_error(void);
 int lssvc_version(void);
 

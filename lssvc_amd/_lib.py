@@ -35,7 +35,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class CdfTable(C.Structure):
+    _fields_ = [("cdfs", C.c_void_p), ("n_cdfs", C.c_int32), ("stride", C.c_int32), ("sizes", C.c_void_p),
+                ("offsets", C.c_void_p)]
+
+
 VP = C.POINTER(View)
+TP = C.POINTER(CdfTable)
 
 # name -> (restype, argtypes); every symbol include/lssvc_hip.h declares
 SIGNATURES = {
@@ -60,6 +66,17 @@ SIGNATURES = {
     "lssvc_gaussian_conditional": (C.c_int, [VP, VP, VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_entropy_bottleneck": (C.c_int, [VP, C.c_void_p, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_build_indexes": (C.c_int, [VP, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lssvc_rans_encoder_new": (C.c_void_p, []),
+    "lssvc_rans_encoder_free": (None, [C.c_void_p]),
+    "lssvc_rans_encoder_reset": (None, [C.c_void_p]),
+    "lssvc_rans_encode_with_indexes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, TP]),
+    "lssvc_rans_encoder_flush": (C.c_int64, [C.c_void_p]),
+    "lssvc_rans_encoder_bytes": (C.c_void_p, [C.c_void_p]),
+    "lssvc_rans_decoder_new": (C.c_void_p, []),
+    "lssvc_rans_decoder_free": (None, [C.c_void_p]),
+    "lssvc_rans_decoder_set_stream": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "lssvc_rans_decode_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, TP, C.c_void_p]),
+    "lssvc_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lssvc_last_error": (C.c_char_p, []),
     "lssvc_version": (C.c_int, []),
 }

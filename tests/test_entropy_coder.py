@@ -1,0 +1,87 @@
+"""Host entropy coder (CPU-only): the product's C++ coder in liblssvc_hip.so against (a) the reference's own
+pmf_to_quantized_cdf outputs (tests/golden/cdf_vectors.json, generated from the reference's ops.cpp), and
+(b) the oracle's plain-C restatement of the reference rANS wrapper: identical bytes, exact round trips,
+escapes, multi-call cursor, corrupt/short streams rejected."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def oracle_rans():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_build/librans_oracle.so"], stdout=subprocess.DEVNULL)
+    from lssvc_oracle import rans
+    return rans
+
+
+def test_cdf_quantiser_matches_reference(oracle_rans):
+    from lssvc_amd.entropy_coder import pmf_to_quantized_cdf
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "cdf_vectors.json")))
+    assert len(vec) >= 10
+    for v in vec:
+        assert [int(x) for x in pmf_to_quantized_cdf(v["pmf"], v["precision"])] == v["cdf"]
+        assert [int(x) for x in oracle_rans.pmf_to_quantized_cdf(v["pmf"], v["precision"])] == v["cdf"]
+
+
+def _tables(rng, n_tab=6):
+    from lssvc_amd.entropy_coder import Tables
+    lengths = rng.integers(3, 40, n_tab)
+    pmf = rng.random((n_tab, 40)).astype(np.float32) ** 3
+    for i in range(n_tab):
+        pmf[i, lengths[i]:] = 0
+        pmf[i] /= pmf[i].sum()
+    tail = np.full((n_tab, 1), 1e-5, dtype=np.float32)
+    return Tables.from_pmfs(pmf, tail, lengths, -rng.integers(0, 20, n_tab))
+
+
+@pytest.mark.parametrize("seed,n,spread", [(0, 1, 3), (1, 7, 3), (2, 20000, 10), (3, 50000, 300)])
+def test_bytes_equal_oracle_and_round_trip(oracle_rans, seed, n, spread):
+    from lssvc_amd.entropy_coder import RansEncoder, RansDecoder
+    rng = np.random.default_rng(seed)
+    t = _tables(rng)
+    idx = rng.integers(0, t.cdfs.shape[0], n).astype(np.int32)
+    sym = rng.integers(-spread, spread + 30, n).astype(np.int32)        # includes symbols outside every table -> escapes
+    cut = n // 3
+    enc, ref = RansEncoder(), oracle_rans.Encoder()
+    for e in (enc, ref):
+        e.reset()
+    enc.encode_with_indexes(sym[:cut], idx[:cut], t)
+    enc.encode_with_indexes(sym[cut:], idx[cut:], t)
+    ref.encode_with_indexes(sym[:cut], idx[:cut], t.cdfs, t.sizes, t.offsets)
+    ref.encode_with_indexes(sym[cut:], idx[cut:], t.cdfs, t.sizes, t.offsets)
+    data = enc.flush()
+    assert data == ref.flush() and len(data) % 4 == 0
+    dec = RansDecoder()
+    dec.set_stream(data)
+    half = n // 2
+    got = np.concatenate([dec.decode_stream(idx[:half], t), dec.decode_stream(idx[half:], t)])
+    assert np.array_equal(got, sym)
+    rdec = oracle_rans.Decoder()
+    rdec.set_stream(data)
+    assert np.array_equal(rdec.decode_stream(idx, t.cdfs, t.sizes, t.offsets), sym)
+
+
+def test_empty_and_error_paths(oracle_rans):
+    from lssvc_amd.entropy_coder import RansEncoder, RansDecoder
+    from lssvc_amd._lib import LssvcHipError
+    rng = np.random.default_rng(9)
+    t = _tables(rng)
+    enc = RansEncoder()
+    empty = enc.flush()
+    assert len(empty) == 8 and empty == oracle_rans.Encoder().flush()     # just the flushed state
+    with pytest.raises(LssvcHipError):
+        enc.encode_with_indexes([0], [99], t)                              # index outside the tables
+    dec = RansDecoder()
+    with pytest.raises(LssvcHipError):
+        dec.set_stream(b"\x00\x01\x02")                                    # not a rANS64 stream
+    enc.reset()
+    enc.encode_with_indexes(rng.integers(0, 10, 4000), rng.integers(0, 6, 4000), t)
+    data = enc.flush()
+    dec.set_stream(data[:len(data) // 2 // 4 * 4])
+    with pytest.raises(LssvcHipError):
+        dec.decode_stream(rng.integers(0, 6, 4000), t)                     # truncated stream is detected, not over-read
