@@ -159,15 +159,28 @@ int lssvc_factorized_quant_bits(const lssvc_view *z, const float *params, const 
 /* GaussianConditional.forward, eval mode (img_entropy_models.py:650-685): y_hat = round(y-mu)+mu,
  * lik = .5erfc(-(.5-|v|)/s/sqrt2) - .5erfc(-(-.5-|v|)/s/sqrt2), v = (round(y-mu)+mu)-mu,
  * s = max(scale, 0.11), lik >= 1e-9; sum_out[0] = sum ln(lik) (natural log; the caller divides
- * by -ln2 as IntraSS.py:163 does). */
+ * by -ln2 as IntraSS.py:163 does). y_q (optional) receives the symbols round(y-mu) for the coder. */
 int lssvc_gaussian_conditional(const lssvc_view *y, const lssvc_view *scale, const lssvc_view *mean,
-                               const lssvc_view *y_hat, double *sum_out, void *workspace, void *stream);
+                               const lssvc_view *y_hat, const lssvc_view *y_q, double *sum_out, void *workspace,
+                               void *stream);
 
 /* EntropyBottleneck.forward, eval mode (img_entropy_models.py:483-554): z_hat = round(z-med)+med,
  * lik = |sigmoid(s*u) - sigmoid(s*l)| >= 1e-9 with the 1-3-3-3-3-1 per-channel MLP.
  * params: [59][C] rows = softplus(matrices) (3+9+9+9+3), biases (3+3+3+3+1), tanh(factors) (3*4), median. */
 int lssvc_entropy_bottleneck(const lssvc_view *z, const float *params, const lssvc_view *z_hat,
-                             double *sum_out, void *workspace, void *stream);
+                             const lssvc_view *z_q, double *sum_out, void *workspace, void *stream);
+
+/* Symbol / index planes for the host coder, flat NCHW int32 as the reference flattens them
+ * (video_entropy_models.py:234-236,315-319): sym = (int) q, idx = table index of sigma (or the channel
+ * number when sigma is NULL: BitEstimator / EntropyBottleneck tables are per channel). With chunk_of_mask
+ * (4 entries, a permutation of 0..3) the C-channel inputs are folded to C/4 channels as the 4-step prior
+ * writes them (LSSVC_net.py:432-442): 2x2 position m takes channel chunk chunk_of_mask[m]. */
+int lssvc_export_symbols(const lssvc_view *q, const lssvc_view *sigma, const int32_t *chunk_of_mask, float log_min,
+                         float log_step, float add, int32_t levels, int32_t *sym_nchw, int32_t *idx_nchw, void *stream);
+/* Decoder side: out = sym + mean + channel_add[c] (means / medians optional); with chunk_of_mask only the
+ * channel chunk of each 2x2 position is written (LSSVC_net_extend.py:208-213). sym_nchw is a device pointer. */
+int lssvc_import_symbols(const int32_t *sym_nchw, const lssvc_view *mean, const float *channel_add,
+                         const int32_t *chunk_of_mask, const lssvc_view *out, void *stream);
 
 /* sigma -> CDF-table index planes for the host coder (video_entropy_models.py:309-313,
  * img_entropy_models.py:687-691): idx = clamp((ln max(s,1e-5) - ln smin)/step + add, 0, levels-1). */

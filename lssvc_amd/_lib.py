@@ -63,8 +63,10 @@ SIGNATURES = {
     "lssvc_four_part_step": (C.c_int, [VP, VP, VP, C.POINTER(C.c_int32), VP, VP, VP, C.c_void_p]),
     "lssvc_laplace_bits": (C.c_int, [VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_factorized_quant_bits": (C.c_int, [VP, C.c_void_p, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "lssvc_gaussian_conditional": (C.c_int, [VP, VP, VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "lssvc_entropy_bottleneck": (C.c_int, [VP, C.c_void_p, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_gaussian_conditional": (C.c_int, [VP, VP, VP, VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_entropy_bottleneck": (C.c_int, [VP, C.c_void_p, VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_export_symbols": (C.c_int, [VP, VP, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_import_symbols": (C.c_int, [C.c_void_p, VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
     "lssvc_build_indexes": (C.c_int, [VP, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "lssvc_rans_encoder_new": (C.c_void_p, []),
     "lssvc_rans_encoder_free": (None, [C.c_void_p]),

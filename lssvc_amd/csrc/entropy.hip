@@ -122,15 +122,17 @@ __global__ void factorized_kernel(V z, const float *__restrict__ P, V z_hat, lon
 }
 
 // ---- GaussianConditional (I-frame y) --------------------------------------------------------------
-__global__ void gaussian_kernel(V y, V scale, V mean, V y_hat, long long total, double *partials) {
+__global__ void gaussian_kernel(V y, V scale, V mean, V y_hat, V y_q, long long total, double *partials) {
     const float kC = -0.70710678118654752440f;  // float(-(2 ** -0.5))
     double acc = 0.0;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int c = (int)(idx % y.C);
         const size_t pix = (size_t)(idx / y.C);
         const float mu = mean.p[pix * mean.ld + c];
-        const float out = rintf(y.p[pix * y.ld + c] - mu) + mu;
+        const float q = rintf(y.p[pix * y.ld + c] - mu);
+        const float out = q + mu;
         if (y_hat.p) y_hat.p[pix * y_hat.ld + c] = out;
+        if (y_q.p) y_q.p[pix * y_q.ld + c] = q;
         const float v = fabsf(out - mu);
         const float s = fmaxf(scale.p[pix * scale.ld + c], 0.11f);
         const float upper = 0.5f * erfcf(kC * ((0.5f - v) / s));
@@ -172,14 +174,16 @@ __device__ __forceinline__ float eb_logits(float v, const float *__restrict__ P,
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ void bottleneck_kernel(V z, const float *__restrict__ P, V z_hat, long long total, double *partials) {
+__global__ void bottleneck_kernel(V z, const float *__restrict__ P, V z_hat, V z_q, long long total, double *partials) {
     double acc = 0.0;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int c = (int)(idx % z.C);
         const size_t pix = (size_t)(idx / z.C);
         const float med = P[58 * z.C + c];
-        const float out = rintf(z.p[pix * z.ld + c] - med) + med;
+        const float zq = rintf(z.p[pix * z.ld + c] - med);
+        const float out = zq + med;
         if (z_hat.p) z_hat.p[pix * z_hat.ld + c] = out;
+        if (z_q.p) z_q.p[pix * z_q.ld + c] = zq;
         const float lower = eb_logits(out - 0.5f, P, z.C, c);
         const float upper = eb_logits(out + 0.5f, P, z.C, c);
         const float sum = lower + upper;
@@ -202,6 +206,56 @@ __global__ void build_indexes_kernel(V sigma, float log_min, float log_step, flo
     float v = (logf(s) - log_min) / log_step + add;
     v = fminf(fmaxf(v, 0.f), (float)(levels - 1));
     idx_out[pix * sigma.C + c] = (int32_t)v;
+}
+
+
+// ---- symbol / index planes for the host coder (write_stream = 1) -------------------------------------
+// The host coder consumes flat NCHW-ordered int32 planes, exactly the order in which the reference flattens
+// its tensors (x.reshape(-1) of an NCHW tensor, video_entropy_models.py:234-236,315-319).
+__device__ __forceinline__ int32_t sigma_index(float sigma, float log_min, float log_step, float add, int levels) {
+    const float s = fmaxf(sigma, 1e-5f);
+    float v = (logf(s) - log_min) / log_step + add;
+    v = fminf(fmaxf(v, 0.f), (float)(levels - 1));
+    return (int32_t)v;
+}
+
+// chunk_of_mask < 0: plain export of a C-channel tensor. Otherwise the 4-step fold (LSSVC_net.py:432-442):
+// out channel j at 2x2 position m takes channel chunk_of_mask[m]*C4 + j of the C-channel inputs.
+__global__ void export_symbols_kernel(V q, V sigma, int cm0, int cm1, int cm2, int cm3, float log_min, float log_step, float add,
+                                      int levels, int32_t *sym, int32_t *idx, int C_out, int H, int W, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int j = (int)(t % C_out);
+    const long long pix = t / C_out;
+    int c = j;
+    if (cm0 >= 0) {
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        const int m = (y & 1) * 2 + (x & 1);
+        c = (m == 0 ? cm0 : (m == 1 ? cm1 : (m == 2 ? cm2 : cm3))) * C_out + j;
+    }
+    const size_t o = (size_t)j * H * W + pix;
+    if (sym) sym[o] = (int32_t)q.p[(size_t)pix * q.ld + c];
+    if (idx) idx[o] = sigma.p ? sigma_index(sigma.p[(size_t)pix * sigma.ld + c], log_min, log_step, add, levels) : j;
+}
+
+// out[pix][c] = sym + mean + add[c]; with chunk_of_mask >= 0 the 4-step unfold (LSSVC_net_extend.py:208-213):
+// only channel chunk_of_mask[m]*C4 + j at position m is written.
+__global__ void import_symbols_kernel(const int32_t *__restrict__ sym, V mean, const float *__restrict__ add, int cm0, int cm1,
+                                      int cm2, int cm3, V out, int C_in, int H, int W, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int j = (int)(t % C_in);
+    const long long pix = t / C_in;
+    int c = j;
+    if (cm0 >= 0) {
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        const int m = (y & 1) * 2 + (x & 1);
+        c = (m == 0 ? cm0 : (m == 1 ? cm1 : (m == 2 ? cm2 : cm3))) * C_in + j;
+    }
+    float v = (float)sym[(size_t)j * H * W + pix];
+    if (mean.p) v += mean.p[(size_t)pix * mean.ld + c];
+    if (add) v += add[c];
+    out.p[(size_t)pix * out.ld + c] = v;
 }
 
 }  // namespace lssvc
@@ -271,25 +325,26 @@ extern "C" int lssvc_factorized_quant_bits(const lssvc_view *z, const float *par
 }
 
 extern "C" int lssvc_gaussian_conditional(const lssvc_view *y, const lssvc_view *scale, const lssvc_view *mean,
-                                          const lssvc_view *y_hat, double *sum_out, void *workspace, void *stream) {
+                                          const lssvc_view *y_hat, const lssvc_view *y_q, double *sum_out, void *workspace,
+                                          void *stream) {
     LSSVC_CHECK(view_ok(y) && view_ok(scale) && view_ok(mean) && sum_out && workspace, "gaussian_conditional: bad arguments");
     LSSVC_CHECK(same_shape(y, scale) && same_shape(y, mean) && (!y_hat || !y_hat->ptr || same_shape(y, y_hat)),
                 "gaussian_conditional: shape mismatch");
     const long long total = (long long)y->H * y->W * y->C;
     const unsigned blocks = reduce_blocks(total);
     hipLaunchKernelGGL(gaussian_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mk(y), mk(scale), mk(mean), opt(y_hat),
-                       total, (double *)workspace);
+                       opt(y_q), total, (double *)workspace);
     if (int e = launch_status("gaussian_conditional")) return e;
     return finish_reduce(blocks, workspace, sum_out, (hipStream_t)stream, "gaussian_conditional/reduce");
 }
 
-extern "C" int lssvc_entropy_bottleneck(const lssvc_view *z, const float *params, const lssvc_view *z_hat, double *sum_out,
-                                        void *workspace, void *stream) {
+extern "C" int lssvc_entropy_bottleneck(const lssvc_view *z, const float *params, const lssvc_view *z_hat, const lssvc_view *z_q,
+                                        double *sum_out, void *workspace, void *stream) {
     LSSVC_CHECK(view_ok(z) && params && sum_out && workspace, "entropy_bottleneck: bad arguments");
     LSSVC_CHECK(!z_hat || !z_hat->ptr || same_shape(z, z_hat), "entropy_bottleneck: z_hat shape mismatch");
     const long long total = (long long)z->H * z->W * z->C;
     const unsigned blocks = reduce_blocks(total);
-    hipLaunchKernelGGL(bottleneck_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mk(z), params, opt(z_hat), total,
+    hipLaunchKernelGGL(bottleneck_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mk(z), params, opt(z_hat), opt(z_q), total,
                        (double *)workspace);
     if (int e = launch_status("entropy_bottleneck")) return e;
     return finish_reduce(blocks, workspace, sum_out, (hipStream_t)stream, "entropy_bottleneck/reduce");
@@ -302,6 +357,49 @@ extern "C" int lssvc_build_indexes(const lssvc_view *sigma, float log_min, float
     hipLaunchKernelGGL(build_indexes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mk(sigma),
                        log_min, log_step, add, levels, idx_nhwc, total);
     return launch_status("build_indexes");
+}
+
+
+static int chunk_masks_ok(const int32_t *cm) {
+    if (!cm) return 1;
+    int seen = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (cm[i] < 0 || cm[i] > 3) return 0;
+        seen |= 1 << cm[i];
+    }
+    return seen == 15;
+}
+
+extern "C" int lssvc_export_symbols(const lssvc_view *q, const lssvc_view *sigma, const int32_t *chunk_of_mask, float log_min,
+                                    float log_step, float add, int32_t levels, int32_t *sym_nchw, int32_t *idx_nchw, void *stream) {
+    const lssvc_view *ref = (q && q->ptr) ? q : sigma;
+    LSSVC_CHECK(view_ok(ref) && (sym_nchw || idx_nchw), "export_symbols: bad arguments");
+    LSSVC_CHECK(!sym_nchw || view_ok(q), "export_symbols: symbols requested without q");
+    LSSVC_CHECK(!(q && q->ptr && sigma && sigma->ptr) || same_shape(q, sigma), "export_symbols: q / sigma shape mismatch");
+    LSSVC_CHECK(chunk_masks_ok(chunk_of_mask) && (!chunk_of_mask || ref->C % 4 == 0), "export_symbols: bad chunk_of_mask");
+    LSSVC_CHECK(!(sigma && sigma->ptr) || (levels > 0 && log_step > 0.f), "export_symbols: bad index parameters");
+    const int C_out = chunk_of_mask ? ref->C / 4 : ref->C;
+    const long long total = (long long)ref->H * ref->W * C_out;
+    const int32_t none[4] = {-1, -1, -1, -1};
+    const int32_t *cm = chunk_of_mask ? chunk_of_mask : none;
+    hipLaunchKernelGGL(export_symbols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, opt(q),
+                       opt(sigma), cm[0], cm[1], cm[2], cm[3], log_min, log_step, add, levels, sym_nchw, idx_nchw, C_out, ref->H,
+                       ref->W, total);
+    return launch_status("export_symbols");
+}
+
+extern "C" int lssvc_import_symbols(const int32_t *sym_nchw, const lssvc_view *mean, const float *channel_add,
+                                    const int32_t *chunk_of_mask, const lssvc_view *out, void *stream) {
+    LSSVC_CHECK(sym_nchw && view_ok(out), "import_symbols: bad arguments");
+    LSSVC_CHECK(!(mean && mean->ptr) || same_shape(mean, out), "import_symbols: mean shape mismatch");
+    LSSVC_CHECK(chunk_masks_ok(chunk_of_mask) && (!chunk_of_mask || out->C % 4 == 0), "import_symbols: bad chunk_of_mask");
+    const int C_in = chunk_of_mask ? out->C / 4 : out->C;
+    const long long total = (long long)out->H * out->W * C_in;
+    const int32_t none[4] = {-1, -1, -1, -1};
+    const int32_t *cm = chunk_of_mask ? chunk_of_mask : none;
+    hipLaunchKernelGGL(import_symbols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym_nchw,
+                       opt(mean), channel_add, cm[0], cm[1], cm[2], cm[3], mk(out), C_in, out->H, out->W, total);
+    return launch_status("import_symbols");
 }
 
 // ---- error plumbing ---------------------------------------------------------------------------------

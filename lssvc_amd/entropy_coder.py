@@ -81,3 +81,29 @@ class RansDecoder:
     def __del__(self):
         if lib is not None:
             lib.lssvc_rans_decoder_free(self.h)
+
+
+class SymbolSink:
+    """Encoder side of one rANS string: latents are pushed in coding order (as the reference's
+    entropy_coder.reset_encoder / *.encode(...) / flush_encoder sequence, dmc_net_extend.py:89-95)."""
+
+    def __init__(self):
+        self.enc = RansEncoder()
+        self.enc.reset()
+
+    def push(self, symbols, indexes, tables):
+        self.enc.encode_with_indexes(symbols, indexes, tables)
+
+    def flush(self):
+        return self.enc.flush()
+
+
+class SymbolSource:
+    """Decoder side: pulls latents from one rANS string in the same order."""
+
+    def __init__(self, string):
+        self.dec = RansDecoder()
+        self.dec.set_stream(string)
+
+    def pull(self, indexes, tables):
+        return self.dec.decode_stream(indexes, tables)

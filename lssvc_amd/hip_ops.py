@@ -289,11 +289,37 @@ def factorized_quant_bits(z, params, slots, slot, z_hat=None):
                                           stream_ptr()))
 
 
-def gaussian_conditional(y, scale, mean, slots, slot, y_hat=None):
-    check(lib.lssvc_gaussian_conditional(y.ref, scale.ref, mean.ref, _opt(y_hat), slots.slot(slot), slots.wsp,
+def gaussian_conditional(y, scale, mean, slots, slot, y_hat=None, y_q=None):
+    check(lib.lssvc_gaussian_conditional(y.ref, scale.ref, mean.ref, _opt(y_hat), _opt(y_q), slots.slot(slot), slots.wsp,
                                          stream_ptr()))
 
 
-def entropy_bottleneck(z, params, slots, slot, z_hat=None):
-    check(lib.lssvc_entropy_bottleneck(z.ref, C.c_void_p(params.data_ptr()), _opt(z_hat), slots.slot(slot), slots.wsp,
-                                       stream_ptr()))
+def entropy_bottleneck(z, params, slots, slot, z_hat=None, z_q=None):
+    check(lib.lssvc_entropy_bottleneck(z.ref, C.c_void_p(params.data_ptr()), _opt(z_hat), _opt(z_q), slots.slot(slot),
+                                       slots.wsp, stream_ptr()))
+
+
+def export_symbols(q, sigma, index_params=None, chunk_of_mask=None):
+    """-> (symbols, indexes) as host int32 numpy planes in NCHW order (either may be None).
+    index_params = (log_min, log_step, add, levels) when sigma is given; chunk_of_mask folds C -> C/4."""
+    ref = q if q is not None else sigma
+    c_out = ref.C // 4 if chunk_of_mask is not None else ref.C
+    n = ref.H * ref.W * c_out
+    sym = torch.empty(n, dtype=torch.int32, device=ref.device) if q is not None else None
+    idx = torch.empty(n, dtype=torch.int32, device=ref.device)
+    lo, step, add, levels = index_params if index_params is not None else (0.0, 1.0, 0.0, 1)
+    cm = (C.c_int32 * 4)(*chunk_of_mask) if chunk_of_mask is not None else None
+    check(lib.lssvc_export_symbols(_opt(q), _opt(sigma), cm, lo, step, add, levels,
+                                   C.c_void_p(sym.data_ptr()) if sym is not None else None, C.c_void_p(idx.data_ptr()),
+                                   stream_ptr()))
+    return (sym.cpu().numpy() if sym is not None else None), idx.cpu().numpy()
+
+
+def import_symbols(symbols, out, mean=None, channel_add=None, chunk_of_mask=None):
+    """Host int32 NCHW plane -> device, out = sym + mean + channel_add[c] (unfolding C/4 -> C with chunk_of_mask)."""
+    dev = torch.from_numpy(symbols).to(out.device)
+    cm = (C.c_int32 * 4)(*chunk_of_mask) if chunk_of_mask is not None else None
+    check(lib.lssvc_import_symbols(C.c_void_p(dev.data_ptr()), _opt(mean),
+                                   C.c_void_p(channel_add.data_ptr()) if channel_add is not None else None, cm, out.ref,
+                                   stream_ptr()))
+    return out

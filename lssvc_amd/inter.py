@@ -6,17 +6,23 @@ Reference: src/models/LSSVC_net.py:12-528 (EL, `forward_one_frame` :445-528),
 src/models/dmc_net.py:159-488 (BL `DMC.get_inter_layer_information` :421-488),
 src/InterModules/lssvc_modules.py, src/InterModules/video_net_component.py.
 """
+import time
+
 import torch
 
 from . import hip_ops as ops
 from .hip_ops import T
 from . import blocks as B
-from .intra import _HostModel
+from . import bitstream, tables
+from .entropy_coder import SymbolSink, SymbolSource
+from .intra import _HostModel, _channel_indexes, LAPLACE_IDX
 from .weights import strip_module_prefix, validate
 
 # (chunk, mask) pairs per step of the 4-step spatial/channel prior (LSSVC_net.py:361-413):
 # MASK_OF_CHUNK[step][chunk] = 2x2 position index, 0:(0,0) 1:(0,1) 2:(1,0) 3:(1,1)
 MASK_OF_CHUNK = ((0, 1, 2, 3), (3, 2, 1, 0), (2, 3, 0, 1), (1, 0, 3, 2))
+# inverse view used by the folded symbol planes: CHUNK_OF_MASK[step][mask] = channel chunk coded at that 2x2 position
+CHUNK_OF_MASK = tuple(tuple(m.index(k) for k in range(4)) for m in MASK_OF_CHUNK)
 
 
 class LSSVC_extend(_HostModel):
@@ -47,25 +53,54 @@ class LSSVC_extend(_HostModel):
         t = ops.conv_t(W, p + ".2", t, 2, act="lrelu")
         return ops.conv_t(W, p + ".4", t, 1, out=out)
 
-    def _bl_forward(self, x, ref_frame, ref_feature):
-        """DMC.get_inter_layer_information, eval mode (dmc_net.py:421-488). Bit slots 0..3 = y, z, mv_y, mv_z."""
-        W, S, p = self.W, self.slots, "base_layer_model"
-        est_mv = B.spynet(W, p + ".optic_flow", x, ref_frame)
+    def _pull_factorized(self, source, table, c, h, w):
+        """BitEstimator.decode_stream (video_entropy_models.py:240-245): z_hat = decoded symbols."""
+        z_hat = T.empty(h, w, c, self.device)
+        return ops.import_symbols(source.pull(_channel_indexes(c, h, w), table), z_hat)
 
-        # mv_encoder (dmc_net.py:174-188)
-        t, e = est_mv, p + ".mv_encoder"
-        for base in (0, 4, 8):
-            t = ops.conv(W, "%s.%d" % (e, base), t, stride=2)
-            t = ops.gdn(W, "%s.%d" % (e, base + 1), t, "inter")
-            t = B.res_block(W, "%s.%d" % (e, base + 2), t, start_from_relu=False)
-            t = ops.lrelu(t, 0.1)
-        mv_y = ops.conv(W, e + ".12", t, stride=2)
-        mv_z = self._prior_encoder(p + ".mv_prior_encoder", mv_y)
-        mv_z_hat = mv_z.like()
-        ops.factorized_quant_bits(mv_z, W.bit_estimator(p + ".bit_estimator_z_mv"), S, 3, z_hat=mv_z_hat)
+    def _pull_laplace(self, source, scales, means, chunk_of_mask=None, out=None):
+        """GaussianEncoder.decode_stream (video_entropy_models.py:321-326) + the `+ means` that follows it."""
+        _, idx = ops.export_symbols(None, scales, LAPLACE_IDX, chunk_of_mask=chunk_of_mask)
+        if out is None:
+            out = T.empty(scales.H, scales.W, scales.C, self.device)
+        return ops.import_symbols(source.pull(idx, self._tables["laplace"]), out, mean=means, chunk_of_mask=chunk_of_mask)
+
+    def _bl_codec(self, x, ref_frame, ref_feature, sink=None, source=None):
+        """DMC base layer in one of two roles sharing every decoder-side kernel:
+        encoder (x given): get_inter_layer_information (dmc_net.py:421-488) / DMCExtend.compress
+        (dmc_net_extend.py:55-107, symbols pushed to `sink` in the order mv_z, mv_y, z, y);
+        decoder (source given): DMCExtend.decompress (dmc_net_extend.py:109-146).
+        Estimate-mode bit slots 0..3 = y, z, mv_y, mv_z."""
+        W, S, p = self.W, self.slots, "base_layer_model"
+        tb = self._tables
+        decoding = source is not None
+        if not decoding:
+            est_mv = B.spynet(W, p + ".optic_flow", x, ref_frame)
+            # mv_encoder (dmc_net.py:174-188)
+            t, e = est_mv, p + ".mv_encoder"
+            for base in (0, 4, 8):
+                t = ops.conv(W, "%s.%d" % (e, base), t, stride=2)
+                t = ops.gdn(W, "%s.%d" % (e, base + 1), t, "inter")
+                t = B.res_block(W, "%s.%d" % (e, base + 2), t, start_from_relu=False)
+                t = ops.lrelu(t, 0.1)
+            mv_y = ops.conv(W, e + ".12", t, stride=2)
+            mv_z = self._prior_encoder(p + ".mv_prior_encoder", mv_y)
+            mv_z_hat = mv_z.like()
+            ops.factorized_quant_bits(mv_z, W.bit_estimator(p + ".bit_estimator_z_mv"), S, 3, z_hat=mv_z_hat)
+            if sink:
+                sink.push(*ops.export_symbols(mv_z_hat, None), tb["bl_z_mv"])
+        else:
+            zh, zw = bitstream.get_downsampled_shape(ref_frame.H, ref_frame.W, 64)
+            mv_z_hat = self._pull_factorized(source, tb["bl_z_mv"], 64, zh, zw)
         mv_scales, mv_means = self._prior_decoder_bl(p + ".mv_prior_decoder", mv_z_hat).chunk(2)
-        mv_y_hat = mv_y.like()
-        ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 2, y_hat=mv_y_hat)
+        if not decoding:
+            mv_y_hat = mv_y.like()
+            mv_y_q = mv_y.like() if sink else None
+            ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 2, y_q=mv_y_q, y_hat=mv_y_hat)
+            if sink:
+                sink.push(*ops.export_symbols(mv_y_q, mv_scales, LAPLACE_IDX), tb["laplace"])
+        else:
+            mv_y_hat = self._pull_laplace(source, mv_scales, mv_means)
 
         # mv_decoder (dmc_net.py:208-221)
         d = p + ".mv_decoder"
@@ -85,10 +120,15 @@ class LSSVC_extend(_HostModel):
         c1, c2, c3 = B.context_fusion(W, p + ".context_fusion_net", ops.flow_warp(r1, mv_hat), ops.flow_warp(r2, mv2),
                                       ops.flow_warp(r3, mv3))
 
-        y = B.res_encoder_gdn(W, p + ".res_encoder", x, c1, c2, c3, "inter")
-        z = self._prior_encoder(p + ".res_prior_encoder", y)
-        z_hat = z.like()
-        ops.factorized_quant_bits(z, W.bit_estimator(p + ".bit_estimator_z"), S, 1, z_hat=z_hat)
+        if not decoding:
+            y = B.res_encoder_gdn(W, p + ".res_encoder", x, c1, c2, c3, "inter")
+            z = self._prior_encoder(p + ".res_prior_encoder", y)
+            z_hat = z.like()
+            ops.factorized_quant_bits(z, W.bit_estimator(p + ".bit_estimator_z"), S, 1, z_hat=z_hat)
+            if sink:
+                sink.push(*ops.export_symbols(z_hat, None), tb["bl_z"])
+        else:
+            z_hat = self._pull_factorized(source, tb["bl_z"], 64, zh, zw)
 
         # params = cat(temporal 192, hierarchical 192) -> res_entropy_parameter (dmc_net.py:440-445)
         q = p + ".temporal_prior_encoder"
@@ -101,8 +141,14 @@ class LSSVC_extend(_HostModel):
         t = ops.conv(W, q + ".0", [temporal, hier], act="lrelu")
         t = ops.conv(W, q + ".2", t, act="lrelu")
         scales, means = ops.conv(W, q + ".4", t).chunk(2)
-        y_hat = y.like()
-        ops.laplace_quant_bits(y, means, scales, S, 0, y_hat=y_hat)
+        if not decoding:
+            y_hat = y.like()
+            y_q = y.like() if sink else None
+            ops.laplace_quant_bits(y, means, scales, S, 0, y_q=y_q, y_hat=y_hat)
+            if sink:
+                sink.push(*ops.export_symbols(y_q, scales, LAPLACE_IDX), tb["laplace"])
+        else:
+            y_hat = self._pull_laplace(source, scales, means)
 
         res = B.res_decoder_gdn(W, p + ".res_decoder", y_hat, c2, c3, "inter")
         feature, recon = B.recon_generation(W, p + ".recon_generation_net", res, c1)
@@ -197,11 +243,15 @@ class LSSVC_extend(_HostModel):
         d3 = B.depth_conv_block(W, p + ".up_conv3", [x2, ops.subpel(W, p + ".up3", x3)])
         return B.depth_conv_block(W, p + ".up_conv2", [x1, ops.subpel(W, p + ".up2", d3)])
 
-    def _four_part_prior(self, y, common):
-        """LSSVC.forward_four_part_prior, write=False (LSSVC_net.py:338-443): four masked quantise steps;
-        steps 2-4 recompute (sigma, mu) from cat(y_hat_so_far, common_params)."""
+    def _four_part_prior(self, y, common, sink=None, source=None):
+        """LSSVC.forward_four_part_prior (LSSVC_net.py:338-443) / compress_four_part_prior (write=True) /
+        decompress_four_part_prior (LSSVC_net_extend.py:193-263): four masked steps; steps 2-4 recompute
+        (sigma, mu) from cat(y_hat_so_far, common_params). Encoder: quantise y; decoder: pull the folded
+        C/4-channel symbol plane of each step from the stream and unfold it."""
         W = self.W
-        y_q, y_hat, s_hat = T.zeros(y.H, y.W, y.C, y.device), T.zeros(y.H, y.W, y.C, y.device), T.zeros(y.H, y.W, y.C, y.device)
+        ref = common.slice(0, common.C // 2)
+        mk = lambda: T.zeros(ref.H, ref.W, ref.C, self.device)
+        y_q, y_hat, s_hat = (mk() if source is None else None), mk(), (mk() if source is None else None)
         scales, means = common.chunk(2)
         for step in range(4):
             if step > 0:
@@ -209,16 +259,24 @@ class LSSVC_extend(_HostModel):
                 for i in range(3):
                     t = B.depth_conv_block(W, "y_spatial_prior.%d" % i, t)
                 scales, means = t.chunk(2)
-            ops.four_part_step(y, means, scales, MASK_OF_CHUNK[step], y_q, y_hat, s_hat)
+            if source is None:
+                ops.four_part_step(y, means, scales, MASK_OF_CHUNK[step], y_q, y_hat, s_hat)
+            else:
+                self._pull_laplace(source, scales, means, chunk_of_mask=CHUNK_OF_MASK[step], out=y_hat)
+        if sink:
+            for step in range(4):          # y_q_w_0..3 / scales_w_0..3 (LSSVC_net.py:432-442), pushed after the loop
+                sink.push(*ops.export_symbols(y_q, s_hat, LAPLACE_IDX, chunk_of_mask=CHUNK_OF_MASK[step]), self._tables["laplace"])
         return y_q, y_hat, s_hat
 
-    def _forward(self, xb, xe, ref_bl, ref_el, feat_bl, feat_el):
-        """LSSVC.forward_one_frame (LSSVC_net.py:445-528) on NHWC views. EL bit slots 4..7 = y, mv_y, z, mv_z."""
+    def _el_codec(self, xe, bl, ref_el, feat_el, sink=None, source=None):
+        """LSSVC enhancement layer; `bl` = base-layer outputs {feature, mv_hat, y_hat} (encoder-side in estimate
+        mode, DECODED in write mode, LSSVC_net_extend.py:143-147). Encoder: forward_one_frame
+        (LSSVC_net.py:458-508) / compress (LSSVC_net_extend.py:24-84, symbols pushed in the order mv_z, mv_y, z,
+        y_w0..3); decoder: decompress (LSSVC_net_extend.py:86-136). EL estimate bit slots 4..7 = y, mv_y, z, mv_z."""
         W, S = self.W, self.slots
+        tb = self._tables
         H, Wd = self.shape_hr
-        assert (xe.H, xe.W) == (H, Wd), "x_el is %dx%d but shape_hr is %dx%d" % (xe.H, xe.W, H, Wd)
-        bl = self._bl_forward(xb, ref_bl, feat_bl)
-
+        decoding = source is not None
         mv_up = self._mv_resampler(bl["mv_hat"])
         # mv_ctx_prior_encoder (LSSVC_net.py:108-116)
         t, e = mv_up, "mv_ctx_prior_encoder"
@@ -227,20 +285,26 @@ class LSSVC_extend(_HostModel):
         mv_ctx_prior = ops.conv(W, e + ".6", t, stride=2)
         mv_ctx = B.res_block(W, "mv_ctx_transform.transform.1", ops.conv(W, "mv_ctx_transform.transform.0", mv_up, stride=2))
 
-        mv = B.spynet(W, "optic_flow", xe, ref_el)
-        # MVResEncoder (lssvc_modules.py:445-469)
-        e = "mv_encoder.encoder1"
-        t = ops.gdn(W, e + ".1", ops.conv(W, e + ".0", mv, stride=2), "inter")
-        t = ops.lrelu(B.res_block(W, e + ".2", t, start_from_relu=False), 0.1)
-        e = "mv_encoder.encoder2"
-        t = ops.gdn(W, e + ".1", ops.conv(W, e + ".0", [t, mv_ctx], stride=2), "inter")
-        t = ops.lrelu(B.res_block(W, e + ".2", t, start_from_relu=False), 0.1)
-        t = ops.gdn(W, e + ".5", ops.conv(W, e + ".4", t, stride=2), "inter")
-        t = ops.lrelu(B.res_block(W, e + ".6", t, start_from_relu=False), 0.1)
-        mv_y = ops.conv(W, e + ".8", t, stride=2)
-        mv_z = self._prior_encoder("mv_prior_encoder", mv_y)
-        mv_z_hat = mv_z.like()
-        ops.factorized_quant_bits(mv_z, W.bit_estimator("bit_estimator_z_mv"), S, 7, z_hat=mv_z_hat)
+        zh, zw = bitstream.get_downsampled_shape(H, Wd, 64)
+        if not decoding:
+            mv = B.spynet(W, "optic_flow", xe, ref_el)
+            # MVResEncoder (lssvc_modules.py:445-469)
+            e = "mv_encoder.encoder1"
+            t = ops.gdn(W, e + ".1", ops.conv(W, e + ".0", mv, stride=2), "inter")
+            t = ops.lrelu(B.res_block(W, e + ".2", t, start_from_relu=False), 0.1)
+            e = "mv_encoder.encoder2"
+            t = ops.gdn(W, e + ".1", ops.conv(W, e + ".0", [t, mv_ctx], stride=2), "inter")
+            t = ops.lrelu(B.res_block(W, e + ".2", t, start_from_relu=False), 0.1)
+            t = ops.gdn(W, e + ".5", ops.conv(W, e + ".4", t, stride=2), "inter")
+            t = ops.lrelu(B.res_block(W, e + ".6", t, start_from_relu=False), 0.1)
+            mv_y = ops.conv(W, e + ".8", t, stride=2)
+            mv_z = self._prior_encoder("mv_prior_encoder", mv_y)
+            mv_z_hat = mv_z.like()
+            ops.factorized_quant_bits(mv_z, W.bit_estimator("bit_estimator_z_mv"), S, 7, z_hat=mv_z_hat)
+            if sink:
+                sink.push(*ops.export_symbols(mv_z_hat, None), tb["el_z_mv"])
+        else:
+            mv_z_hat = self._pull_factorized(source, tb["el_z_mv"], 64, zh, zw)
         q = "mv_prior_decoder"
         t = ops.subpel(W, q + ".0", mv_z_hat, act="lrelu")
         t = ops.subpel(W, q + ".2", t, act="lrelu")
@@ -249,8 +313,14 @@ class LSSVC_extend(_HostModel):
         t = ops.conv(W, q + ".0", [hyper, mv_ctx_prior], act="lrelu")
         t = ops.conv(W, q + ".2", t, act="lrelu")
         mv_scales, mv_means = ops.conv(W, q + ".4", t).chunk(2)
-        mv_y_hat = mv_y.like()
-        ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 5, y_hat=mv_y_hat)
+        if not decoding:
+            mv_y_hat = mv_y.like()
+            mv_y_q = mv_y.like() if sink else None
+            ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 5, y_q=mv_y_q, y_hat=mv_y_hat)
+            if sink:
+                sink.push(*ops.export_symbols(mv_y_q, mv_scales, LAPLACE_IDX), tb["laplace"])
+        else:
+            mv_y_hat = self._pull_laplace(source, mv_scales, mv_means)
         # MVResDecoder (lssvc_modules.py:472-494)
         d = "mv_decoder.decoder1"
         t = ops.subpel(W, d + ".0", mv_y_hat, act="lrelu", slope=0.1)
@@ -264,24 +334,29 @@ class LSSVC_extend(_HostModel):
 
         c1, c2, c3, warp_frame = self._el_context(bl["feature"], mv_hat, ref_el, feat_el)
 
-        # ResEncoder without GDN (lssvc_modules.py:235-254); the concat feeding each ResBlock is built in place
-        p = "res_encoder"
-        t = T.empty(H // 2, Wd // 2, 64 + c2.C, self.device)
-        ops.conv(W, p + ".conv1", [xe, c1], stride=2, out=t.slice(0, 64))
-        ops.copy(c2, t.slice(64, t.C))
-        t = B.res_block(W, p + ".res1", t, slope=0.1, end_with_relu=True)
-        u = T.empty(H // 4, Wd // 4, 96 + c3.C, self.device)
-        ops.conv(W, p + ".conv2", t, stride=2, out=u.slice(0, 96))
-        ops.copy(c3, u.slice(96, u.C))
-        u = B.res_block(W, p + ".res2", u, slope=0.1, end_with_relu=True)
-        y = ops.conv(W, p + ".conv4", ops.conv(W, p + ".conv3", u, stride=2), stride=2)
-
-        z = self._prior_encoder("res_prior_encoder", y)
-        z_hat = z.like()
-        ops.factorized_quant_bits(z, W.bit_estimator("bit_estimator_z"), S, 6, z_hat=z_hat)
+        if not decoding:
+            # ResEncoder without GDN (lssvc_modules.py:235-254); the concat feeding each ResBlock is built in place
+            p = "res_encoder"
+            t = T.empty(H // 2, Wd // 2, 64 + c2.C, self.device)
+            ops.conv(W, p + ".conv1", [xe, c1], stride=2, out=t.slice(0, 64))
+            ops.copy(c2, t.slice(64, t.C))
+            t = B.res_block(W, p + ".res1", t, slope=0.1, end_with_relu=True)
+            u = T.empty(H // 4, Wd // 4, 96 + c3.C, self.device)
+            ops.conv(W, p + ".conv2", t, stride=2, out=u.slice(0, 96))
+            ops.copy(c3, u.slice(96, u.C))
+            u = B.res_block(W, p + ".res2", u, slope=0.1, end_with_relu=True)
+            y = ops.conv(W, p + ".conv4", ops.conv(W, p + ".conv3", u, stride=2), stride=2)
+            z = self._prior_encoder("res_prior_encoder", y)
+            z_hat = z.like()
+            ops.factorized_quant_bits(z, W.bit_estimator("bit_estimator_z"), S, 6, z_hat=z_hat)
+            if sink:
+                sink.push(*ops.export_symbols(z_hat, None), tb["el_z"])
+        else:
+            y = None
+            z_hat = self._pull_factorized(source, tb["el_z"], 128, zh, zw)
 
         # prior fusion input cat(hyper 128, temporal 128, layer 128) written in place (lssvc_modules.py:440-442)
-        fused = T.empty(y.H, y.W, 384, self.device)
+        fused = T.empty(H // 16, Wd // 16, 384, self.device)
         q = "res_prior_decoder"                                     # LSSVC_net.py:63-73
         t = ops.conv(W, q + ".0", z_hat, act="lrelu")
         t = ops.subpel(W, q + ".2", t, act="lrelu")
@@ -294,8 +369,9 @@ class LSSVC_extend(_HostModel):
         self._layer_prior_resampler(bl["y_hat"], out=fused.slice(256, 384))
         params = B.depth_conv_block(W, "prior_fusion_net.prior_fusion_conv.1",
                                     B.depth_conv_block(W, "prior_fusion_net.prior_fusion_conv.0", fused))
-        y_q, y_hat, scales_hat = self._four_part_prior(y, params)
-        ops.laplace_bits(y_q, scales_hat, S, 4)
+        y_q, y_hat, scales_hat = self._four_part_prior(y, params, sink=sink, source=source)
+        if not decoding:
+            ops.laplace_bits(y_q, scales_hat, S, 4)
 
         # ResDecoder (lssvc_modules.py:257-276)
         p = "res_decoder"
@@ -315,14 +391,17 @@ class LSSVC_extend(_HostModel):
         f = ops.conv(W, p + ".first_conv", [res, c1])
         feature = self._unet(p + ".unet_2", self._unet(p + ".unet_1", f))
         recon_el = ops.conv(W, p + ".recon_conv", feature)
-        return bl, feature, recon_el, mv_hat, warp_frame
+        return feature, recon_el, mv_hat, warp_frame
 
     # ---------------------------------------------------------------------------------------------
     def forward_one_frame(self, x_bl, x_el, ref_frame_bl, ref_frame_el, ref_feature_bl, ref_feature_el):
+        """LSSVC.forward_one_frame (LSSVC_net.py:445-528): estimate mode."""
         self._require_device()
         nhwc = lambda t: None if t is None else T.from_nchw(t)
-        bl, feature, recon_el, mv_hat, warp_frame = self._forward(
-            nhwc(x_bl), nhwc(x_el), nhwc(ref_frame_bl), nhwc(ref_frame_el), nhwc(ref_feature_bl), nhwc(ref_feature_el))
+        xe = nhwc(x_el)
+        assert (xe.H, xe.W) == self.shape_hr, "x_el is %dx%d but shape_hr is %s" % (xe.H, xe.W, self.shape_hr)
+        bl = self._bl_codec(nhwc(x_bl), nhwc(ref_frame_bl), nhwc(ref_feature_bl))
+        feature, recon_el, mv_hat, warp_frame = self._el_codec(xe, bl, nhwc(ref_frame_el), nhwc(ref_feature_el))
         dpb = {"ref_frame_bl": bl["recon"].to_nchw(), "ref_feature_bl": bl["feature"].to_nchw(),
                "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()}
         out = {"dpb": dpb, "mv_hat": mv_hat.to_nchw(), "warp_frame": warp_frame.to_nchw(),
@@ -332,13 +411,62 @@ class LSSVC_extend(_HostModel):
         out["bit_el"] = s[4] + s[5] + s[6] + s[7]          # y + mv_y + z + mv_z  (LSSVC_net.py:508)
         return out
 
+    def encode_decode_extend(self, x_bl, x_el, dpb, output_path_bl, output_path_el):
+        """LSSVC_extend.encode_decode_extend (LSSVC_net_extend.py:138-191) with DMCExtend.encode_decode_extend
+        (dmc_net_extend.py:148-173): each layer is compressed to a real rANS string, framed, written, read back
+        and DECODED; the decoded tensors become the DPB. The EL sees the DECODED base layer."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        nhwc = lambda t: None if t is None else T.from_nchw(t)
+        xb, xe = nhwc(x_bl), nhwc(x_el)
+        ref_bl, ref_el = nhwc(dpb["ref_frame_bl"]), nhwc(dpb["ref_frame_el"])
+        feat_bl, feat_el = nhwc(dpb["ref_feature_bl"]), nhwc(dpb["ref_feature_el"])
+        sync = lambda: torch.cuda.synchronize(self.device)
+        # ---- base layer ----
+        sync(); t0 = time.time()
+        sink = SymbolSink()
+        bl_e = self._bl_codec(xb, ref_bl, feat_bl, sink=sink)
+        bitstream.encode_p(sink.flush(), output_path_bl)
+        bit_bl = bitstream.filesize(output_path_bl) * 8
+        sync(); t1 = time.time()
+        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(output_path_bl)))
+        recon_bl = bl["recon"].to_nchw().clamp_(0, 1)                         # dmc_net_extend.py:138
+        sync(); t2 = time.time()
+        # ---- enhancement layer ----
+        sink = SymbolSink()
+        feature_e, recon_e, mv_hat, warp_frame = self._el_codec(xe, bl, ref_el, feat_el, sink=sink)
+        bitstream.encode_p(sink.flush(), output_path_el)
+        bit_el = bitstream.filesize(output_path_el) * 8
+        est = self.slots.fetch()
+        sync(); t3 = time.time()
+        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(output_path_el)))
+        sync(); t4 = time.time()
+        out_dpb = {"ref_frame_bl": recon_bl, "ref_feature_bl": bl["feature"].to_nchw(),
+                   "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()}
+        return {"dpb": out_dpb, "bit_bl": bit_bl, "bit_el": bit_el,
+                "encoding_time_BL": t1 - t0, "decoding_time_BL": t2 - t1, "encoding_time_EL": t3 - t2, "decoding_time_EL": t4 - t3,
+                "mv_hat": mv_hat.to_nchw(), "warp_frame": warp_frame.to_nchw(),
+                # extras (not in the reference's dict)
+                "bit_bl_estimate": est[0] + est[1] + est[2] + est[3], "bit_el_estimate": est[4] + est[5] + est[6] + est[7],
+                "encoder_side": {"ref_frame_bl": bl_e["recon"].to_nchw(), "ref_feature_bl": bl_e["feature"].to_nchw(),
+                                 "ref_frame_el": recon_e.to_nchw(), "ref_feature_el": feature_e.to_nchw()}}
+
     def encode_decode(self, x_bl, x_el, dpb, output_path_bl=None, output_path_el=None,
                       pic_width=None, pic_height=None, pic_width_bl=None, pic_height_bl=None):
         """LSSVC.encode_decode (LSSVC_net.py:172-185). output_path_el None <=> estimate mode."""
         if output_path_el is not None:
-            raise NotImplementedError("write_stream=1 (real bitstream) is not built yet in lssvc_amd; use estimate mode")
+            return self.encode_decode_extend(x_bl, x_el, dpb, output_path_bl, output_path_el)
         return self.forward_one_frame(x_bl, x_el, dpb["ref_frame_bl"], dpb["ref_frame_el"], dpb["ref_feature_bl"],
                                       dpb["ref_feature_el"])
 
     def update(self, force=False):
-        raise NotImplementedError("update() builds CDF tables for write_stream=1, which is not built yet")
+        """LSSVC_extend.update + DMCExtend.update (LSSVC_net_extend.py:17-22, dmc_net_extend.py:49-53)."""
+        if self._tables is not None and not force:
+            return
+        sd = self._sd
+        self._tables = {"laplace": tables.laplace_tables(),
+                        "el_z": tables.bit_estimator_tables(sd, "bit_estimator_z"),
+                        "el_z_mv": tables.bit_estimator_tables(sd, "bit_estimator_z_mv"),
+                        "bl_z": tables.bit_estimator_tables(sd, "base_layer_model.bit_estimator_z"),
+                        "bl_z_mv": tables.bit_estimator_tables(sd, "base_layer_model.bit_estimator_z_mv")}

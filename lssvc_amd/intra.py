@@ -13,7 +13,19 @@ import torch
 from . import hip_ops as ops
 from .hip_ops import T
 from . import blocks as B
+from . import bitstream, tables
+from .entropy_coder import SymbolSink, SymbolSource
 from .weights import WeightStore, strip_module_prefix, validate
+
+GAUSS_IDX = tables.index_params(tables.GAUSSIAN, 1.0)       # GaussianConditional.build_indexes (+1)
+LAPLACE_IDX = tables.index_params(tables.LAPLACE, 0.0)      # GaussianEncoder.build_indexes
+
+
+def _channel_indexes(c, h, w):
+    """BitEstimator / EntropyBottleneck build_indexes: index = channel, NCHW order (video_entropy_models.py:225-231)."""
+    import numpy as np
+    return np.repeat(np.arange(c, dtype=np.int32), h * w)
+
 
 _CDF_BUFFERS = ("._offset", "._quantized_cdf", "._cdf_length")
 
@@ -28,6 +40,8 @@ class _HostModel:
         self.scale_factor = 2.0
         self.pad_size = (0, 0, 0, 0)
         self.training = False
+        self._tables = None
+        self._medians = {}
 
     def to(self, device):
         device = torch.device(device)
@@ -93,25 +107,49 @@ class IntraSS(_HostModel):
         return cls(sd)
 
     # ---------------------------------------------------------------------------------------------
-    def _bl_forward(self, x_bl):
-        """IntraNoAR.get_layer_information (priors.py:368-388)."""
+    # Every codec stage below runs in one of two roles with the SAME kernels on the shared part:
+    #   encoder (x given):      analysis transform -> quantise -> [push symbols to a SymbolSink] -> synthesis
+    #   decoder (source given): pull symbols from a SymbolSource -> synthesis
+    # so that the decoder's sigma -> table index is computed by exactly the code that the encoder ran.
+    def _bl_codec(self, x_bl, sinks=None, sources=None, lat_hw=None):
+        """IntraNoAR: get_layer_information (priors.py:368-388) / compress (:422-437) / decompress (:439-452).
+        sinks / sources = (y_coder, z_coder): the reference writes y and z as two rANS strings."""
         W, p = self.W, "base_layer_model"
-        g = p + ".g_a"
-        t = B.residual_block_with_stride(W, g + ".0", x_bl)
-        t = B.residual_block(W, g + ".1", t)
-        t = B.residual_block_with_stride(W, g + ".2", t)
-        t = B.residual_block(W, g + ".3", t)
-        t = B.residual_block_with_stride(W, g + ".4", t)
-        t = B.residual_block(W, g + ".5", t)
-        y = ops.conv(W, g + ".6", t, stride=2)
-        z = _lrelu_conv_seq(W, p + ".h_a", y, [(0, "conv", 1), (2, "conv", 1), (4, "conv", 2), (6, "conv", 1), (8, "conv", 2)])
-        z_hat = z.like()
-        ops.entropy_bottleneck(z, W.entropy_bottleneck(p + ".entropy_bottleneck"), self.slots, 1, z_hat=z_hat)
+        T_ = self._tables
+        N = self.N_bl
+        if sources is None:
+            g = p + ".g_a"
+            t = B.residual_block_with_stride(W, g + ".0", x_bl)
+            t = B.residual_block(W, g + ".1", t)
+            t = B.residual_block_with_stride(W, g + ".2", t)
+            t = B.residual_block(W, g + ".3", t)
+            t = B.residual_block_with_stride(W, g + ".4", t)
+            t = B.residual_block(W, g + ".5", t)
+            y = ops.conv(W, g + ".6", t, stride=2)
+            z = _lrelu_conv_seq(W, p + ".h_a", y, [(0, "conv", 1), (2, "conv", 1), (4, "conv", 2), (6, "conv", 1), (8, "conv", 2)])
+            z_hat = z.like()
+            z_q = z.like() if sinks else None
+            ops.entropy_bottleneck(z, W.entropy_bottleneck(p + ".entropy_bottleneck"), self.slots, 1, z_hat=z_hat, z_q=z_q)
+            if sinks:
+                sinks[1].push(*ops.export_symbols(z_q, None), T_["bl_eb"][0])
+        else:
+            zh, zw = lat_hw
+            z_hat = T.empty(zh, zw, N, self.device)
+            idx = _channel_indexes(N, zh, zw)
+            ops.import_symbols(sources[1].pull(idx, T_["bl_eb"][0]), z_hat, channel_add=self._dev_medians("bl_eb"))
         params = _lrelu_conv_seq(W, p + ".h_s", z_hat,
                                  [(0, "conv", 1), (2, "subpel", 1), (4, "conv", 1), (6, "subpel", 1), (8, "conv", 1)])
         scales, means = params.chunk(2)
-        y_hat = y.like()
-        ops.gaussian_conditional(y, scales, means, self.slots, 0, y_hat=y_hat)
+        if sources is None:
+            y_hat = y.like()
+            y_q = y.like() if sinks else None
+            ops.gaussian_conditional(y, scales, means, self.slots, 0, y_hat=y_hat, y_q=y_q)
+            if sinks:
+                sinks[0].push(*ops.export_symbols(y_q, scales, GAUSS_IDX), T_["gauss"])
+        else:
+            y_hat = T.empty(scales.H, scales.W, scales.C, self.device)
+            _, idx = ops.export_symbols(None, scales, GAUSS_IDX)
+            ops.import_symbols(sources[0].pull(idx, T_["gauss"]), y_hat, mean=means)
         g = p + ".g_s"
         t = B.residual_block(W, g + ".0", y_hat)
         t = B.residual_block_upsample(W, g + ".1", t)
@@ -123,15 +161,11 @@ class IntraSS(_HostModel):
         x_hat = ops.subpel(W, g + ".7", t)
         return x_hat, y_hat
 
-    def forward(self, x_bl, x_el):
-        """IntraSS.forward (IntraSS.py:137-172)."""
-        self._require_device()
+    def _el_codec(self, xe, x_hat_bl, y_hat_bl, sinks=None, sources=None, lat_hw=None):
+        """IntraSS EL: forward (IntraSS.py:148-161) / compress (:304-314) / decompress (:316-336)."""
         W = self.W
+        T_ = self._tables
         H, Wd = self.shape_hr
-        xb, xe = T.from_nchw(x_bl), T.from_nchw(x_el)
-        assert (xe.H, xe.W) == (H, Wd), "x_el is %dx%d but shape_hr is %dx%d" % (xe.H, xe.W, H, Wd)
-        x_hat_bl, y_hat_bl = self._bl_forward(xb)
-
         # multi_scale_context_mining (IntraSS.py:119-122)
         t = ops.conv(W, "texture_resampler.conv_adaptor.0", x_hat_bl, act="lrelu")
         t = ops.conv(W, "texture_resampler.conv_adaptor.2", t)
@@ -139,13 +173,22 @@ class IntraSS(_HostModel):
         t1, t2, t3 = B.pyramid_extractor(W, "texture_extractor", tex)
         c1, c2, c3 = B.context_fusion(W, "context_fusion_net", t1, t2, t3)
 
-        y = B.res_encoder_gdn(W, "g_a", xe, c1, c2, c3, "intra")
-        z = _lrelu_conv_seq(W, "h_a", y, [(0, "conv", 1), (2, "conv", 2), (4, "conv", 2)])
-        z_hat = z.like()
-        ops.entropy_bottleneck(z, W.entropy_bottleneck("entropy_bottleneck"), self.slots, 3, z_hat=z_hat)
+        if sources is None:
+            y = B.res_encoder_gdn(W, "g_a", xe, c1, c2, c3, "intra")
+            z = _lrelu_conv_seq(W, "h_a", y, [(0, "conv", 1), (2, "conv", 2), (4, "conv", 2)])
+            z_hat = z.like()
+            z_q = z.like() if sinks else None
+            ops.entropy_bottleneck(z, W.entropy_bottleneck("entropy_bottleneck"), self.slots, 3, z_hat=z_hat, z_q=z_q)
+            if sinks:
+                sinks[1].push(*ops.export_symbols(z_q, None), T_["eb"][0])
+        else:
+            zh, zw = lat_hw
+            z_hat = T.empty(zh, zw, 64, self.device)
+            ops.import_symbols(sources[1].pull(_channel_indexes(64, zh, zw), T_["eb"][0]), z_hat,
+                               channel_add=self._dev_medians("eb"))
 
         # PriorFusion input cat(hyper 192, layer 96, context_params 192) is written in place (layers.py:489-492)
-        fused = T.empty(y.H, y.W, 480, self.device)
+        fused = T.empty(H // 16, Wd // 16, 480, self.device)
         _lrelu_conv_seq(W, "h_s", z_hat, [(0, "subpel", 1), (2, "subpel", 1), (4, "conv", 1)], out=fused.slice(0, 192))
         t = ops.conv(W, "layer_prior_resampler.conv_adaptor.0", y_hat_bl, act="lrelu")
         t = ops.conv(W, "layer_prior_resampler.conv_adaptor.2", t)
@@ -156,12 +199,29 @@ class IntraSS(_HostModel):
         t = ops.conv(W, "prior_fusion_net.params_net.2", t, act="lrelu")
         params = ops.conv(W, "prior_fusion_net.params_net.4", t)
         scales, means = params.chunk(2)
-        y_hat = y.like()
-        ops.gaussian_conditional(y, scales, means, self.slots, 2, y_hat=y_hat)
+        if sources is None:
+            y_hat = y.like()
+            y_q = y.like() if sinks else None
+            ops.gaussian_conditional(y, scales, means, self.slots, 2, y_hat=y_hat, y_q=y_q)
+            if sinks:
+                sinks[0].push(*ops.export_symbols(y_q, scales, GAUSS_IDX), T_["gauss"])
+        else:
+            y_hat = T.empty(scales.H, scales.W, scales.C, self.device)
+            _, idx = ops.export_symbols(None, scales, GAUSS_IDX)
+            ops.import_symbols(sources[0].pull(idx, T_["gauss"]), y_hat, mean=means)
 
         res_hat = B.res_decoder_gdn(W, "g_s", y_hat, c2, c3, "intra")
         feature, x_hat = B.recon_generation(W, "recon_net", res_hat, c1)
+        return feature, x_hat
 
+    def forward(self, x_bl, x_el):
+        """IntraSS.forward (IntraSS.py:137-172): estimate mode."""
+        self._require_device()
+        H, Wd = self.shape_hr
+        xb, xe = T.from_nchw(x_bl), T.from_nchw(x_el)
+        assert (xe.H, xe.W) == (H, Wd), "x_el is %dx%d but shape_hr is %dx%d" % (xe.H, xe.W, H, Wd)
+        x_hat_bl, y_hat_bl = self._bl_codec(xb)
+        feature, x_hat = self._el_codec(xe, x_hat_bl, y_hat_bl)
         out = {"x_hat_bl": x_hat_bl.to_nchw(), "x_hat_el": x_hat.to_nchw(), "feature_el": feature.to_nchw()}
         s = self.slots.fetch()
         out["bit_bl"] = (s[0] + s[1]) / (-math.log(2))
@@ -170,11 +230,47 @@ class IntraSS(_HostModel):
 
     def encode_decode(self, x_bl, x_el, bin_path_bl, bin_path_el,
                       pic_height_bl=None, pic_width_bl=None, pic_height_el=None, pic_width_el=None):
-        """IntraSS.encode_decode (IntraSS.py:245-302). bin_path None <=> estimate mode."""
+        """IntraSS.encode_decode (IntraSS.py:245-302). bin_path None <=> estimate mode; otherwise both layers are
+        written to real bitstreams, read back and DECODED, and the decoded tensors are returned."""
         if bin_path_bl is None:
             return self.forward(x_bl, x_el)
-        raise NotImplementedError("write_stream=1 (real bitstream) is not built yet in lssvc_amd; use estimate mode")
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")       # img_entropy_models.py:265-267
+        assert pic_height_el is not None and pic_width_el is not None
+        xb, xe = T.from_nchw(x_bl), T.from_nchw(x_el)
+        # ---- encode ----
+        sinks = (SymbolSink(), SymbolSink())
+        x_hat_bl_e, y_hat_bl_e = self._bl_codec(xb, sinks=sinks)
+        bitstream.encode_i(pic_height_bl, pic_width_bl, sinks[0].flush(), sinks[1].flush(), bin_path_bl)
+        bit_bl = bitstream.filesize(bin_path_bl) * 8
+        sinks = (SymbolSink(), SymbolSink())
+        feature_e, x_hat_e = self._el_codec(xe, x_hat_bl_e, y_hat_bl_e, sinks=sinks)
+        bitstream.encode_i(pic_height_el, pic_width_el, sinks[0].flush(), sinks[1].flush(), bin_path_el)
+        bit_el = bitstream.filesize(bin_path_el) * 8
+        est = self.slots.fetch()
+        # ---- decode ----
+        h, w, y_string, z_string = bitstream.decode_i(bin_path_bl)
+        x_hat_bl, y_hat_bl = self._bl_codec(None, sources=(SymbolSource(y_string), SymbolSource(z_string)),
+                                            lat_hw=bitstream.get_downsampled_shape(h, w, 64))
+        h, w, y_string, z_string = bitstream.decode_i(bin_path_el)
+        feature, x_hat = self._el_codec(None, x_hat_bl, y_hat_bl, sources=(SymbolSource(y_string), SymbolSource(z_string)),
+                                        lat_hw=bitstream.get_downsampled_shape(h, w, 64))
+        return {"bit_bl": bit_bl, "bit_el": bit_el, "x_hat_bl": x_hat_bl.to_nchw(), "x_hat_el": x_hat.to_nchw(),
+                "feature_el": feature.to_nchw(),
+                # extras (not in the reference's dict): estimated bits and the encoder-side reconstructions
+                "bit_bl_estimate": (est[0] + est[1]) / (-math.log(2)), "bit_el_estimate": (est[2] + est[3]) / (-math.log(2)),
+                "encoder_side": {"x_hat_bl": x_hat_bl_e.to_nchw(), "x_hat_el": x_hat_e.to_nchw(), "feature_el": feature_e.to_nchw()}}
 
     def update(self, force=False):
-        """Only needed for write_stream=1 (test.py:561-564)."""
-        raise NotImplementedError("update() builds CDF tables for write_stream=1, which is not built yet")
+        """IntraSS.update (IntraSS.py:234-237): build the CDF tables the real bitstream needs (test.py:561-564)."""
+        if self._tables is not None and not force:
+            return
+        self._tables = {"gauss": tables.gaussian_tables(), "eb": tables.bottleneck_tables(self._sd, "entropy_bottleneck"),
+                        "bl_eb": tables.bottleneck_tables(self._sd, "base_layer_model.entropy_bottleneck")}
+        self._medians = {}
+
+    def _dev_medians(self, which):
+        if which not in self._medians:
+            self._medians[which] = torch.from_numpy(self._tables[which][1]).to(self.device)
+        return self._medians[which]

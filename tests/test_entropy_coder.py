@@ -85,3 +85,48 @@ def test_empty_and_error_paths(oracle_rans):
     dec.set_stream(data[:len(data) // 2 // 4 * 4])
     with pytest.raises(LssvcHipError):
         dec.decode_stream(rng.integers(0, 6, 4000), t)                     # truncated stream is detected, not over-read
+
+
+def test_cdf_tables_match_reference_update():
+    """lssvc_amd.tables against the tables the REFERENCE's update(force=True) built for the same synthetic
+    weights (tests/golden/cdf_tables.json from tests/golden/make_tables_golden.py): every row, length, offset."""
+    import hashlib
+    from lssvc_amd import tables
+    from lssvc_amd.synth import synth_state_dict
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "cdf_tables.json")))
+    sd_i = synth_state_dict("intra_ss", g["seed"], g["gain"])
+    sd_p = synth_state_dict("lssvc_extend", g["seed"], g["gain"])
+    got = {"el.bit_estimator_z": tables.bit_estimator_tables(sd_p, "bit_estimator_z"),
+           "el.bit_estimator_z_mv": tables.bit_estimator_tables(sd_p, "bit_estimator_z_mv"),
+           "bl.bit_estimator_z": tables.bit_estimator_tables(sd_p, "base_layer_model.bit_estimator_z"),
+           "bl.bit_estimator_z_mv": tables.bit_estimator_tables(sd_p, "base_layer_model.bit_estimator_z_mv"),
+           "laplace": tables.laplace_tables(), "gaussian": tables.gaussian_tables(),
+           "intra.entropy_bottleneck": tables.bottleneck_tables(sd_i, "entropy_bottleneck")[0],
+           "intra.bl.entropy_bottleneck": tables.bottleneck_tables(sd_i, "base_layer_model.entropy_bottleneck")[0]}
+    for name, t in got.items():
+        want = g[name]
+        assert list(t.cdfs.shape) == want["shape"], name
+        assert [int(v) for v in t.sizes] == want["lengths"] and [int(v) for v in t.offsets] == want["offsets"], name
+        assert [int(v) for v in t.cdfs[0]] == want["row0"] and [int(v) for v in t.cdfs[-1]] == want["row_last"], name
+        assert hashlib.sha1(t.cdfs.tobytes()).hexdigest() == want["sha1"], name
+
+
+def test_stream_length_is_the_tables_ideal_code_length():
+    """rANS codes within a whisker of -sum log2(freq / 2^16) of the tables it is given (+ the 64-bit final state)."""
+    from lssvc_amd.entropy_coder import RansEncoder
+    rng = np.random.default_rng(5)
+    t = _tables(rng)
+    n = 200000
+    idx = rng.integers(0, t.cdfs.shape[0], n).astype(np.int32)
+    sym = np.empty(n, np.int32)
+    ideal = 0.0
+    for i in range(t.cdfs.shape[0]):                  # draw in-table symbols from each table's own distribution
+        sel = np.where(idx == i)[0]
+        freq = np.diff(t.cdfs[i, :t.sizes[i]]).astype(np.float64)[:-1]          # last slot = escape, never drawn here
+        v = rng.choice(freq.size, size=sel.size, p=freq / freq.sum())
+        sym[sel] = v + t.offsets[i]
+        ideal += -np.log2(freq[v] / 65536.0).sum()
+    enc = RansEncoder()
+    enc.encode_with_indexes(sym, idx, t)
+    bits = len(enc.flush()) * 8
+    assert ideal <= bits <= ideal * 1.0005 + 96, (bits, ideal)
