@@ -29,7 +29,7 @@ struct ConvP {
     int tiles_x, tiles_y, m_tiles;
     int in_vec[LSSVC_CONV_MAX_INPUTS];
     int n_chunks;    // total 8-channel chunks over all input segments
-    int debug;       // perf-experiment switches (LSSVC_CONV_DEBUG): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger
+    int debug;       // perf-ablation switches (env LSSVC_CONV_DEBUG; results are WRONG when set): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger, 16 skip LDS fragment reads
     int out_vec, res_vec, gdn_vec;
 };
 
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
         read_frags(0, fa[0], fb[0]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (t + 1 < NT) read_frags(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+            if (t + 1 < NT && !(p.debug & 16)) read_frags(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int f = 0; f < MF; ++f)

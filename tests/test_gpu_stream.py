@@ -88,3 +88,80 @@ def test_stream_needs_update(tmp_path):
     net.set_scale_information(2.0, (128, 128), (0, 0, 0, 0))
     with pytest.raises(ValueError):
         net.encode_decode(x_bl, x_el, str(tmp_path / "a.bin"), str(tmp_path / "b.bin"), 64, 64, 128, 128)
+
+
+class _Recorder:
+    """A SymbolSink that only records what would be coded."""
+
+    def __init__(self):
+        self.items = []
+
+    def push(self, symbols, indexes, tables):
+        self.items.append((symbols.copy(), indexes.copy()))
+
+    def flush(self):
+        return b""
+
+
+def _agree(a, b, what, tol=2e-3):
+    bad = (a != b).mean()
+    assert bad <= tol, "%s: %.4f%% of entries differ" % (what, 100 * bad)
+
+
+def test_symbol_and_index_planes_match_oracle():
+    """What the coder is fed (the pinnable part of the stream path): the int32 symbol and table-index
+    planes exported by the GPU equal those derived from the CPU oracle's latents and scales (up to the rare
+    rounding-boundary flip), in the reference's NCHW flattening and 4-step fold order."""
+    import numpy as np
+    from lssvc_amd.hip_ops import T
+    from lssvc_amd.synth import synth_state_dict
+    from lssvc_amd.inter import CHUNK_OF_MASK
+    from lssvc_oracle.intra import intra_forward
+    from lssvc_oracle.inter import inter_forward
+    from lssvc_oracle import entropy as E
+    H = W = 128
+    seed, gain = 6, 0.65
+    inet, pnet = _nets(seed, gain)
+    sd_i, sd_p = synth_state_dict("intra_ss", seed, gain), synth_state_dict("lssvc_extend", seed, gain)
+    x_bl, x_el = _clip(2, H, W, seed)
+    inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+    pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+    with torch.no_grad():
+        oi = intra_forward(sd_i, x_bl[0:1].cpu(), x_el[0:1].cpu(), (H, W), extras=True)
+    # I-frame EL: y symbols round(y - mu) with Gaussian-table indexes, z symbols round(z - median) per channel
+    rec = (_Recorder(), _Recorder())
+    x_hat_bl, y_hat_bl = inet._bl_codec(T.from_nchw(x_bl[0:1]))
+    inet._el_codec(T.from_nchw(x_el[0:1]), x_hat_bl, y_hat_bl, sinks=rec)
+    (ysym, yidx), (zsym, zidx) = rec[0].items[0], rec[1].items[0]
+    _agree(ysym, torch.round(oi["y"] - oi["means"]).int().reshape(-1).numpy(), "I-frame y symbols")
+    _agree(yidx, E.gaussian_indexes(oi["scales"]).reshape(-1).numpy(), "I-frame y indexes")
+    med = sd_i["entropy_bottleneck.quantiles"][:, 0, 1].view(1, -1, 1, 1)
+    _agree(zsym, torch.round(oi["z"] - med).int().reshape(-1).numpy(), "I-frame z symbols")
+    assert np.array_equal(zidx, np.repeat(np.arange(64, dtype=np.int32), zsym.size // 64))
+    # first P-frame, EL: mv_z, mv_y, z, then the four folded y planes
+    ri = inet.encode_decode(x_bl[0:1], x_el[0:1], None, None)
+    dpb = {"ref_frame_bl": ri["x_hat_bl"].clamp(0, 1), "ref_frame_el": ri["x_hat_el"].clamp(0, 1),
+           "ref_feature_bl": None, "ref_feature_el": ri["feature_el"]}
+    dpo = {"ref_frame_bl": oi["x_hat_bl"].clamp(0, 1), "ref_frame_el": oi["x_hat_el"].clamp(0, 1),
+           "ref_feature_bl": None, "ref_feature_el": oi["feature_el"]}
+    with torch.no_grad():
+        op = inter_forward(sd_p, x_bl[1:2].cpu(), x_el[1:2].cpu(), dpo, (H, W), 2.0, extras=True)
+    nh = lambda t: None if t is None else T.from_nchw(t)
+    bl = pnet._bl_codec(nh(x_bl[1:2]), nh(dpb["ref_frame_bl"]), None)
+    rec = _Recorder()
+    pnet._el_codec(nh(x_el[1:2]), bl, nh(dpb["ref_frame_el"]), nh(dpb["ref_feature_el"]), sink=rec)
+    assert len(rec.items) == 7
+    flat = lambda t: t.int().reshape(-1).numpy()
+    _agree(rec.items[0][0], flat(op["mv_z_hat"]), "mv_z symbols")
+    _agree(rec.items[1][0], flat(op["mv_y_q"]), "mv_y symbols")
+    _agree(rec.items[1][1], flat(E.laplace_indexes(op["mv_scales"])), "mv_y indexes")
+    _agree(rec.items[2][0], flat(op["z_hat"]), "z symbols")
+    yq, sh = op["y_q"], op["scales_hat"]
+    for step in range(4):                       # y_q_w_k / scales_w_k (LSSVC_net.py:432-442)
+        fold_q, fold_s = torch.zeros(1, 32, H // 16, W // 16), torch.zeros(1, 32, H // 16, W // 16)
+        for m, (r, c) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            ch = CHUNK_OF_MASK[step][m]
+            fold_q[:, :, r::2, c::2] = yq[:, ch * 32:(ch + 1) * 32, r::2, c::2]
+            fold_s[:, :, r::2, c::2] = sh[:, ch * 32:(ch + 1) * 32, r::2, c::2]
+        _agree(rec.items[3 + step][0], flat(fold_q), "y_w%d symbols" % step, tol=5e-3)
+        _agree(rec.items[3 + step][1], flat(E.laplace_indexes(fold_s)), "y_w%d indexes" % step, tol=5e-3)
