@@ -25,7 +25,11 @@ sys.path.insert(0, ROOT)
 GOP = 32
 HEIGHT, WIDTH, RATIO = 1080, 1920, 2.0
 GAIN = 0.55                       # synthetic-weight gain at which a 32-frame GOP stays numerically stable
+PEAK_FP16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = 64 FLOP/clk/SIMD
+
+
+DTYPE = {"f32": "f32", "f16x3": "f16x3 (3x3/7x7 convs: fp16 MFMA on hi/lo-split operands, fp32 accumulate; everything else f32)"}
 
 
 def log(*a):
@@ -70,8 +74,11 @@ def roofline_from_log(op_log):
     groups = {}
     for e in op_log:
         ms = e["events"][0].elapsed_time(e["events"][1])
-        name = "conv_mfma_kernel<%d, %d, %d, %d, %s>" % (e["variant"] // 16, e["variant"] % 16, e["ks"], e["stride"],
-                                                         "true" if e["vec"] else "false")
+        if e.get("f16x3"):
+            name = "conv_f16x3_kernel<%d, %d, %d, %d>" % (e["variant"] // 16, e["variant"] % 16, e["ks"], e["stride"])
+        else:
+            name = "conv_mfma_kernel<%d, %d, %d, %d, %s>" % (e["variant"] // 16, e["variant"] % 16, e["ks"], e["stride"],
+                                                             "true" if e["vec"] else "false")
         g = groups.setdefault(name, {"ms": 0.0, "macs": 0, "launches": 0})
         g["ms"] += ms
         g["macs"] += e["macs"]
@@ -97,8 +104,11 @@ def roofline_from_log(op_log):
                 f.write("%-10s cin %4d cout %4d @%4dx%-4d <%d,%d> n=%4d  %8.2f ms (%4.1f%%)  %6.1f TF\n" % (
                     k[0], k[1], k[2], k[3], k[4], k[5] // 16, k[5] % 16, g[2], g[0], 100 * g[0] / tot, 2e-9 * g[1] / g[0]))
     dom = table[0]
-    roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
+    # peak in ALGORITHMIC TFLOP/s: the fp32 kernel runs 1 MFMA flop per algorithmic flop on the fp32 matrix pipe;
+    # the f16x3 kernel runs 3 fp16-MFMA flops per algorithmic flop (hi*hi + hi*lo + lo*hi) on the 2.5 PFLOP/s fp16 pipe
+    peak = PEAK_FP16_MFMA_TFLOPS / 3.0 if dom["kernel"].startswith("conv_f16x3") else PEAK_FP32_MFMA_TFLOPS
+    roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": pmc_traffic(dom["kernel"]),
             "launches": dom["launches"], "avg_launch_us": dom["avg_us"], "gflop_per_launch": dom["gflop_per_launch"],
             "conv_time_ms_per_gop": round(sum(r["total_ms"] for r in table), 2),
             "conv_tflop_per_gop": round(sum(r["gflop_per_launch"] * r["launches"] for r in table) * 1e-3, 3)}
@@ -163,6 +173,8 @@ def main():
     ap.add_argument("--frames", type=int, default=GOP, help="frames per GOP (default 32 = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events in the last timed step")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
+                    help="conv arithmetic (default: lssvc_amd's default, see hip_ops.CONV_PRECISION)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +189,8 @@ def main():
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (got world=%d, --gpus=%d)" % (world, args.gpus)
 
     from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
+    if args.precision:
+        hip_ops.set_conv_precision(args.precision)
     from lssvc_amd.synth import synth_state_dict
     inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, GAIN)).to(device).eval()
     pnet = LSSVC_extend()
@@ -225,7 +239,7 @@ def main():
             "metric": "encoded frames/sec, LSSVC two-layer x2 (BL 540p + EL 1080p), GOP 32 (1 I + 31 P), estimate mode",
             "value": round(frames / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE[hip_ops.CONV_PRECISION], "data": "synthetic",
             "config": {"workload": "configs[1]: LSSVC two-layer x2, EL 1152x1920 (1080p padded) / BL 576x960, "
                                    "%d-frame GOP per GPU per step, write_stream=0" % args.frames,
                        "frames_per_step_per_gpu": args.frames, "weights": "seeded synthetic (lssvc_amd.synth, gain %.2f)" % GAIN,

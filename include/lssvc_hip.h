@@ -40,6 +40,11 @@ enum { LSSVC_INACT_NONE = 0, LSSVC_INACT_LRELU = 1, LSSVC_INACT_SQUARE = 2 };
  *   X_DIV_SQRT  : x / sqrt(v)       InterModules GDN forward      (video_net_component.py:102-103) */
 enum { LSSVC_EPI_NONE = 0, LSSVC_EPI_X_MUL_RSQRT = 1, LSSVC_EPI_X_MUL_SQRT = 2, LSSVC_EPI_X_DIV_SQRT = 3 };
 
+/* Conv arithmetic. F16X3: operands split x = hi + lo in fp16, hi*hi + hi*lo + lo*hi accumulated in fp32 on
+ * v_mfma_f32_16x16x32_f16 -- fp32-class accuracy (holds the 1e-5 bpp / 1e-4 dB bars; plain fp16 does not) at
+ * 3/8 of the fp32-MFMA pipe cycles x 16x the rate. Used for 3x3 / 7x7 stride-1 layers; others stay F32. */
+enum { LSSVC_PREC_F32 = 0, LSSVC_PREC_F16X3 = 1 };
+
 #define LSSVC_CONV_MAX_INPUTS 3
 #define LSSVC_CONV_CK 8 /* input channels per K-chunk; each input segment is zero-padded to a multiple */
 
@@ -75,6 +80,8 @@ typedef struct lssvc_conv_desc {
     float out_scale;     /* multiplied last; 1.0f = none */
     int32_t pixel_shuffle; /* 0 or 1 (r = 2) */
     lssvc_view out;      /* H_out x W_out x Cout, or 2H_out x 2W_out x Cout/4 with pixel_shuffle */
+    int32_t precision;   /* LSSVC_PREC_F32 (exact fp32 MFMA, the parity reference path) or LSSVC_PREC_F16X3 */
+    const void *weight16; /* F16X3 only: fp16 weights [hi|lo][chunk16][ky][kx][m][16] (lssvc_amd/weights.py) */
 } lssvc_conv_desc;
 
 int lssvc_conv2d(const lssvc_conv_desc *d, void *stream);

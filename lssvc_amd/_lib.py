@@ -14,6 +14,7 @@ CONV_CK = 8
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 INACT_NONE, INACT_LRELU, INACT_SQUARE = 0, 1, 2
+PREC_F32, PREC_F16X3 = 0, 1
 EPI_NONE, EPI_X_MUL_RSQRT, EPI_X_MUL_SQRT, EPI_X_DIV_SQRT = 0, 1, 2, 3
 
 
@@ -32,6 +33,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("slope", C.c_float),
         ("residual", View), ("out_scale", C.c_float),
         ("pixel_shuffle", C.c_int32), ("out", View),
+        ("precision", C.c_int32), ("weight16", C.c_void_p),
     ]
 
 

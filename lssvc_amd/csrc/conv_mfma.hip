@@ -19,7 +19,7 @@
 // fp32 MFMA is exact fp32 (fmaf chain), so this is the parity path against the fp32 CPU oracle.
 #include <cstdlib>
 
-#include "conv_mfma_kernel.h"
+#include "conv_f16x3_kernel.h"
 
 namespace lssvc {
 
@@ -122,6 +122,18 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     const int ks = d->KH, sd = d->stride;
     bool vec = true;
     for (int i = 0; i < p.n_in; ++i) vec = vec && p.in_vec[i];
+    if (d->precision == LSSVC_PREC_F16X3) {
+        // fp16-MFMA 3-term split: built for the MFMA-bound layers (3x3 / 7x7, stride 1, 16-byte addressable inputs);
+        // everything else (1x1, strided, 2..3-channel inputs, GDN) stays on the exact-fp32 kernel
+        LSSVC_CHECK(d->weight16 != nullptr, "conv2d: precision f16x3 needs weight16");
+        if (vec && sd == 1 && (ks == 3 || ks == 7)) {
+            p.w16 = d->weight16;
+            long long chunks16 = 0;
+            for (int i = 0; i < d->n_in; ++i) chunks16 += (d->in[i].C + 15) / 16;
+            p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
+            return ks == 3 ? dispatch_tile_f16x3<3, 1>(p, MF, RPW, st) : dispatch_tile_f16x3<7, 1>(p, MF, RPW, st);
+        }
+    }
 #define LSSVC_CONV_KS(K, SD) \
     if (ks == K && sd == SD) return vec ? dispatch_tile<K, SD, true>(p, MF, RPW, st) : dispatch_tile<K, SD, false>(p, MF, RPW, st);
     LSSVC_CONV_KS(1, 1) LSSVC_CONV_KS(1, 2) LSSVC_CONV_KS(2, 1) LSSVC_CONV_KS(3, 1) LSSVC_CONV_KS(3, 2) LSSVC_CONV_KS(7, 1)

@@ -29,11 +29,102 @@ struct ConvP {
     int tiles_x, tiles_y, m_tiles;
     int in_vec[LSSVC_CONV_MAX_INPUTS];
     int n_chunks;    // total 8-channel chunks over all input segments
+    const void *w16; // f16x3 mode: fp16 weights [plane hi|lo][chunk16][ky][kx][m][16]
+    long long w16_plane;   // elements per plane
     int debug;       // perf-ablation switches (env LSSVC_CONV_DEBUG; results are WRONG when set): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger, 16 skip LDS fragment reads
     int out_vec, res_vec, gdn_vec;
 };
 
 constexpr int CP = 12;  // LDS row pitch in floats (CK=8 + 4 pad)
+
+// ---- fused epilogue shared by the conv kernels: bias -> GDN -> activation -> residual -> scale ->
+//      (pixel-shuffle) store. Lane (li, lg) of wave `wave` holds, for fragment (f, r), channels
+//      m0 + 16f + 4lg .. +3 of pixel (oy0 + wave*RPW + r, ox0 + li). ------------------------------------
+template <int MF, int RPW>
+__device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x4 (&acc)[MF][RPW], int oy0, int ox0, int m0, int wave,
+                                              int li, int lg) {
+    const int ox = ox0 + li;
+    const int cps = p.Cout >> 2;  // channels after pixel shuffle
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int oy = oy0 + wave * RPW + r;
+        if (oy >= p.Hout || ox >= p.Wout) continue;
+        const size_t opix = (size_t)oy * p.Wout + ox;
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int mb = m0 + f * 16 + 4 * lg;
+            if (mb >= p.Cout) continue;
+            float v[4] = {acc[f][r][0], acc[f][r][1], acc[f][r][2], acc[f][r][3]};
+            const bool full = (mb + 3 < p.Cout);
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4 *>(p.bias + mb);  // bias is M_pad long
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (p.epilogue != LSSVC_EPI_NONE) {
+                float x[4] = {0.f, 0.f, 0.f, 0.f};
+                const float *xs = p.gdn_x.p + opix * p.gdn_x.ld + mb;
+                if (full && p.gdn_vec) {
+                    const float4 t = *reinterpret_cast<const float4 *>(xs);
+                    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (mb + j < p.Cout) x[j] = xs[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sq = sqrtf(v[j]);
+                    if (p.epilogue == LSSVC_EPI_X_MUL_RSQRT) v[j] = x[j] * (1.0f / sq);
+                    else if (p.epilogue == LSSVC_EPI_X_MUL_SQRT) v[j] = x[j] * sq;
+                    else v[j] = x[j] / sq;
+                }
+            }
+            if (p.act == LSSVC_ACT_LRELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+            } else if (p.act == LSSVC_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            }
+            if (p.res.p) {
+                const float *rs = p.res.p + opix * p.res.ld + mb;
+                if (full && p.res_vec) {
+                    const float4 t = *reinterpret_cast<const float4 *>(rs);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (mb + j < p.Cout) v[j] += rs[j];
+                }
+            }
+            if (p.out_scale != 1.0f) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
+            }
+            if (!p.pixel_shuffle) {
+                float *dst = p.out.p + opix * p.out.ld + mb;
+                if (full && p.out_vec) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (mb + j < p.Cout) dst[j] = v[j];
+                }
+            } else {
+                // m = q*cps + c, q = dy*2+dx  (weights were permuted on the host)
+                if (full && p.out_vec && (cps & 3) == 0) {
+                    const int q = mb / cps, c = mb - q * cps;
+                    float *dst = p.out.p + ((size_t)(2 * oy + (q >> 1)) * p.out.W + 2 * ox + (q & 1)) * p.out.ld + c;
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = mb + j;
+                        if (m >= p.Cout) break;
+                        const int q = m / cps, c = m - q * cps;
+                        p.out.p[((size_t)(2 * oy + (q >> 1)) * p.out.W + 2 * ox + (q & 1)) * p.out.ld + c] = v[j];
+                    }
+                }
+            }
+        }
+    }
+}
 
 // One K "phase" = one 8-channel chunk x RPP kernel rows. Small kernels (<=3x3) take all rows in one
 // phase (the whole KSxKS filter slab of the chunk sits in LDS); 7x7 takes one kernel row per phase.
@@ -281,88 +372,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvP p) {
         cur = nxt;
     }
 
-    // ---- fused epilogue: bias -> GDN -> activation -> residual -> scale -> (pixel-shuffle) store ----
-    const int ox = ox0 + li;
-    const int cps = p.Cout >> 2;  // channels after pixel shuffle
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int oy = oy0 + wave * RPW + r;
-        if (oy >= p.Hout || ox >= p.Wout) continue;
-        const size_t opix = (size_t)oy * p.Wout + ox;
-#pragma unroll
-        for (int f = 0; f < MF; ++f) {
-            const int mb = m0 + f * 16 + 4 * lg;
-            if (mb >= p.Cout) continue;
-            float v[4] = {acc[f][r][0], acc[f][r][1], acc[f][r][2], acc[f][r][3]};
-            const bool full = (mb + 3 < p.Cout);
-            if (p.bias) {
-                const float4 bb = *reinterpret_cast<const float4 *>(p.bias + mb);  // bias is M_pad long
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
-            if (p.epilogue != LSSVC_EPI_NONE) {
-                float x[4] = {0.f, 0.f, 0.f, 0.f};
-                const float *xs = p.gdn_x.p + opix * p.gdn_x.ld + mb;
-                if (full && p.gdn_vec) {
-                    const float4 t = *reinterpret_cast<const float4 *>(xs);
-                    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
-                } else {
-                    for (int j = 0; j < 4; ++j)
-                        if (mb + j < p.Cout) x[j] = xs[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float sq = sqrtf(v[j]);
-                    if (p.epilogue == LSSVC_EPI_X_MUL_RSQRT) v[j] = x[j] * (1.0f / sq);
-                    else if (p.epilogue == LSSVC_EPI_X_MUL_SQRT) v[j] = x[j] * sq;
-                    else v[j] = x[j] / sq;
-                }
-            }
-            if (p.act == LSSVC_ACT_LRELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
-            } else if (p.act == LSSVC_ACT_RELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-            }
-            if (p.res.p) {
-                const float *rs = p.res.p + opix * p.res.ld + mb;
-                if (full && p.res_vec) {
-                    const float4 t = *reinterpret_cast<const float4 *>(rs);
-                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                } else {
-                    for (int j = 0; j < 4; ++j)
-                        if (mb + j < p.Cout) v[j] += rs[j];
-                }
-            }
-            if (p.out_scale != 1.0f) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
-            }
-            if (!p.pixel_shuffle) {
-                float *dst = p.out.p + opix * p.out.ld + mb;
-                if (full && p.out_vec) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int j = 0; j < 4; ++j)
-                        if (mb + j < p.Cout) dst[j] = v[j];
-                }
-            } else {
-                // m = q*cps + c, q = dy*2+dx  (weights were permuted on the host)
-                if (full && p.out_vec && (cps & 3) == 0) {
-                    const int q = mb / cps, c = mb - q * cps;
-                    float *dst = p.out.p + ((size_t)(2 * oy + (q >> 1)) * p.out.W + 2 * ox + (q & 1)) * p.out.ld + c;
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = mb + j;
-                        if (m >= p.Cout) break;
-                        const int q = m / cps, c = m - q * cps;
-                        p.out.p[((size_t)(2 * oy + (q >> 1)) * p.out.W + 2 * ox + (q & 1)) * p.out.ld + c] = v[j];
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<MF, RPW>(p, acc, oy0, ox0, m0, wave, li, lg);
 }
 
 template <int MF, int RPW, int KS, int S, bool VEC>

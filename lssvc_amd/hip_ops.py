@@ -13,6 +13,20 @@ from ._lib import lib, check, View, ConvDesc
 
 _NULL_VIEW = View(None, 0, 0, 0, 0)
 
+# Conv arithmetic for the MFMA-bound layers (3x3 / 7x7, stride 1): "f16x3" (default: fp16 MFMA on hi/lo-split
+# operands, fp32 accumulate -- fp32-class accuracy, holds the parity bars, ~2-3x faster) or "f32" (exact fp32
+# MFMA everywhere). Set with set_conv_precision() or env LSSVC_CONV_PRECISION.
+import os as _os
+CONV_PRECISION = _os.environ.get("LSSVC_CONV_PRECISION", "f16x3")
+
+
+def set_conv_precision(mode):
+    global CONV_PRECISION
+    if mode not in ("f32", "f16x3"):
+        raise ValueError("conv precision must be 'f32' or 'f16x3'")
+    CONV_PRECISION = mode
+
+
 # optional op log: list of (kind, name, macs) appended by conv() when enabled (bench / profiling)
 OP_LOG = None
 
@@ -90,7 +104,7 @@ _INACT = {None: _lib.INACT_NONE, "lrelu": _lib.INACT_LRELU, "square": _lib.INACT
 
 
 def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=None, in_slope=0.01, epilogue=0,
-                 gdn_x=None, act=None, slope=0.01, residual=None, out_scale=1.0, pixel_shuffle=False, name=""):
+                 gdn_x=None, act=None, slope=0.01, residual=None, out_scale=1.0, pixel_shuffle=False, name="", w16=None):
     w_dev, b_dev, cout, m_pad = prepared
     d = ConvDesc()
     for i, t in enumerate(inputs):
@@ -108,6 +122,8 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
     d.out_scale = out_scale
     d.pixel_shuffle = 1 if pixel_shuffle else 0
     d.out = out.v
+    if w16 is not None:
+        d.precision, d.weight16 = _lib.PREC_F16X3, w16.data_ptr()
     if OP_LOG is None:
         check(lib.lssvc_conv2d(C.byref(d), stream_ptr()))
         return out
@@ -123,6 +139,7 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
                    "hout": hout, "wout": wout, "cin": cin, "cout": cout,
                    "variant": lib.lssvc_conv2d_variant(hout, wout, m_pad, stride), "ks": KH, "stride": stride,
                    "vec": all(t.C % 4 == 0 and t.ld % 4 == 0 and t.v.ptr % 16 == 0 for t in inputs),
+                   "f16x3": w16 is not None,
                    "events": (e0, e1)})
     return out
 
@@ -140,9 +157,12 @@ def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slo
     wout = (x.W + 2 * pad - KW) // stride + 1
     if out is None:
         out = T.empty(hout * 2, wout * 2, cout // 4, x.device) if pixel_shuffle else T.empty(hout, wout, cout, x.device)
+    w16 = None
+    if CONV_PRECISION == "f16x3" and stride == 1 and KH in (3, 7) and all(t.C % 4 == 0 and t.ld % 4 == 0 for t in inputs):
+        w16 = W.conv_f16x3(name, [t.C for t in inputs], pixel_shuffle)
     return _conv_launch(inputs, (w_dev, b_dev, cout, m_pad), KH, KW, stride, pad, pad, out, in_act=in_act,
                         in_slope=in_slope, act=act, slope=slope, residual=residual, out_scale=out_scale,
-                        pixel_shuffle=pixel_shuffle, name=name)
+                        pixel_shuffle=pixel_shuffle, name=name, w16=w16)
 
 
 def subpel(W, name, inputs, **kw):

@@ -73,6 +73,25 @@ def layout_conv(w, bias, splits, pixel_shuffle):
     return wp, bp, cout, m_pad
 
 
+def layout_conv_f16x3(w, splits, pixel_shuffle):
+    """fp16 hi/lo planes for the f16x3 conv mode: (2, chunk16, KH, KW, M_pad, 16) fp16, hi = fp16(w),
+    lo = fp16(w - hi); same concat-segment / pixel-shuffle / M padding rules as layout_conv, 16-channel chunks."""
+    cout, cin, kh, kw = w.shape
+    if pixel_shuffle:
+        cps = cout // 4
+        w = w.reshape(cps, 4, cin, kh, kw).permute(1, 0, 2, 3, 4).reshape(cout, cin, kh, kw)
+    m_pad = _pad_to(cout, 16)
+    segs, a = [], 0
+    for c in splits:
+        segs.append(F.pad(w[:, a:a + c], (0, 0, 0, 0, 0, _pad_to(c, 16) - c)))
+        a += c
+    wp = F.pad(torch.cat(segs, dim=1), (0, 0, 0, 0, 0, 0, 0, m_pad - cout))
+    wp = wp.reshape(m_pad, wp.shape[1] // 16, 16, kh, kw).permute(1, 3, 4, 0, 2).contiguous()
+    hi = wp.half()
+    lo = (wp - hi.float()).half()
+    return torch.stack([hi, lo], 0).contiguous()
+
+
 def conv_t_as_conv(w, bias, stride):
     """ConvTranspose2d(k=3, padding=1[, stride=2, output_padding=1]) weight (Cin, Cout, 3, 3) ->
     (equivalent conv weight OIHW, bias, KH, pad, pixel_shuffle)."""
@@ -124,6 +143,12 @@ class WeightStore:
             b = self.sd.get(name + ".bias")
             wp, bp, cout, m_pad = layout_conv(w, b, splits, pixel_shuffle)
             self._cache[key] = (self._dev(wp), self._dev(bp), cout, m_pad, w.shape[2], w.shape[3])
+        return self._cache[key]
+
+    def conv_f16x3(self, name, splits, pixel_shuffle=False):
+        key = ("conv16", name, tuple(splits), pixel_shuffle)
+        if key not in self._cache:
+            self._cache[key] = self._dev(layout_conv_f16x3(self.sd[name + ".weight"], splits, pixel_shuffle))
         return self._cache[key]
 
     def conv_t(self, name, stride):

@@ -21,8 +21,18 @@ def _nets(m):
     return inet, pnet
 
 
+@pytest.fixture(params=["f16x3", "f32"])
+def precision(request):
+    """Every frame-level bar is held in both conv arithmetic modes."""
+    from lssvc_amd import hip_ops
+    old = hip_ops.CONV_PRECISION
+    hip_ops.set_conv_precision(request.param)
+    yield request.param
+    hip_ops.set_conv_precision(old)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_frames_match_reference(case):
+def test_frames_match_reference(case, precision):
     z, m = load_case(case)
     inet, pnet = _nets(m)
 
@@ -66,7 +76,7 @@ def test_rejects_cpu_device():
         net.to("cpu")
 
 
-def test_gop_drift_vs_oracle():
+def test_gop_drift_vs_oracle(precision):
     """Errors feed forward through the DPB: code an 8-frame GOP (1 I + 7 P) and hold every frame to the
     per-frame bars against the CPU oracle run on the same inputs (closed loop on both sides)."""
     from lssvc_amd import IntraSS, LSSVC_extend

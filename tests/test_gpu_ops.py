@@ -278,3 +278,48 @@ def test_four_part_step_schedule(hip):
             q = torch.round(y[sl] - mu[sl])
             want_q[sl], want_h[sl], want_s[sl] = q, q + mu[sl], sg[sl]
     assert torch.equal(back(yq), want_q) and torch.equal(back(yh), want_h) and torch.equal(back(sh), want_s)
+
+
+# ----------------------------------------------------------------------------------------- f16x3 precision mode
+F16X3_CASES = [([64], 64, 3, 40, 56), ([48], 48, 3, 33, 47), ([64, 64], 48, 3, 20, 36), ([32], 64, 7, 18, 30),
+               ([16], 2, 7, 16, 32), ([192], 192, 3, 9, 15), ([96], 256, 3, 12, 20), ([8], 32, 7, 24, 24)]
+
+
+@pytest.mark.parametrize("cins,cout,k,H,W", F16X3_CASES)
+def test_conv_f16x3_matches_fp64(hip, cins, cout, k, H, W):
+    """The fp16-MFMA 3-term split (hi*hi + hi*lo + lo*hi) is fp32-class: against an fp64 reference its error is
+    within a small factor of the exact-fp32 kernel's own error, and ~1000x below plain fp16's."""
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, k)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    w = torch.randn(cout, sum(cins), k, k, generator=g) / math.sqrt(sum(cins) * k * k)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double(), padding=k // 2)
+    Wt = FakeW({"c.weight": w, "c.bias": b})
+    try:
+        hip.set_conv_precision("f16x3")
+        got16 = back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs]))
+    finally:
+        hip.set_conv_precision("f32")
+    got32 = back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs]))
+    e16 = (got16.double() - ref).abs().max().item()
+    e32 = (got32.double() - ref).abs().max().item()
+    half = F.conv2d(torch.cat(xs, 1).half().float(), w.half().float(), b, padding=k // 2)
+    e_half = (half.double() - ref).abs().max().item()
+    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
+    assert e16 <= e_half / 100, (e16, e_half)
+
+
+def test_conv_f16x3_fused_paths(hip):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 64, 24, 40, generator=g)
+    r = torch.randn(1, 64, 48, 80, generator=g)
+    w = torch.randn(256, 64, 3, 3, generator=g) / 24
+    b = torch.randn(256, generator=g)
+    Wt = FakeW({"s.0.weight": w, "s.0.bias": b})
+    want = F.leaky_relu(F.pixel_shuffle(F.conv2d(F.leaky_relu(x, 0.1), w, b, padding=1), 2), 0.01)
+    try:
+        hip.set_conv_precision("f16x3")
+        got = back(hip.subpel(Wt, "s", nhwc(hip, x), in_act="lrelu", in_slope=0.1, act="lrelu"))
+    finally:
+        hip.set_conv_precision("f32")
+    close(got, want, rtol=1e-5, atol=1e-5)
