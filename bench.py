@@ -26,6 +26,7 @@ GOP = 32
 HEIGHT, WIDTH, RATIO = 1080, 1920, 2.0
 GAIN = 0.55                       # synthetic-weight gain at which a 32-frame GOP stays numerically stable
 PEAK_FP16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured achievable)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = 64 FLOP/clk/SIMD
 
 
@@ -70,30 +71,31 @@ def encode_gop(inet, pnet, x_bls, x_els, shape_hr):
 
 
 def roofline_from_log(op_log):
-    """Group the conv launches of one GOP by kernel instantiation; dominant = largest total time."""
+    """Group the conv launches of one GOP by the kernel instantiation that ran (name reported by the library);
+    dominant = largest total time. MFMA-bound kernels (3x3 / 7x7 ...) are priced in algorithmic TFLOP/s, the
+    1x1 kernels -- no spatial reuse, a few dozen FLOP per byte -- against HBM bandwidth with their algorithmic
+    bytes (input + output + residual read, fp32)."""
     groups = {}
     for e in op_log:
         ms = e["events"][0].elapsed_time(e["events"][1])
-        if e.get("f16x3"):
-            name = "conv_f16x3_kernel<%d, %d, %d, %d>" % (e["variant"] // 16, e["variant"] % 16, e["ks"], e["stride"])
-        else:
-            name = "conv_mfma_kernel<%d, %d, %d, %d, %s>" % (e["variant"] // 16, e["variant"] % 16, e["ks"], e["stride"],
-                                                             "true" if e["vec"] else "false")
-        g = groups.setdefault(name, {"ms": 0.0, "macs": 0, "launches": 0})
+        g = groups.setdefault(e["kernel"], {"ms": 0.0, "macs": 0, "bytes": 0, "launches": 0, "ks": e["ks"]})
         g["ms"] += ms
         g["macs"] += e["macs"]
+        g["bytes"] += e["bytes"]
         g["launches"] += 1
     table = []
     for v, g in groups.items():
-        table.append({"kernel": v, "launches": g["launches"],
+        table.append({"kernel": v, "launches": g["launches"], "ks": g["ks"],
                       "total_ms": round(g["ms"], 3), "avg_us": round(1e3 * g["ms"] / g["launches"], 2),
                       "gflop_per_launch": round(2e-9 * g["macs"] / g["launches"], 3),
-                      "tflops": round(2e-9 * g["macs"] / g["ms"], 2) if g["ms"] > 0 else 0.0})
+                      "mbytes_per_launch": round(1e-6 * g["bytes"] / g["launches"], 2),
+                      "tflops": round(2e-9 * g["macs"] / g["ms"], 2) if g["ms"] > 0 else 0.0,
+                      "gbps": round(1e-6 * g["bytes"] / g["ms"], 1) if g["ms"] > 0 else 0.0})
     table.sort(key=lambda r: -r["total_ms"])
     if os.environ.get("LSSVC_BENCH_SIGNATURES"):      # per-signature breakdown for kernel work (not part of the JSON line)
         sig = {}
         for e in op_log:
-            k = (e["kind"], e["cin"], e["cout"], e["hout"], e["wout"], e["variant"])
+            k = (e["kind"], e["cin"], e["cout"], e["hout"], e["wout"], e["kernel"])
             g = sig.setdefault(k, [0.0, 0, 0])
             g[0] += e["events"][0].elapsed_time(e["events"][1])
             g[1] += e["macs"]
@@ -101,17 +103,26 @@ def roofline_from_log(op_log):
         with open(os.environ["LSSVC_BENCH_SIGNATURES"], "w") as f:
             tot = sum(g[0] for g in sig.values())
             for k, g in sorted(sig.items(), key=lambda kv: -kv[1][0]):
-                f.write("%-10s cin %4d cout %4d @%4dx%-4d <%d,%d> n=%4d  %8.2f ms (%4.1f%%)  %6.1f TF\n" % (
-                    k[0], k[1], k[2], k[3], k[4], k[5] // 16, k[5] % 16, g[2], g[0], 100 * g[0] / tot, 2e-9 * g[1] / g[0]))
+                f.write("%-10s cin %4d cout %4d @%4dx%-4d %-40s n=%4d  %8.2f ms (%4.1f%%)  %6.1f TF\n" % (
+                    k[0], k[1], k[2], k[3], k[4], k[5], g[2], g[0], 100 * g[0] / tot, 2e-9 * g[1] / g[0]))
     dom = table[0]
-    # peak in ALGORITHMIC TFLOP/s: the fp32 kernel runs 1 MFMA flop per algorithmic flop on the fp32 matrix pipe;
-    # the f16x3 kernel runs 3 fp16-MFMA flops per algorithmic flop (hi*hi + hi*lo + lo*hi) on the 2.5 PFLOP/s fp16 pipe
-    peak = PEAK_FP16_MFMA_TFLOPS / 3.0 if dom["kernel"].startswith("conv_f16x3") else PEAK_FP32_MFMA_TFLOPS
-    roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4), "traffic": pmc_traffic(dom["kernel"]),
-            "launches": dom["launches"], "avg_launch_us": dom["avg_us"], "gflop_per_launch": dom["gflop_per_launch"],
-            "conv_time_ms_per_gop": round(sum(r["total_ms"] for r in table), 2),
-            "conv_tflop_per_gop": round(sum(r["gflop_per_launch"] * r["launches"] for r in table) * 1e-3, 3)}
+    common = {"kernel": dom["kernel"], "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
+              "gflop_per_launch": dom["gflop_per_launch"], "mbytes_per_launch": dom["mbytes_per_launch"],
+              "traffic": pmc_traffic(dom["kernel"]),
+              "conv_time_ms_per_gop": round(sum(r["total_ms"] for r in table), 2),
+              "conv_tflop_per_gop": round(sum(r["gflop_per_launch"] * r["launches"] for r in table) * 1e-3, 3)}
+    if dom["ks"] == 1:
+        roof = {"bound": "hbm", "achieved": dom["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": round(dom["gbps"] / PEAK_HBM_GBPS, 4)}
+    else:
+        # peak in ALGORITHMIC TFLOP/s: the fp32 kernel runs 1 MFMA flop per algorithmic flop on the fp32 matrix pipe;
+        # the f16x3 kernels run 3 fp16-MFMA flops per algorithmic flop (hi*hi + hi*lo + lo*hi) on the 2.5 PFLOP/s fp16 pipe
+        peak = PEAK_FP16_MFMA_TFLOPS / 3.0 if "f16x3" in dom["kernel"] else PEAK_FP32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(dom["tflops"] / peak, 4)}
+    roof.update(common)
+    for r in table:
+        r.pop("ks")
     return roof, table
 
 

@@ -90,6 +90,8 @@ int lssvc_conv2d(const lssvc_conv_desc *d, void *stream);
  * `stride`: returns MF*16 + RPW (kernel name conv_mfma_kernel<MF,RPW>; tile = 4*RPW rows x 16 cols x
  * 16*MF channels). Lets profilers attribute launches to kernels; no GPU work. */
 int lssvc_conv2d_variant(int32_t Hout, int32_t Wout, int32_t M_pad, int32_t stride);
+/* Name (as rocprofv3 prints it, without the lssvc:: prefix) of the kernel the calling thread's last lssvc_conv2d launched. */
+const char *lssvc_conv2d_last_kernel(void);
 
 /* Depthwise 3x3, stride 1, pad 1 (lssvc_modules.py:23-24). weight: [9][C], bias: [C]. */
 int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const float *bias, const lssvc_view *out,

@@ -49,6 +49,7 @@ TP = C.POINTER(CdfTable)
 SIGNATURES = {
     "lssvc_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "lssvc_conv2d_variant": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "lssvc_conv2d_last_kernel": (C.c_char_p, []),
     "lssvc_dwconv3x3": (C.c_int, [VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
     "lssvc_resize_bilinear": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
     "lssvc_flow_warp": (C.c_int, [VP, VP, VP, C.c_void_p]),

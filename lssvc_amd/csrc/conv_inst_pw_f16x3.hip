@@ -1,0 +1,27 @@
+// instantiations + tile choice of the streaming 1x1 conv kernel (f16x3 mode)
+#include <cstdlib>
+
+#include "conv_pw_f16x3_kernel.h"
+namespace lssvc {
+int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name) {
+    static const int rpw = getenv("LSSVC_PW_RPW") ? atoi(getenv("LSSVC_PW_RPW")) : 2;
+    const int frags = p.M_pad / 16;
+    const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
+    int mf_fit = kPwMaxLds / (nslot * 1024);          // each 16-channel M fragment costs nslot KiB of LDS (hi + lo planes)
+    if (mf_fit < 1) return fail("conv2d(pw f16x3): Cin too large for the LDS-resident weight tile");
+    int MF = frags < 4 ? frags : 4;
+    if (frags % 4 != 0 && frags % 3 == 0) MF = 3;
+    if (MF > mf_fit) MF = mf_fit;
+    snprintf(kernel_name, 96, "conv_pw_f16x3_kernel<%d, %d>", MF, rpw);
+    if (rpw == 1) {
+        if (MF == 4) return launch_pw_f16x3<4, 1>(p, st);
+        if (MF == 3) return launch_pw_f16x3<3, 1>(p, st);
+        if (MF == 2) return launch_pw_f16x3<2, 1>(p, st);
+        return launch_pw_f16x3<1, 1>(p, st);
+    }
+    if (MF == 4) return launch_pw_f16x3<4, 2>(p, st);
+    if (MF == 3) return launch_pw_f16x3<3, 2>(p, st);
+    if (MF == 2) return launch_pw_f16x3<2, 2>(p, st);
+    return launch_pw_f16x3<1, 2>(p, st);
+}
+}  // namespace lssvc

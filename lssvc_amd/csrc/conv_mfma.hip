@@ -19,9 +19,14 @@
 // fp32 MFMA is exact fp32 (fmaf chain), so this is the parity path against the fp32 CPU oracle.
 #include <cstdlib>
 
-#include "conv_f16x3_kernel.h"
+#include "conv_pw_f16x3_kernel.h"
 
 namespace lssvc {
+
+static char *last_kernel_name() {
+    static thread_local char name[96] = {0};
+    return name;
+}
 
 static long long grid_blocks(const ConvP &p, int MF, int RPW) {
     const int TH = 4 * RPW;
@@ -42,6 +47,8 @@ static void pick_variant(const ConvP &p, int &MF, int &RPW) {
 }  // namespace lssvc
 
 using namespace lssvc;
+
+extern "C" const char *lssvc_conv2d_last_kernel(void) { return last_kernel_name(); }
 
 extern "C" int lssvc_conv2d_variant(int32_t Hout, int32_t Wout, int32_t M_pad, int32_t stride) {
     ConvP p;
@@ -120,20 +127,27 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     pick_variant(p, MF, RPW);
 
     const int ks = d->KH, sd = d->stride;
+    char *kname = last_kernel_name();
     bool vec = true;
     for (int i = 0; i < p.n_in; ++i) vec = vec && p.in_vec[i];
     if (d->precision == LSSVC_PREC_F16X3) {
         // fp16-MFMA 3-term split: built for the MFMA-bound layers (3x3 / 7x7, stride 1, 16-byte addressable inputs);
         // everything else (1x1, strided, 2..3-channel inputs, GDN) stays on the exact-fp32 kernel
         LSSVC_CHECK(d->weight16 != nullptr, "conv2d: precision f16x3 needs weight16");
+        long long chunks16 = 0;
+        for (int i = 0; i < d->n_in; ++i) chunks16 += (d->in[i].C + 15) / 16;
+        p.n_chunks16 = (int)chunks16;
+        p.w16 = d->weight16;
+        p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
         if (vec && sd == 1 && (ks == 3 || ks == 7)) {
-            p.w16 = d->weight16;
-            long long chunks16 = 0;
-            for (int i = 0; i < d->n_in; ++i) chunks16 += (d->in[i].C + 15) / 16;
-            p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
+            snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, %d, 1>", MF, RPW, ks);
             return ks == 3 ? dispatch_tile_f16x3<3, 1>(p, MF, RPW, st) : dispatch_tile_f16x3<7, 1>(p, MF, RPW, st);
         }
+        // 1x1: streaming kernel with LDS-resident weights; GDN (square + normalise) stays on the exact path
+        if (vec && sd == 1 && ks == 1 && d->epilogue == LSSVC_EPI_NONE && ((chunks16 + 1) / 2) * 2 * 1024 <= kPwMaxLds)
+            return dispatch_pw_f16x3(p, st, kname);
     }
+    snprintf(kname, 96, "conv_mfma_kernel<%d, %d, %d, %d, %s>", MF, RPW, ks, sd, vec ? "true" : "false");
 #define LSSVC_CONV_KS(K, SD) \
     if (ks == K && sd == SD) return vec ? dispatch_tile<K, SD, true>(p, MF, RPW, st) : dispatch_tile<K, SD, false>(p, MF, RPW, st);
     LSSVC_CONV_KS(1, 1) LSSVC_CONV_KS(1, 2) LSSVC_CONV_KS(2, 1) LSSVC_CONV_KS(3, 1) LSSVC_CONV_KS(3, 2) LSSVC_CONV_KS(7, 1)

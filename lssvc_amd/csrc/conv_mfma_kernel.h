@@ -29,6 +29,7 @@ struct ConvP {
     int tiles_x, tiles_y, m_tiles;
     int in_vec[LSSVC_CONV_MAX_INPUTS];
     int n_chunks;    // total 8-channel chunks over all input segments
+    int n_chunks16;  // total 16-channel chunks over all input segments (f16x3 kernels)
     const void *w16; // f16x3 mode: fp16 weights [plane hi|lo][chunk16][ky][kx][m][16]
     long long w16_plane;   // elements per plane
     int debug;       // perf-ablation switches (env LSSVC_CONV_DEBUG; results are WRONG when set): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger, 16 skip LDS fragment reads
@@ -39,17 +40,17 @@ constexpr int CP = 12;  // LDS row pitch in floats (CK=8 + 4 pad)
 
 // ---- fused epilogue shared by the conv kernels: bias -> GDN -> activation -> residual -> scale ->
 //      (pixel-shuffle) store. Lane (li, lg) of wave `wave` holds, for fragment (f, r), channels
-//      m0 + 16f + 4lg .. +3 of pixel (oy0 + wave*RPW + r, ox0 + li). ------------------------------------
+//      m0 + 16f + 4lg .. +3 of one pixel per fragment row r. ------------------------------------------------
 template <int MF, int RPW>
-__device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x4 (&acc)[MF][RPW], int oy0, int ox0, int m0, int wave,
-                                              int li, int lg) {
-    const int ox = ox0 + li;
+__device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
+                                                   int lg) {
+    // pix[r] = conv-space pixel index oy*Wout + ox of this lane's column of fragment row r, or -1 if outside
     const int cps = p.Cout >> 2;  // channels after pixel shuffle
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        const int oy = oy0 + wave * RPW + r;
-        if (oy >= p.Hout || ox >= p.Wout) continue;
-        const size_t opix = (size_t)oy * p.Wout + ox;
+        if (pix[r] < 0) continue;
+        const size_t opix = (size_t)pix[r];
+        const int oy = (int)(opix / p.Wout), ox = (int)(opix - (size_t)oy * p.Wout);   // only the pixel-shuffle store needs them
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const int mb = m0 + f * 16 + 4 * lg;
@@ -124,6 +125,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x4 (&acc)[MF][R
             }
         }
     }
+}
+
+template <int MF, int RPW>
+__device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x4 (&acc)[MF][RPW], int oy0, int ox0, int m0, int wave,
+                                              int li, int lg) {
+    long long pix[RPW];
+    const int ox = ox0 + li;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int oy = oy0 + wave * RPW + r;
+        pix[r] = (oy < p.Hout && ox < p.Wout) ? (long long)oy * p.Wout + ox : -1;
+    }
+    conv_epilogue_flat<MF, RPW>(p, acc, pix, m0, lg);
 }
 
 // One K "phase" = one 8-channel chunk x RPP kernel rows. Small kernels (<=3x3) take all rows in one

@@ -1,0 +1,196 @@
+// conv_pw_f16x3_kernel.h -- 1x1 (pointwise) convolutions in the f16x3 precision mode, as a streaming GEMM.
+//
+// A 1x1 conv has no spatial reuse: per output pixel it reads Cin and writes Cout values once, so at these
+// channel counts it is bound by memory traffic and per-workgroup overheads, not by the matrix pipe
+// (DESIGN.md section 8). This kernel is therefore laid out as a stream:
+//   - the weights of the workgroup's M tile (all of K, hi/lo fp16 planes) are staged into LDS ONCE; after one
+//     barrier the workgroup never synchronises again,
+//   - workgroups are persistent: each wave walks pixel groups (RPW x 16 consecutive pixels of the flattened
+//     image) with a grid-wide stride,
+//   - the pixel operand goes straight from global memory into MFMA B fragments: lane (i, g) loads 8 consecutive
+//     channels of pixel i (two float4), i.e. every pixel contributes whole 128-byte lines per K-step; the fp32
+//     values get the fused input activation, are split hi/lo in registers and feed
+//     v_mfma_f32_16x16x32_f16 three times (lo*hi + hi*lo + hi*hi), next K-step's loads already in flight,
+//   - the shared fused epilogue (bias / activation / residual / scale / pixel-shuffle) stores float4s.
+// K order: a K-step of 32 = two 16-channel chunks of the (virtually concatenated) inputs; lane group g>>1
+// picks the chunk, g&1 the 8-channel half -- the same fragment convention as conv_f16x3_kernel.h, so the
+// host-side weight layout [chunk16][m][16] is shared (KH = KW = 1).
+#pragma once
+#include "conv_f16x3_kernel.h"
+
+namespace lssvc {
+
+constexpr int kPwMaxLds = 64 * 1024;
+
+template <int MF, int RPW>
+__global__ __launch_bounds__(256, RPW == 1 ? 4 : 2) void conv_pw_f16x3_kernel(const ConvP p) {
+    constexpr int TM = 16 * MF;
+    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];     // [plane hi|lo][chunk16 (padded to even)][TM][16]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+    const int tsel = lg >> 1;
+    const int ch8 = (lg & 1) * 8;
+
+    const int nchunk = p.n_chunks16;                  // 16-channel chunks over all input segments
+    const int nstep = (nchunk + 1) >> 1;
+    const int nslot = nstep * 2;
+    const int m_tile = blockIdx.x % p.m_tiles;
+    const int m0 = m_tile * TM;
+    const int plane = nslot * TM * CK16;              // elements per LDS plane
+
+    // ---- stage this M tile's weights once --------------------------------------------------------------
+    {
+        const _Float16 *g_h = reinterpret_cast<const _Float16 *>(p.w16);
+        const _Float16 *g_l = g_h + p.w16_plane;
+        const int items = nslot * TM * 2;             // 16-byte items per plane
+        for (int idx = tid; idx < items; idx += 256) {
+            const int c = idx / (TM * 2);
+            const int r = idx - c * (TM * 2);
+            const int m = r >> 1, half = r & 1;
+            f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < nchunk && m0 + m < p.M_pad) {
+                const size_t o = ((size_t)c * p.M_pad + m0 + m) * CK16 + half * 8;
+                h = *reinterpret_cast<const f16x8 *>(g_h + o);
+                l = *reinterpret_cast<const f16x8 *>(g_l + o);
+            }
+            const int d = (c * TM + m) * CK16 + half * 8;
+            *reinterpret_cast<f16x8 *>(wlds + d) = h;
+            *reinterpret_cast<f16x8 *>(wlds + plane + d) = l;
+        }
+    }
+    __syncthreads();
+
+    const bool sq = p.in_act == LSSVC_INACT_SQUARE;
+    const float in_slope = p.in_act == LSSVC_INACT_LRELU ? p.in_slope : 1.0f;
+    const long long npix = (long long)p.Hout * p.Wout;
+    const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
+    const long long wave_id = (long long)(blockIdx.x / p.m_tiles) * 4 + wave;
+    const long long wave_stride = (long long)(gridDim.x / p.m_tiles) * 4;
+
+    // chunk -> (segment base pointer, pixel pitch, first channel, channels left) for this lane group's chunk of step s
+    auto chunk_src = [&](int c, const float *&base, int &ld, int &c0, int &left) {
+        int seg = 0, first = 0;
+#pragma unroll
+        for (int i = 0; i < LSSVC_CONV_MAX_INPUTS - 1; ++i) {
+            const int n = (p.in[seg].C + 15) >> 4;
+            if (seg < p.n_in - 1 && c >= first + n) {
+                first += n;
+                ++seg;
+            }
+        }
+        base = p.in[seg].p;
+        ld = p.in[seg].ld;
+        c0 = (c - first) * 16;
+        left = p.in[seg].C - c0;
+    };
+
+    for (long long grp = wave_id; grp < ngroups; grp += wave_stride) {
+        long long pix[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const long long q = (grp * RPW + r) * 16 + li;
+            pix[r] = q < npix ? q : -1;
+        }
+        f32x4 acc[MF][RPW];
+#pragma unroll
+        for (int a = 0; a < MF; ++a)
+#pragma unroll
+            for (int b = 0; b < RPW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        float4 raw[2][RPW][2];
+        int left_of[2];
+        auto load_step = [&](int s, float4 (&dst)[RPW][2], int &left8) {
+            const int c = 2 * s + tsel;
+            const float *base; int ld, c0, left;
+            chunk_src(c < nchunk ? c : nchunk - 1, base, ld, c0, left);
+            left8 = c < nchunk ? left - ch8 : 0;                    // channels available from this lane's first channel on
+            const int cc = left8 > 0 ? c0 + ch8 : 0;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float *src = base + (size_t)(pix[r] >= 0 ? pix[r] : 0) * ld + cc;
+                dst[r][0] = *reinterpret_cast<const float4 *>(src);
+                dst[r][1] = *reinterpret_cast<const float4 *>(src + (left8 > 4 ? 4 : 0));
+            }
+        };
+        auto compute_step = [&](int s, const float4 (&src)[RPW][2], int left8) {
+            f16x8 bh[RPW], bl[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                float v[8] = {src[r][0].x, src[r][0].y, src[r][0].z, src[r][0].w, src[r][1].x, src[r][1].y, src[r][1].z, src[r][1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = (pix[r] >= 0 && j < left8) ? v[j] : 0.f;     // left8 is a multiple of 4 (inputs are 4-channel aligned)
+                    x *= sq ? x : (x > 0.f ? 1.0f : in_slope);
+                    x = fminf(fmaxf(x, -65504.f), 65504.f);
+                    const _Float16 h = (_Float16)x;
+                    bh[r][j] = h;
+                    bl[r][j] = (_Float16)(x - (float)h);
+                }
+            }
+            const int slot = 2 * s + tsel;
+            f16x8 ah[MF], al[MF];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int o = (slot * TM + f * 16 + li) * CK16 + ch8;
+                ah[f] = *reinterpret_cast<const f16x8 *>(wlds + o);
+                al[f] = *reinterpret_cast<const f16x8 *>(wlds + plane + o);
+            }
+            // three passes over the MF x RPW accumulators so consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][r], 0, 0, 0);
+        };
+        load_step(0, raw[0], left_of[0]);
+        for (int s = 0; s < nstep; s += 2) {          // two steps per trip so the register buffers have static names
+            if (s + 1 < nstep) load_step(s + 1, raw[1], left_of[1]);
+            compute_step(s, raw[0], left_of[0]);
+            if (s + 1 < nstep) {
+                if (s + 2 < nstep) load_step(s + 2, raw[0], left_of[0]);
+                compute_step(s + 1, raw[1], left_of[1]);
+            }
+        }
+        conv_epilogue_flat<MF, RPW>(p, acc, pix, m0, lg);
+    }
+}
+
+template <int MF, int RPW>
+static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
+    ConvP q = p;
+    q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
+    const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
+    const size_t lds = (size_t)2 * nslot * 16 * MF * CK16 * sizeof(_Float16);
+    if (lds > (size_t)kPwMaxLds) return fail("conv2d(pw f16x3): %zu bytes of weights do not fit LDS", lds);
+    static const int resident = [] {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_pw_f16x3_kernel<MF, RPW>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        return per_cu * cus;
+    }();
+    const long long npix = (long long)p.Hout * p.Wout;
+    const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
+    long long per_m = (ngroups + 3) / 4;                                    // workgroups that have work, per M tile
+    const long long cap = resident / q.m_tiles > 0 ? resident / q.m_tiles : 1;
+    if (per_m > cap) per_m = cap;
+    const long long blocks = per_m * q.m_tiles;
+    hipLaunchKernelGGL((conv_pw_f16x3_kernel<MF, RPW>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    return launch_status("conv2d(pw f16x3)");
+}
+
+int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name);
+
+}  // namespace lssvc

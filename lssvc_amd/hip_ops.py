@@ -139,7 +139,9 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
                    "hout": hout, "wout": wout, "cin": cin, "cout": cout,
                    "variant": lib.lssvc_conv2d_variant(hout, wout, m_pad, stride), "ks": KH, "stride": stride,
                    "vec": all(t.C % 4 == 0 and t.ld % 4 == 0 and t.v.ptr % 16 == 0 for t in inputs),
-                   "f16x3": w16 is not None,
+                   "f16x3": w16 is not None, "kernel": lib.lssvc_conv2d_last_kernel().decode(),
+                   "bytes": 4 * (hout * wout * cin * (stride * stride) + out.H * out.W * out.C
+                                 + (out.H * out.W * out.C if residual is not None else 0)),
                    "events": (e0, e1)})
     return out
 
@@ -158,7 +160,7 @@ def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slo
     if out is None:
         out = T.empty(hout * 2, wout * 2, cout // 4, x.device) if pixel_shuffle else T.empty(hout, wout, cout, x.device)
     w16 = None
-    if CONV_PRECISION == "f16x3" and stride == 1 and KH in (3, 7) and all(t.C % 4 == 0 and t.ld % 4 == 0 for t in inputs):
+    if CONV_PRECISION == "f16x3" and stride == 1 and KH in (1, 3, 7) and all(t.C % 4 == 0 and t.ld % 4 == 0 for t in inputs):
         w16 = W.conv_f16x3(name, [t.C for t in inputs], pixel_shuffle)
     return _conv_launch(inputs, (w_dev, b_dev, cout, m_pad), KH, KW, stride, pad, pad, out, in_act=in_act,
                         in_slope=in_slope, act=act, slope=slope, residual=residual, out_scale=out_scale,

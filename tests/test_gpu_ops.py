@@ -323,3 +323,43 @@ def test_conv_f16x3_fused_paths(hip):
     finally:
         hip.set_conv_precision("f32")
     close(got, want, rtol=1e-5, atol=1e-5)
+
+
+PW_CASES = [([64], 256, 40, 56), ([256], 64, 33, 47), ([48], 48, 20, 36), ([64, 64], 64, 18, 30), ([128, 256], 384, 9, 15),
+            ([512], 128, 12, 20), ([1024], 384, 8, 8), ([32], 128, 17, 19), ([48], 32, 16, 16), ([8], 16, 5, 7)]
+
+
+@pytest.mark.parametrize("cins,cout,H,W", PW_CASES)
+def test_conv1x1_f16x3_matches_fp64(hip, cins, cout, H, W):
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    w = torch.randn(cout, sum(cins), 1, 1, generator=g) / math.sqrt(sum(cins))
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(1, cout, H, W, generator=g)
+    ref = F.leaky_relu(F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double()), 0.1) + r.double()
+    Wt = FakeW({"c.weight": w, "c.bias": b})
+    out = {}
+    for mode in ("f16x3", "f32"):
+        try:
+            hip.set_conv_precision(mode)
+            out[mode] = back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], act="lrelu", slope=0.1, residual=nhwc(hip, r)))
+        finally:
+            hip.set_conv_precision("f32")
+    e16 = (out["f16x3"].double() - ref).abs().max().item()
+    e32 = (out["f32"].double() - ref).abs().max().item()
+    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
+
+
+def test_subpel1x1_f16x3(hip):
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(1, 128, 12, 20, generator=g)
+    w = torch.randn(256, 128, 1, 1, generator=g) / 11
+    b = torch.randn(256, generator=g)
+    want = F.pixel_shuffle(F.conv2d(x, w, b), 2)
+    Wt = FakeW({"s.0.weight": w, "s.0.bias": b})
+    try:
+        hip.set_conv_precision("f16x3")
+        got = back(hip.subpel(Wt, "s", nhwc(hip, x)))
+    finally:
+        hip.set_conv_precision("f32")
+    close(got, want, rtol=1e-5, atol=1e-5)
