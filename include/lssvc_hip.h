@@ -82,6 +82,9 @@ typedef struct lssvc_conv_desc {
     lssvc_view out;      /* H_out x W_out x Cout, or 2H_out x 2W_out x Cout/4 with pixel_shuffle */
     int32_t precision;   /* LSSVC_PREC_F32 (exact fp32 MFMA, the parity reference path) or LSSVC_PREC_F16X3 */
     const void *weight16; /* F16X3 only: fp16 weights [hi|lo][chunk16][ky][kx][m][16] (lssvc_amd/weights.py) */
+    float weight16_unscale; /* F16X3 only: weight16 holds w * 2^e (a power of two chosen so that the lo parts are
+                             * normal fp16 numbers); the accumulators are multiplied by this 2^-e (exact) before the
+                             * epilogue. 0 is read as 1. */
 } lssvc_conv_desc;
 
 int lssvc_conv2d(const lssvc_conv_desc *d, void *stream);

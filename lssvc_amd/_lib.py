@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("slope", C.c_float),
         ("residual", View), ("out_scale", C.c_float),
         ("pixel_shuffle", C.c_int32), ("out", View),
-        ("precision", C.c_int32), ("weight16", C.c_void_p),
+        ("precision", C.c_int32), ("weight16", C.c_void_p), ("weight16_unscale", C.c_float),
     ]
 
 

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
         __syncthreads();
         cur = nxt;
     }
+    conv_unscale<MF, RPW>(p, acc);
     conv_epilogue<MF, RPW>(p, acc, oy0, ox0, m0, wave, li, lg);
 }
 

@@ -12,6 +12,19 @@ int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name) {
     int MF = frags < 4 ? frags : 4;
     if (frags % 4 != 0 && frags % 3 == 0) MF = 3;
     if (MF > mf_fit) MF = mf_fit;
+    static const int allm = getenv("LSSVC_PW_ALLM") ? atoi(getenv("LSSVC_PW_ALLM")) : 1;
+    {   // small K and the whole weight matrix in LDS: convert the pixels once, loop the M tiles inside the wave
+        int mf = frags < 4 ? frags : 4;
+        if (frags % 4 != 0 && frags % 3 == 0) mf = 3;
+        const int m_tiles = (frags + mf - 1) / mf;
+        if (allm && p.n_chunks16 <= 4 && (long long)nslot * m_tiles * mf * 1024 <= kPwMaxLds) {
+            snprintf(kernel_name, 96, "conv_pw_allm_f16x3_kernel<%d, 2>", mf);
+            if (mf == 4) return launch_pw_allm_f16x3<4, 2>(p, st);
+            if (mf == 3) return launch_pw_allm_f16x3<3, 2>(p, st);
+            if (mf == 2) return launch_pw_allm_f16x3<2, 2>(p, st);
+            return launch_pw_allm_f16x3<1, 2>(p, st);
+        }
+    }
     snprintf(kernel_name, 96, "conv_pw_f16x3_kernel<%d, %d>", MF, rpw);
     if (rpw == 1) {
         if (MF == 4) return launch_pw_f16x3<4, 1>(p, st);

@@ -138,6 +138,7 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         for (int i = 0; i < d->n_in; ++i) chunks16 += (d->in[i].C + 15) / 16;
         p.n_chunks16 = (int)chunks16;
         p.w16 = d->weight16;
+        p.w16_unscale = d->weight16_unscale != 0.0f ? d->weight16_unscale : 1.0f;
         p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
         if (vec && sd == 1 && (ks == 3 || ks == 7)) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, %d, 1>", MF, RPW, ks);

@@ -32,6 +32,7 @@ struct ConvP {
     int n_chunks16;  // total 16-channel chunks over all input segments (f16x3 kernels)
     const void *w16; // f16x3 mode: fp16 weights [plane hi|lo][chunk16][ky][kx][m][16]
     long long w16_plane;   // elements per plane
+    float w16_unscale;     // f16x3 mode: accumulators *= this (power of two) before the epilogue
     int debug;       // perf-ablation switches (env LSSVC_CONV_DEBUG; results are WRONG when set): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger, 16 skip LDS fragment reads
     int out_vec, res_vec, gdn_vec;
 };
@@ -41,6 +42,14 @@ constexpr int CP = 12;  // LDS row pitch in floats (CK=8 + 4 pad)
 // ---- fused epilogue shared by the conv kernels: bias -> GDN -> activation -> residual -> scale ->
 //      (pixel-shuffle) store. Lane (li, lg) of wave `wave` holds, for fragment (f, r), channels
 //      m0 + 16f + 4lg .. +3 of one pixel per fragment row r. ------------------------------------------------
+template <int MF, int RPW>
+__device__ __forceinline__ void conv_unscale(const ConvP &p, f32x4 (&acc)[MF][RPW]) {
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) acc[f][r] *= p.w16_unscale;
+}
+
 template <int MF, int RPW>
 __device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
                                                    int lg) {

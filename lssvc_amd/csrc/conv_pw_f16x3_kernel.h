@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256, RPW == 1 ? 4 : 2) void conv_pw_f16x3_kernel(co
                 compute_step(s + 1, raw[1], left_of[1]);
             }
         }
+        conv_unscale<MF, RPW>(p, acc);
         conv_epilogue_flat<MF, RPW>(p, acc, pix, m0, lg);
     }
 }
@@ -189,6 +190,182 @@ static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
     const long long blocks = per_m * q.m_tiles;
     hipLaunchKernelGGL((conv_pw_f16x3_kernel<MF, RPW>), dim3((unsigned)blocks), dim3(256), lds, st, q);
     return launch_status("conv2d(pw f16x3)");
+}
+
+
+// ---- "all-M" variant for small K (<= 64 input channels, i.e. <= 2 K-steps) whose whole weight matrix fits LDS:
+// the wave converts its pixel fragments ONCE, keeps them in registers and walks every M tile itself (so X is
+// read and split once instead of once per M tile, and all output channels of a pixel are written by one wave),
+// while the raw loads of its next pixel group are already in flight.
+template <int MF, int RPW>
+__global__ __launch_bounds__(256, 2) void conv_pw_allm_f16x3_kernel(const ConvP p) {
+    constexpr int TM = 16 * MF;
+    constexpr int NS = 2;                                                   // K-steps held in registers
+    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];     // [plane][slot][M_all][16]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+    const int tsel = lg >> 1;
+    const int ch8 = (lg & 1) * 8;
+    const int nchunk = p.n_chunks16;
+    const int nstep = (nchunk + 1) >> 1;                                    // 1 or 2
+    const int nslot = nstep * 2;
+    const int m_all = p.m_tiles * TM;                                       // rows held in LDS (>= M_pad)
+    const int plane = nslot * m_all * CK16;
+    {
+        const _Float16 *g_h = reinterpret_cast<const _Float16 *>(p.w16);
+        const _Float16 *g_l = g_h + p.w16_plane;
+        const int items = nslot * m_all * 2;
+        for (int idx = tid; idx < items; idx += 256) {
+            const int c = idx / (m_all * 2);
+            const int r = idx - c * (m_all * 2);
+            const int m = r >> 1, half = r & 1;
+            f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < nchunk && m < p.M_pad) {
+                const size_t o = ((size_t)c * p.M_pad + m) * CK16 + half * 8;
+                h = *reinterpret_cast<const f16x8 *>(g_h + o);
+                l = *reinterpret_cast<const f16x8 *>(g_l + o);
+            }
+            const int d = (c * m_all + m) * CK16 + half * 8;
+            *reinterpret_cast<f16x8 *>(wlds + d) = h;
+            *reinterpret_cast<f16x8 *>(wlds + plane + d) = l;
+        }
+    }
+    __syncthreads();
+
+    const bool sq = p.in_act == LSSVC_INACT_SQUARE;
+    const float in_slope = p.in_act == LSSVC_INACT_LRELU ? p.in_slope : 1.0f;
+    const long long npix = (long long)p.Hout * p.Wout;
+    const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
+    const long long wave_id = (long long)blockIdx.x * 4 + wave;
+    const long long wave_stride = (long long)gridDim.x * 4;
+
+    // this lane group's source chunk per K-step is the same for every pixel group: resolve it once
+    const float *base[NS];
+    int ld[NS], cc[NS], left8[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = 2 * s + tsel;
+        int seg = 0, first = 0;
+#pragma unroll
+        for (int i = 0; i < LSSVC_CONV_MAX_INPUTS - 1; ++i) {
+            const int n = (p.in[seg].C + 15) >> 4;
+            if (seg < p.n_in - 1 && c >= first + n) {
+                first += n;
+                ++seg;
+            }
+        }
+        const int c0 = (c - first) * 16;
+        left8[s] = (s < nstep && c < nchunk) ? p.in[seg].C - c0 - ch8 : 0;
+        base[s] = p.in[seg].p;
+        ld[s] = p.in[seg].ld;
+        cc[s] = left8[s] > 0 ? c0 + ch8 : 0;
+    }
+
+    float4 raw[NS][RPW][2];
+    auto load_group = [&](long long grp) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                long long q = (grp * RPW + r) * 16 + li;
+                if (q >= npix) q = 0;
+                const float *src = base[s] + (size_t)q * ld[s] + cc[s];
+                raw[s][r][0] = *reinterpret_cast<const float4 *>(src);
+                raw[s][r][1] = *reinterpret_cast<const float4 *>(src + (left8[s] > 4 ? 4 : 0));
+            }
+    };
+    if (wave_id < ngroups) load_group(wave_id);
+    for (long long grp = wave_id; grp < ngroups; grp += wave_stride) {
+        long long pix[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const long long q = (grp * RPW + r) * 16 + li;
+            pix[r] = q < npix ? q : -1;
+        }
+        f16x8 bh[NS][RPW], bl[NS][RPW];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float v[8] = {raw[s][r][0].x, raw[s][r][0].y, raw[s][r][0].z, raw[s][r][0].w,
+                                    raw[s][r][1].x, raw[s][r][1].y, raw[s][r][1].z, raw[s][r][1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = (pix[r] >= 0 && j < left8[s]) ? v[j] : 0.f;
+                    x *= sq ? x : (x > 0.f ? 1.0f : in_slope);
+                    x = fminf(fmaxf(x, -65504.f), 65504.f);
+                    const _Float16 h = (_Float16)x;
+                    bh[s][r][j] = h;
+                    bl[s][r][j] = (_Float16)(x - (float)h);
+                }
+            }
+        if (grp + wave_stride < ngroups) load_group(grp + wave_stride);      // in flight during the whole M loop
+        for (int mt = 0; mt < p.m_tiles; ++mt) {
+            f32x4 acc[MF][RPW];
+#pragma unroll
+            for (int a = 0; a < MF; ++a)
+#pragma unroll
+                for (int b = 0; b < RPW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < nstep) {
+                    f16x8 ah[MF], al[MF];
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        const int o = ((2 * s + tsel) * m_all + mt * TM + f * 16 + li) * CK16 + ch8;
+                        ah[f] = *reinterpret_cast<const f16x8 *>(wlds + o);
+                        al[f] = *reinterpret_cast<const f16x8 *>(wlds + plane + o);
+                    }
+#pragma unroll
+                    for (int f = 0; f < MF; ++f)
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[s][r], acc[f][r], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < MF; ++f)
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[s][r], acc[f][r], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < MF; ++f)
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[s][r], acc[f][r], 0, 0, 0);
+                }
+            }
+            conv_unscale<MF, RPW>(p, acc);
+            conv_epilogue_flat<MF, RPW>(p, acc, pix, mt * TM, lg);
+        }
+    }
+}
+
+template <int MF, int RPW>
+static int launch_pw_allm_f16x3(const ConvP &p, hipStream_t st) {
+    ConvP q = p;
+    q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
+    const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
+    const size_t lds = (size_t)2 * nslot * q.m_tiles * 16 * MF * CK16 * sizeof(_Float16);
+    if (lds > (size_t)kPwMaxLds || p.n_chunks16 > 4) return fail("conv2d(pw all-M f16x3): shape does not fit");
+    static const int resident = [] {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_pw_allm_f16x3_kernel<MF, RPW>, 256, kPwMaxLds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        return per_cu * cus;
+    }();
+    const long long npix = (long long)p.Hout * p.Wout;
+    const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
+    long long blocks = (ngroups + 3) / 4;
+    // LDS use varies per launch; size the persistent grid by what the actual footprint admits (2 per CU at most by registers)
+    long long cap = resident;
+    const long long by_lds = (long long)(160 * 1024 / (lds > 1024 ? lds : 1024)) * 256;
+    if (cap > by_lds) cap = by_lds;
+    if (cap > 2 * 256) cap = 2 * 256;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((conv_pw_allm_f16x3_kernel<MF, RPW>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    return launch_status("conv2d(pw all-M f16x3)");
 }
 
 int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name);

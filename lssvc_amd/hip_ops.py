@@ -29,6 +29,7 @@ def set_conv_precision(mode):
 
 # optional op log: list of (kind, name, macs) appended by conv() when enabled (bench / profiling)
 OP_LOG = None
+CONV_CHECK = _os.environ.get("LSSVC_CONV_CHECK", "0") == "1"
 
 
 def stream_ptr():
@@ -122,8 +123,24 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
     d.out_scale = out_scale
     d.pixel_shuffle = 1 if pixel_shuffle else 0
     d.out = out.v
+    if w16 is not None and CONV_CHECK:
+        # debug aid (LSSVC_CONV_CHECK=1): run the launch in fp32 into a scratch output first, compare afterwards
+        scratch = T.empty(out.H, out.W, out.C, out.device)
+        d.out = scratch.v
+        check(lib.lssvc_conv2d(C.byref(d), stream_ptr()))
+        d.out = out.v
+        d.precision, d.weight16, d.weight16_unscale = _lib.PREC_F16X3, w16[0].data_ptr(), w16[1]
+        check(lib.lssvc_conv2d(C.byref(d), stream_ptr()))
+        a, b = scratch.torch_hwc(), out.torch_hwc()
+        err = (a - b).abs().max().item()
+        ref = a.abs().max().item()
+        if not err <= 1e-4 * max(ref, 1.0):
+            print("CONV_CHECK %s k%d in=%s out=%dx%dx%d(ld %d) kernel=%s: max|f16x3-f32| %.3e (max|f32| %.3e) res=%s ps=%s"
+                  % (name, KH, [(t.C, t.ld) for t in inputs], out.H, out.W, out.C, out.ld,
+                     lib.lssvc_conv2d_last_kernel().decode(), err, ref, residual is not None, pixel_shuffle), flush=True)
+        return out
     if w16 is not None:
-        d.precision, d.weight16 = _lib.PREC_F16X3, w16.data_ptr()
+        d.precision, d.weight16, d.weight16_unscale = _lib.PREC_F16X3, w16[0].data_ptr(), w16[1]
     if OP_LOG is None:
         check(lib.lssvc_conv2d(C.byref(d), stream_ptr()))
         return out

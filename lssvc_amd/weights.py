@@ -13,6 +13,7 @@ Layouts produced here (see include/lssvc_hip.h):
   depthwise (C,1,3,3) -> [9][C]
   BitEstimator / EntropyBottleneck parameters -> [rows][C] tables with softplus / tanh pre-applied
 """
+import math
 import torch
 import torch.nn.functional as F
 
@@ -73,9 +74,15 @@ def layout_conv(w, bias, splits, pixel_shuffle):
     return wp, bp, cout, m_pad
 
 
+F16X3_WEIGHT_EXP = 12      # max|w * 2^e| in [2^11, 2^12): far from fp16's 65504, lo parts normal down to |w'| ~ 0.125
+
+
 def layout_conv_f16x3(w, splits, pixel_shuffle):
-    """fp16 hi/lo planes for the f16x3 conv mode: (2, chunk16, KH, KW, M_pad, 16) fp16, hi = fp16(w),
-    lo = fp16(w - hi); same concat-segment / pixel-shuffle / M padding rules as layout_conv, 16-channel chunks."""
+    """fp16 hi/lo planes for the f16x3 conv mode: (2, chunk16, KH, KW, M_pad, 16) fp16 of w' = w * 2^e,
+    hi = fp16(w'), lo = fp16(w' - hi); same concat-segment / pixel-shuffle / M padding rules as layout_conv,
+    16-channel chunks. Returns (planes, 2^-e). e is picked per layer so that max|w'| lands in [2^11, 2^12]: the
+    lo parts of typical weights (|w| ~ 1e-2) would otherwise be fp16 subnormals and lose up to 10 of their 11
+    bits; the scaling is a power of two, so it is exact and the kernel undoes it exactly on the accumulators."""
     cout, cin, kh, kw = w.shape
     if pixel_shuffle:
         cps = cout // 4
@@ -87,9 +94,12 @@ def layout_conv_f16x3(w, splits, pixel_shuffle):
         a += c
     wp = F.pad(torch.cat(segs, dim=1), (0, 0, 0, 0, 0, 0, 0, m_pad - cout))
     wp = wp.reshape(m_pad, wp.shape[1] // 16, 16, kh, kw).permute(1, 3, 4, 0, 2).contiguous()
+    wmax = float(wp.abs().max())
+    e = 0 if wmax == 0.0 or not math.isfinite(wmax) else max(-14, min(24, F16X3_WEIGHT_EXP - math.frexp(wmax)[1]))
+    wp = wp * (2.0 ** e)
     hi = wp.half()
     lo = (wp - hi.float()).half()
-    return torch.stack([hi, lo], 0).contiguous()
+    return torch.stack([hi, lo], 0).contiguous(), 2.0 ** -e
 
 
 def conv_t_as_conv(w, bias, stride):
@@ -148,7 +158,8 @@ class WeightStore:
     def conv_f16x3(self, name, splits, pixel_shuffle=False):
         key = ("conv16", name, tuple(splits), pixel_shuffle)
         if key not in self._cache:
-            self._cache[key] = self._dev(layout_conv_f16x3(self.sd[name + ".weight"], splits, pixel_shuffle))
+            planes, unscale = layout_conv_f16x3(self.sd[name + ".weight"], splits, pixel_shuffle)
+            self._cache[key] = (self._dev(planes), unscale)
         return self._cache[key]
 
     def conv_t(self, name, stride):
