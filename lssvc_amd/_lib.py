@@ -37,6 +37,14 @@ class ConvDesc(C.Structure):
     ]
 
 
+class FfnDesc(C.Structure):
+    _fields_ = [
+        ("x", View), ("pre_in", View), ("pre_w16", C.c_void_p), ("pre_unscale", C.c_float), ("pre_bias", C.c_void_p),
+        ("ident", View), ("w1_16", C.c_void_p), ("w1_unscale", C.c_float), ("b1", C.c_void_p), ("hidden", C.c_int32),
+        ("w2_16", C.c_void_p), ("w2_unscale", C.c_float), ("b2", C.c_void_p), ("slope", C.c_float), ("out", View),
+    ]
+
+
 class CdfTable(C.Structure):
     _fields_ = [("cdfs", C.c_void_p), ("n_cdfs", C.c_int32), ("stride", C.c_int32), ("sizes", C.c_void_p),
                 ("offsets", C.c_void_p)]
@@ -50,6 +58,8 @@ SIGNATURES = {
     "lssvc_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "lssvc_conv2d_variant": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "lssvc_conv2d_last_kernel": (C.c_char_p, []),
+    "lssvc_ffn_f16x3": (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
+    "lssvc_ffn_f16x3_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "lssvc_dwconv3x3": (C.c_int, [VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
     "lssvc_resize_bilinear": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
     "lssvc_flow_warp": (C.c_int, [VP, VP, VP, C.c_void_p]),

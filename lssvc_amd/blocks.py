@@ -48,8 +48,11 @@ def depth_conv_block(W, p, inputs, out=None):
         ident = inputs
     t = ops.conv(W, q + ".conv1.0", inputs, act="lrelu", slope=0.01)
     t = ops.dwconv3x3(W, q + ".depth_conv", t)
-    o1 = ops.conv(W, q + ".conv2", t, residual=ident)
     f = p + ".block.1"
+    if ops.ffn_fusable(W, f, q + ".conv2", ident.C, t.C):
+        # conv2 + identity + the whole ConvFFN in one launch; the 4C-wide hidden tensor never reaches HBM
+        return ops.ffn_block(W, f, pre_name=q + ".conv2", pre_in=t, ident=ident, slope=0.1, out=out)
+    o1 = ops.conv(W, q + ".conv2", t, residual=ident)
     t = ops.conv(W, f + ".conv.0", o1, act="lrelu", slope=0.1)
     return ops.conv(W, f + ".conv.2", t, act="lrelu", slope=0.1, residual=o1, out=out)
 

@@ -220,6 +220,57 @@ def dwconv3x3(W, name, x, out=None):
     return out
 
 
+FUSE_FFN = _os.environ.get("LSSVC_FUSE_FFN", "1") == "1"
+_FFN_LDS_LIMIT = 160 * 1024
+
+
+def ffn_fusable(W, ffn_prefix, pre_name, c_out, pre_cin):
+    """Can DepthConv.conv2 (+identity) + ConvFFN of this block run as one lssvc_ffn_f16x3 launch?"""
+    if not (FUSE_FFN and CONV_PRECISION == "f16x3" and c_out in (32, 48, 64)):
+        return False
+    w1 = W.raw(ffn_prefix + ".conv.0.weight")
+    if w1.shape[1] != c_out or w1.shape[0] % 32 or not W.has(ffn_prefix + ".conv.0.bias") or not W.has(ffn_prefix + ".conv.2.bias"):
+        return False
+    if pre_name is not None and (pre_cin % 8 or pre_cin > 64 or not W.has(pre_name + ".bias")):
+        return False
+    return lib.lssvc_ffn_f16x3_lds_bytes(c_out, w1.shape[0], pre_cin if pre_name else 0) <= _FFN_LDS_LIMIT
+
+
+def ffn_block(W, ffn_prefix, *, x=None, pre_name=None, pre_in=None, ident=None, slope=0.1, out=None):
+    """out = o1 + lrelu(conv.2(lrelu(conv.0(o1)))) with o1 = x, or o1 = pre_name(pre_in) + ident, in one launch
+    (DepthConvBlock's per-pixel tail, lssvc_modules.py:38-72)."""
+    rec = W.ffn_f16x3(ffn_prefix, pre_name)
+    ref = x if pre_name is None else ident
+    if out is None:
+        out = ref.like()
+    d = _lib.FfnDesc()
+    d.x = x.v if pre_name is None else _NULL_VIEW
+    if pre_name is not None:
+        d.pre_in, d.ident = pre_in.v, ident.v
+        d.pre_w16, d.pre_unscale, d.pre_bias = rec["wp"].data_ptr(), rec["up"], rec["bp"].data_ptr()
+    else:
+        d.pre_in, d.ident = _NULL_VIEW, _NULL_VIEW
+    d.w1_16, d.w1_unscale, d.b1, d.hidden = rec["w1"].data_ptr(), rec["u1"], rec["b1"].data_ptr(), rec["hidden"]
+    d.w2_16, d.w2_unscale, d.b2 = rec["w2"].data_ptr(), rec["u2"], rec["b2"].data_ptr()
+    d.slope = slope
+    d.out = out.v
+    if OP_LOG is None:
+        check(lib.lssvc_ffn_f16x3(C.byref(d), stream_ptr()))
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.lssvc_ffn_f16x3(C.byref(d), stream_ptr()))
+    e1.record()
+    c, hid = rec["C"], rec["hidden"]
+    pre_cin = rec.get("pre_cin", 0) if pre_name is not None else 0
+    npx = out.H * out.W
+    OP_LOG.append({"kind": "ffn_fused", "name": ffn_prefix, "macs": npx * (2 * c * hid + pre_cin * c),
+                   "hout": out.H, "wout": out.W, "cin": c, "cout": c, "variant": 0, "ks": 1, "stride": 1, "vec": True,
+                   "f16x3": True, "kernel": "ffn_f16x3_kernel<%d, %s>" % (c // 16, "true" if pre_name else "false"),
+                   "bytes": 4 * npx * (2 * c + (pre_cin if pre_name else 0)), "events": (e0, e1)})
+    return out
+
+
 def resize(x, H, W_, scale=1.0, out=None):
     if out is None:
         out = T.empty(int(H), int(W_), x.C, x.device)

@@ -102,6 +102,53 @@ def layout_conv_f16x3(w, splits, pixel_shuffle):
     return torch.stack([hi, lo], 0).contiguous(), 2.0 ** -e
 
 
+def _f16x3_planes(w):
+    """(w * 2^e split into fp16 hi / lo, flattened and concatenated [hi | lo]; 2^-e) -- see layout_conv_f16x3."""
+    wmax = float(w.abs().max())
+    e = 0 if wmax == 0.0 or not math.isfinite(wmax) else max(-14, min(24, F16X3_WEIGHT_EXP - math.frexp(wmax)[1]))
+    w = w * (2.0 ** e)
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    return torch.cat([hi.reshape(-1), lo.reshape(-1)]).contiguous(), 2.0 ** -e
+
+
+def _chained_k(n_frag_pairs):
+    """Channel index of K position (pair p, k = 8g + j) when a B operand is assembled from two accumulator
+    fragments of the previous GEMM (csrc/ffn_f16x3.hip): fragment 2p + (j >> 2), row 4g + (j & 3)."""
+    k = torch.arange(32)
+    g, j = k // 8, k % 8
+    p = torch.arange(n_frag_pairs)[:, None]
+    return (2 * p + (j >> 2)[None, :]) * 16 + (4 * g + (j & 3))[None, :]            # (pairs, 32)
+
+
+def layout_ffn_f16x3(w1, w2):
+    """ConvFFN weights (hidden, C, 1, 1) / (C, hidden, 1, 1) -> the two LDS images lssvc_ffn_f16x3 stages:
+    W1 [t][f][s][16][32] (hidden fragment 2t+f, K-step s over the C channels in chained order) and
+    W2 [t][m][16][32] (output fragment m, K = the 32 hidden channels of pair t in chained order)."""
+    hidden, c = w1.shape[0], w1.shape[1]
+    assert c % 16 == 0 and hidden % 32 == 0 and tuple(w2.shape[:2]) == (c, hidden)
+    cf, t = c // 16, hidden // 32
+    s = (cf + 1) // 2
+    w1p = F.pad(w1.reshape(hidden, c), (0, 32 * s - c))                              # (hidden, 32 s) zero-padded
+    ic = _chained_k(s)                                                               # (s, 32)
+    a = w1p[:, ic]                                                                   # (hidden, s, 32)
+    a = a.reshape(t, 2, 16, s, 32).permute(0, 1, 3, 2, 4)                            # [t][f][s][i][k]
+    hc = _chained_k(t)                                                               # (t, 32)
+    b = w2.reshape(c, hidden)[:, hc]                                                 # (c, t, 32)
+    b = b.reshape(cf, 16, t, 32).permute(2, 0, 1, 3)                                 # [t][m][i][k]
+    return _f16x3_planes(a.contiguous()), _f16x3_planes(b.contiguous())
+
+
+def layout_pw_natural_f16x3(w):
+    """A 1x1 conv weight (Cout, Cin, 1, 1) as [m][s][16][32] fragments in natural K order (leading conv of
+    lssvc_ffn_f16x3)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cout % 16 == 0
+    s = (cin + 31) // 32
+    a = F.pad(w.reshape(cout, cin), (0, 32 * s - cin)).reshape(cout // 16, 16, s, 32).permute(0, 2, 1, 3)
+    return _f16x3_planes(a.contiguous())
+
+
 def conv_t_as_conv(w, bias, stride):
     """ConvTranspose2d(k=3, padding=1[, stride=2, output_padding=1]) weight (Cin, Cout, 3, 3) ->
     (equivalent conv weight OIHW, bias, KH, pad, pixel_shuffle)."""
@@ -160,6 +207,21 @@ class WeightStore:
         if key not in self._cache:
             planes, unscale = layout_conv_f16x3(self.sd[name + ".weight"], splits, pixel_shuffle)
             self._cache[key] = (self._dev(planes), unscale)
+        return self._cache[key]
+
+    def ffn_f16x3(self, ffn_prefix, pre_name=None):
+        """Device blobs for lssvc_ffn_f16x3: ConvFFN `ffn_prefix`.conv.{0,2} and, optionally, the leading 1x1 conv."""
+        key = ("ffn16", ffn_prefix, pre_name)
+        if key not in self._cache:
+            w1, w2 = self.sd[ffn_prefix + ".conv.0.weight"], self.sd[ffn_prefix + ".conv.2.weight"]
+            (a, ua), (b, ub) = layout_ffn_f16x3(w1, w2)
+            rec = {"w1": self._dev(a), "u1": ua, "w2": self._dev(b), "u2": ub, "hidden": w1.shape[0], "C": w1.shape[1],
+                   "b1": self._dev(self.sd[ffn_prefix + ".conv.0.bias"]), "b2": self._dev(self.sd[ffn_prefix + ".conv.2.bias"])}
+            if pre_name is not None:
+                wp = self.sd[pre_name + ".weight"]
+                blob, up = layout_pw_natural_f16x3(wp)
+                rec.update({"wp": self._dev(blob), "up": up, "bp": self._dev(self.sd[pre_name + ".bias"]), "pre_cin": wp.shape[1]})
+            self._cache[key] = rec
         return self._cache[key]
 
     def conv_t(self, name, stride):

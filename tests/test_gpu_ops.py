@@ -363,3 +363,97 @@ def test_subpel1x1_f16x3(hip):
     finally:
         hip.set_conv_precision("f32")
     close(got, want, rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------- fused DepthConvBlock tail
+def _ffn_weights(g, c, hidden, pre_cin=None):
+    sd = {"f.conv.0.weight": torch.randn(hidden, c, 1, 1, generator=g) / math.sqrt(c), "f.conv.0.bias": torch.randn(hidden, generator=g) * 0.1,
+          "f.conv.2.weight": torch.randn(c, hidden, 1, 1, generator=g) / math.sqrt(hidden), "f.conv.2.bias": torch.randn(c, generator=g) * 0.1}
+    if pre_cin:
+        sd["p.weight"] = torch.randn(c, pre_cin, 1, 1, generator=g) / math.sqrt(pre_cin)
+        sd["p.bias"] = torch.randn(c, generator=g) * 0.1
+    return sd
+
+
+def _ffn_ref(sd, o1):
+    h = F.leaky_relu(F.conv2d(o1, sd["f.conv.0.weight"].double(), sd["f.conv.0.bias"].double()), 0.1)
+    return o1 + F.leaky_relu(F.conv2d(h, sd["f.conv.2.weight"].double(), sd["f.conv.2.bias"].double()), 0.1)
+
+
+@pytest.mark.parametrize("c,hidden,pre_cin,H,W", [(64, 256, None, 24, 40), (48, 192, None, 19, 23), (32, 128, None, 16, 16),
+                                                 (64, 256, 64, 21, 35), (48, 192, 48, 16, 48), (32, 128, 32, 7, 9),
+                                                 (48, 192, 64, 12, 20), (32, 64, 24, 10, 10), (64, 128, 40, 9, 33)])
+def test_ffn_fused_matches_fp64(hip, c, hidden, pre_cin, H, W):
+    """lssvc_ffn_f16x3 (DepthConv.conv2 + identity + ConvFFN in one launch) against an fp64 reference; error budget as
+    for the unfused f16x3 convs: within 8x of what the exact-fp32 kernels give for the same chain."""
+    g = torch.Generator().manual_seed(c * 1000 + hidden + (pre_cin or 0))
+    sd = _ffn_weights(g, c, hidden, pre_cin)
+    Wt = FakeW(sd)
+    try:
+        hip.set_conv_precision("f16x3")
+        assert hip.ffn_fusable(Wt, "f", "p" if pre_cin else None, c, pre_cin or 0)
+        if pre_cin:
+            t = torch.randn(1, pre_cin, H, W, generator=g)
+            ident = torch.randn(1, c, H, W, generator=g)
+            o1 = F.conv2d(t.double(), sd["p.weight"].double(), sd["p.bias"].double()) + ident.double()
+            got = back(hip.ffn_block(Wt, "f", pre_name="p", pre_in=nhwc(hip, t), ident=nhwc(hip, ident)))
+            hip.set_conv_precision("f32")
+            u = hip.conv(Wt, "p", nhwc(hip, t), residual=nhwc(hip, ident))
+        else:
+            x = torch.randn(1, c, H, W, generator=g)
+            o1 = x.double()
+            got = back(hip.ffn_block(Wt, "f", x=nhwc(hip, x)))
+            hip.set_conv_precision("f32")
+            u = nhwc(hip, x)
+        v = hip.conv(Wt, "f.conv.0", u, act="lrelu", slope=0.1)
+        unfused = back(hip.conv(Wt, "f.conv.2", v, act="lrelu", slope=0.1, residual=u))
+    finally:
+        hip.set_conv_precision("f32")
+    ref = _ffn_ref(sd, o1)
+    e16 = (got.double() - ref).abs().max().item()
+    e32 = (unfused.double() - ref).abs().max().item()
+    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
+
+
+def test_ffn_fused_on_channel_slices_and_in_place(hip):
+    """Views with ld > C (slices of a concat buffer) for every operand, and out aliasing ident."""
+    g = torch.Generator().manual_seed(77)
+    c, hidden, H, W = 48, 192, 13, 21
+    sd = _ffn_weights(g, c, hidden, 48)
+    Wt = FakeW(sd)
+    wide_t = torch.randn(1, 96, H, W, generator=g)
+    wide_i = torch.randn(1, 112, H, W, generator=g)
+    o1 = F.conv2d(wide_t[:, 48:96].double(), sd["p.weight"].double(), sd["p.bias"].double()) + wide_i[:, 16:64].double()
+    ref = _ffn_ref(sd, o1)
+    try:
+        hip.set_conv_precision("f16x3")
+        bt, bi = nhwc(hip, wide_t), nhwc(hip, wide_i)
+        out = hip.ffn_block(Wt, "f", pre_name="p", pre_in=bt.slice(48, 96), ident=bi.slice(16, 64), out=bi.slice(16, 64))
+    finally:
+        hip.set_conv_precision("f32")
+    res = back(bi)
+    close(res[:, 16:64], ref.float(), rtol=2e-5, atol=2e-5)
+    assert torch.equal(res[:, :16], wide_i[:, :16]) and torch.equal(res[:, 64:], wide_i[:, 64:])
+
+
+def test_depth_conv_block_fused_equals_unfused(hip):
+    from lssvc_amd import blocks
+    g = torch.Generator().manual_seed(5)
+    c, H, W = 64, 20, 28
+    sd = {"b.block.0.conv1.0.weight": torch.randn(c, c, 1, 1, generator=g) / 8, "b.block.0.conv1.0.bias": torch.randn(c, generator=g) * 0.1,
+          "b.block.0.depth_conv.weight": torch.randn(c, 1, 3, 3, generator=g) / 3, "b.block.0.depth_conv.bias": torch.randn(c, generator=g) * 0.1,
+          "b.block.0.conv2.weight": torch.randn(c, c, 1, 1, generator=g) / 8, "b.block.0.conv2.bias": torch.randn(c, generator=g) * 0.1}
+    for k, v in _ffn_weights(g, c, 4 * c).items():
+        sd[k.replace("f.", "b.block.1.")] = v
+    Wt = FakeW(sd)
+    x = torch.randn(1, c, H, W, generator=g)
+    outs = {}
+    try:
+        hip.set_conv_precision("f16x3")
+        for fuse in (True, False):
+            hip.FUSE_FFN = fuse
+            outs[fuse] = back(blocks.depth_conv_block(Wt, "b", nhwc(hip, x)))
+    finally:
+        hip.FUSE_FFN = True
+        hip.set_conv_precision("f32")
+    close(outs[True], outs[False], rtol=1e-5, atol=1e-5)
