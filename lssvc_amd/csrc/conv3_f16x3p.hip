@@ -1,0 +1,330 @@
+// conv3_f16x3p.hip -- 3x3 stride-1 convolution in the f16x3 mode: PERSISTENT, double-buffered, WARP-SPECIALISED.
+//
+// Why. In the tiled kernel (conv_f16x3_kernel.h) every wave does everything: address
+// arithmetic + global loads, fp32 -> fp16 hi/lo conversion + LDS stores, LDS fragment reads, MFMAs, epilogue. All of
+// that is one in-order instruction stream per wave, and the waves of a workgroup are barrier-locked into doing the
+// same part at the same time, so the matrix pipe idles while they stage. Ablations on MI355X (3x3 64->64): loads
+// -19 %, conversion -8 %, fragment reads -7 %, epilogue -16 %, loop bookkeeping -26 %; the kernel ran at 215-255
+// TFLOP/s where a bare LDS-fed MFMA loop sustains ~620 (f16x3-equivalent; tools/probes/mfma_probe.hip).
+// Here the work is split by wave role, one workgroup of 8 waves per CU, persistent over 32x16-pixel x 16*MF-channel tiles:
+//   * waves 0-3, one per SIMD, are CONSUMERS: ds_read_b128 fragments + MFMA, nothing else, 8 pixel rows x MF channel
+//     fragments each (up to 128 accumulator registers); after a tile's last phase they run the fused epilogue;
+//   * waves 4-7, one per SIMD, are PRODUCERS: they fetch the next phase's 34x18x16-channel fp32 halo patch, apply the
+//     input activation, split it into fp16 hi/lo planes in LDS, and move the next phase's weights (already fp16 in LDS
+//     image order) global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write). Their VALU / VMEM issue
+//     slots interleave with the consumer's MFMAs on the same SIMD (an MFMA holds the issue port 8 of its 16 cycles);
+//     their memory latency is hidden by not being on the consumers' path at all.
+//   * both operand images are double-buffered in LDS (2 x (39 KB patch + 37 KB weights) = 152 KB): ONE workgroup
+//     barrier per phase (phase = one 16-channel chunk, all 9 taps), and the phase sequence runs on across tile
+//     boundaries, so tiles have no head or tail.
+// Arithmetic, operand order inside a K-step, accumulator layout and the fused epilogue are those of
+// conv_f16x3_kernel (lo*hi + hi*lo + hi*hi per K = 32 step = two taps x 16 channels): results are bit-identical to
+// it. The odd ninth tap is paired with a zeroed B fragment.
+#include "conv_f16x3_kernel.h"
+
+namespace lssvc {
+
+constexpr int kP3Threads = 512;
+constexpr int kP3Consumers = 4;          // waves 0..3
+constexpr int kP3ProducerThreads = kP3Threads - 64 * kP3Consumers;
+
+template <int MF>
+struct P3Geom {
+    static constexpr int RPW = 8, TH = RPW * kP3Consumers, TM = 16 * MF;
+    static constexpr int PH = TH + 2, PW = 18, NTAP = 9, NSTEP = 5;
+    static constexpr int PATCH_HALFS = PH * PW * CK16;            // per plane
+    static constexpr int PATCH_ITEMS = PH * PW * 4;               // float4 items
+    static constexpr int NP = (PATCH_ITEMS + kP3ProducerThreads - 1) / kP3ProducerThreads;
+    static constexpr int W_HALFS = NTAP * TM * CK16;              // per plane
+    static constexpr int W_ITEMS = NTAP * TM * 2;                 // 16-byte items per plane
+    static constexpr int W_INSTR = 2 * W_ITEMS / 64;              // wave-level DMA instructions for both planes (= 9 MF)
+    static constexpr int NPROD = kP3ProducerThreads / 64;
+    static constexpr int NDMA = (W_INSTR + NPROD - 1) / NPROD;
+    static constexpr int LDS_BYTES = 2 * (2 * PATCH_HALFS + 2 * W_HALFS) * 2;
+};
+
+struct P3Phase {
+    int it;        // index into this workgroup's tile sequence
+    KState k;      // segment / channel offset / global chunk index of the phase
+};
+
+template <int MF>
+__global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP p) {
+    using G = P3Geom<MF>;
+    constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP, NP = G::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16 *const patch0 = reinterpret_cast<_Float16 *>(smem);                    // [buf][plane][PH*PW][16]
+    _Float16 *const wts0 = patch0 + 4 * G::PATCH_HALFS;                             // [buf][plane][tap][m][16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    // ---- this workgroup's tiles: the XCD it runs on owns a contiguous range, its workgroups interleave inside it
+    const int ntiles = p.tiles_x * p.tiles_y * p.m_tiles;
+    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
+    const int nb_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_cnt = tq + (xcd < tr ? 1 : 0);
+    const int n_it = kb < t_cnt ? (t_cnt - kb + nb_x - 1) / nb_x : 0;
+    if (n_it == 0) return;
+    const int phases_per_tile = p.n_chunks16;
+
+    auto tile_origin = [&](int it, int &oy0, int &ox0, int &m0) {
+        const int tile = t_begin + kb + it * nb_x;
+        const int mt = tile % p.m_tiles, pt = tile / p.m_tiles;
+        const int tx = pt % p.tiles_x, ty = pt / p.tiles_x;
+        oy0 = ty * G::TH;
+        ox0 = tx * 16;
+        m0 = mt * TM;
+    };
+
+    if (wave >= kP3Consumers) {
+        // =================================================================================== PRODUCER waves
+        const int lt = tid - 64 * kP3Consumers;                   // 0 .. 255
+        const int pw = wave - kP3Consumers;
+        const int quad4 = (lt & 3) * 4;
+        const float in_slope = p.in_act == LSSVC_INACT_LRELU ? p.in_slope : 1.0f;
+        const int Hin = p.in[0].H, Win = p.in[0].W;
+        const _Float16 *w16 = reinterpret_cast<const _Float16 *>(p.w16);
+
+        auto next_phase = [&](P3Phase ph) {
+            ph.k.c0 += CK16;
+            ++ph.k.kc;
+            if (ph.k.c0 >= p.in[ph.k.seg].C) {
+                ph.k.c0 = 0;
+                ++ph.k.seg;
+                if (ph.k.seg >= p.n_in) {
+                    ph.k = KState{0, 0, 0, 0};
+                    ++ph.it;
+                }
+            }
+            return ph;
+        };
+        // everything one phase needs, into LDS buffer `buf`: weights by DMA, patch through registers
+        auto fill = [&](const P3Phase &ph, int buf) {
+            int oy0, ox0, m0;
+            tile_origin(ph.it, oy0, ox0, m0);
+            if (!(p.debug & 1)) {
+                unsigned char *dst = reinterpret_cast<unsigned char *>(wts0 + buf * 2 * G::W_HALFS);
+                const size_t chunk_base = (size_t)ph.k.kc * NTAP * p.M_pad * CK16;
+#pragma unroll
+                for (int t = 0; t < G::NDMA; ++t) {
+                    int j = pw + G::NPROD * t;                       // wave-uniform DMA instruction index
+                    if (j >= G::W_INSTR) j = G::W_INSTR - 1;         // surplus slots rewrite the last KiB with the same bytes
+                    const int i = j * 64 + lane;                     // 16-byte item of the [hi plane | lo plane] image
+                    const int plane = i >= G::W_ITEMS ? 1 : 0;
+                    const int r = i - plane * G::W_ITEMS;
+                    const int tap = r / (2 * TM);
+                    const int rr = r - tap * 2 * TM;
+                    int m = m0 + (rr >> 1);
+                    if (m >= p.M_pad) m = p.M_pad - 1;               // rows past M_pad: any finite weights, masked by the epilogue
+                    const _Float16 *src = w16 + (size_t)plane * p.w16_plane + chunk_base + ((size_t)tap * p.M_pad + m) * CK16 + (rr & 1) * 8;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+                }
+            }
+            if (p.debug & 2) return;
+            const V X = p.in[ph.k.seg];
+            const int cleft = X.C - ph.k.c0;
+            const int cc = quad4 < cleft ? ph.k.c0 + quad4 : 0;
+            float4 preg[NP];
+            unsigned pmask = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int idx = lt + i * kP3ProducerThreads;
+                const int pix = idx >> 2;
+                const int py = pix / PW, px = pix - py * PW;
+                const int gy = oy0 - p.pad_t + py, gx = ox0 - p.pad_l + px;
+                const bool ok = idx < G::PATCH_ITEMS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win && quad4 < cleft;
+                const size_t off = ok ? (size_t)(gy * Win + gx) * X.ld + cc : 0;
+                preg[i] = *reinterpret_cast<const float4 *>(X.p + off);
+                pmask |= ok ? (1u << i) : 0u;
+            }
+            _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;
+            _Float16 *pl_ = ph_ + G::PATCH_HALFS;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int idx = lt + i * kP3ProducerThreads;
+                const bool live = (pmask >> i) & 1u;
+                const float raw[4] = {preg[i].x, preg[i].y, preg[i].z, preg[i].w};
+                f16x4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = live ? raw[j] : 0.f;
+                    x = fmaxf(x, 0.f) + in_slope * fminf(x, 0.f);             // LeakyReLU (slope 1 = none), branch-free, exact
+                    x = fminf(fmaxf(x, -65504.f), 65504.f);
+                    h[j] = (_Float16)x;
+                    l[j] = (_Float16)(x - (float)h[j]);
+                }
+                const int o = (idx >> 2) * CK16 + quad4;
+                if (i + 1 < NP || idx < G::PATCH_ITEMS) {
+                    *reinterpret_cast<f16x4 *>(ph_ + o) = h;
+                    *reinterpret_cast<f16x4 *>(pl_ + o) = l;
+                }
+            }
+        };
+
+        P3Phase ph{0, KState{0, 0, 0, 0}};
+        fill(ph, 0);
+        __syncthreads();                                   // (A) phase 0 is in buffer 0
+        const int total = n_it * phases_per_tile;
+        for (int k = 0; k < total; ++k) {
+            if (k + 1 < total) {
+                ph = next_phase(ph);
+                fill(ph, (k + 1) & 1);                     // the consumers read buffer k & 1 meanwhile
+            }
+            __syncthreads();                               // (B_k) buffer (k+1)&1 complete, buffer k&1 released
+        }
+        return;
+    }
+
+    // ======================================================================================= CONSUMER waves
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+    const int tsel = lg >> 1;
+    const int ch8 = (lg & 1) * 8;
+
+    f32x4 acc[MF][RPW];
+#pragma unroll
+    for (int a = 0; a < MF; ++a)
+#pragma unroll
+        for (int b = 0; b < RPW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                                       // (A)
+    int it = 0, kt = 0;                                    // tile index in this workgroup's sequence, phase inside the tile
+    const int total = n_it * phases_per_tile;
+    for (int k = 0; k < total; ++k) {
+        const int buf = k & 1;
+        const _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;
+        const _Float16 *pl_ = ph_ + G::PATCH_HALFS;
+        const _Float16 *wh_ = wts0 + buf * 2 * G::W_HALFS;
+        const _Float16 *wl_ = wh_ + G::W_HALFS;
+#pragma unroll
+        for (int u = 0; u < NSTEP; ++u) {
+            const bool pad_step = 2 * u + 1 >= NTAP;                         // the ninth tap has no partner
+            const int tap = pad_step ? 2 * u : 2 * u + tsel;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            f16x8 ah[MF], al[MF];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int o = (tap * TM + f * 16 + li) * CK16 + ch8;
+                ah[f] = *reinterpret_cast<const f16x8 *>(wh_ + o);
+                al[f] = *reinterpret_cast<const f16x8 *>(wl_ + o);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f16x8 bh[4], bl[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wave * RPW + half * 4 + r;
+                    const int o = ((row + ky) * PW + li + kx) * CK16 + ch8;
+                    bh[r] = *reinterpret_cast<const f16x8 *>(ph_ + o);
+                    bl[r] = *reinterpret_cast<const f16x8 *>(pl_ + o);
+                    if (pad_step && tsel) {
+                        bh[r] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        bl[r] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[f][half * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][half * 4 + r], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[f][half * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][half * 4 + r], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[f][half * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][half * 4 + r], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // (B_k)
+        if (++kt == phases_per_tile) {
+            int oy0, ox0, m0;
+            tile_origin(it, oy0, ox0, m0);
+            if (!(p.debug & 32)) {
+                conv_unscale<MF, RPW>(p, acc);
+                // two passes of 4 rows: keeps the epilogue's prefetch registers + the 128 accumulators under the cap
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f32x4 part[MF][4];
+#pragma unroll
+                    for (int f = 0; f < MF; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[f][r] = acc[f][half * 4 + r];
+                    long long pix[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int oy = oy0 + wave * RPW + half * 4 + r, ox = ox0 + li;
+                        pix[r] = (oy < p.Hout && ox < p.Wout) ? (long long)oy * p.Wout + ox : -1;
+                    }
+                    conv_epilogue_fast<MF, 4>(p, part, pix, m0, lg);       // the dispatcher only sends p.fast_epi convs here
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < MF; ++a)
+#pragma unroll
+                for (int b = 0; b < RPW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            ++it;
+        }
+    }
+}
+
+template <int MF>
+static int launch_p3(const ConvP &p, hipStream_t st) {
+    using G = P3Geom<MF>;
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+        return 256;
+    }();
+    static bool attr_set = false;
+    if (!attr_set) {
+        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr_set = true;
+    }
+    ConvP q = p;
+    q.tiles_x = (p.Wout + 15) / 16;
+    q.tiles_y = (p.Hout + G::TH - 1) / G::TH;
+    q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
+    const long long ntiles = (long long)q.tiles_x * q.tiles_y * q.m_tiles;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) return fail("conv2d(f16x3p): bad tile count %lld", ntiles);
+    long long blocks = cus;                       // one persistent 8-wave workgroup per CU
+    if (blocks > ntiles) blocks = ntiles;
+    hipLaunchKernelGGL((conv3_f16x3p_kernel<MF>), dim3((unsigned)blocks), dim3(kP3Threads), G::LDS_BYTES, st, q);
+    return launch_status("conv2d(f16x3p)");
+}
+
+static int p3_pick_mf(int frags) {
+    if (frags > 4 && frags % 4 != 0 && frags % 3 == 0) return 3;        // e.g. 96 = 2 x 48 rather than 64 + 32
+    return frags >= 4 ? 4 : frags;
+}
+
+// Worth it only when every CU gets several tiles (otherwise the 32-row tiles quantise badly and there is nothing
+// to pipeline across).
+bool conv3_f16x3p_wanted(const ConvP &p) {
+    static const int on = getenv("LSSVC_F16X3_PERSIST") ? atoi(getenv("LSSVC_F16X3_PERSIST")) : 1;
+    static const int min_tiles = getenv("LSSVC_F16X3_PERSIST_MIN_TILES") ? atoi(getenv("LSSVC_F16X3_PERSIST_MIN_TILES")) : 1024;
+    if (!on || !p.fast_epi) return false;
+    const int mf = p3_pick_mf(p.M_pad / 16);
+    const long long ntiles = (long long)((p.Wout + 15) / 16) * ((p.Hout + 31) / 32) * ((p.M_pad / 16 + mf - 1) / mf);
+    return ntiles >= min_tiles;
+}
+
+int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
+    const int mf = p3_pick_mf(p.M_pad / 16);
+    snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d>", mf);
+    if (mf == 4) return launch_p3<4>(p, st);
+    if (mf == 3) return launch_p3<3>(p, st);
+    if (mf == 2) return launch_p3<2>(p, st);
+    return launch_p3<1>(p, st);
+}
+
+}  // namespace lssvc

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
     while (true) {
         const KState nxt = advance(cur);
         const bool more = nxt.seg < p.n_in;
-        if (more) {
+        if (more && !(p.debug & 1)) {
             load_w(nxt);
             if (nxt.ky == 0) load_patch(nxt);
         }
@@ -201,16 +201,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
             const int ry = tap_b / KS, kx = tap_b - ry * KS;
             const int ky = cur.ky + ry;
             f16x8 ah[MF], al[MF], bh[RPW], bl[RPW];
+            const int dbg_u = (p.debug & 16) ? 0 : 1;          // ablation: every step re-reads step 0's fragments
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                const int o = (tap_w * TM + f * 16 + li) * CK16 + ch8;
+                const int o = dbg_u * (tap_w * TM + f * 16 + li) * CK16 + ch8;
                 ah[f] = *reinterpret_cast<const f16x8 *>(wts_h + o);
                 al[f] = *reinterpret_cast<const f16x8 *>(wts_l + o);
             }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int row = wave * RPW + r;
-                const int o = ((row * S + ky) * PW + li * S + kx) * CK16 + ch8;
+                const int o = dbg_u * ((row * S + ky) * PW + li * S + kx) * CK16 + ch8;
                 bh[r] = *reinterpret_cast<const f16x8 *>(patch_h + o);
                 bl[r] = *reinterpret_cast<const f16x8 *>(patch_l + o);
             }
@@ -231,14 +232,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
                     acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][r], 0, 0, 0);
         }
         if (!more) break;
-        __syncthreads();
-        if (nxt.ky == 0) store_patch();
-        store_w();
-        __syncthreads();
+        if (!(p.debug & 4)) __syncthreads();
+        if (!(p.debug & 2)) {
+            if (nxt.ky == 0) store_patch();
+            store_w();
+        }
+        if (!(p.debug & 4)) __syncthreads();
         cur = nxt;
     }
+    if (p.debug & 32) return;
     conv_unscale<MF, RPW>(p, acc);
-    conv_epilogue<MF, RPW>(p, acc, oy0, ox0, m0, wave, li, lg);
+    conv_epilogue<MF, RPW, false>(p, acc, oy0, ox0, m0, wave, li, lg);
 }
 
 template <int MF, int RPW, int KS, int S>
@@ -265,6 +269,10 @@ int dispatch_tile_f16x3(const ConvP &p, int MF, int RPW, hipStream_t st) {
 #undef LSSVC_CONV_CASE
     return fail("conv2d(f16x3): no kernel for MF=%d RPW=%d", MF, RPW);
 }
+
+// persistent double-buffered 3x3 variant for large images (conv3_f16x3p.hip)
+bool conv3_f16x3p_wanted(const ConvP &p);
+int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
 
 extern template int dispatch_tile_f16x3<3, 1>(const ConvP &, int, int, hipStream_t);
 extern template int dispatch_tile_f16x3<7, 1>(const ConvP &, int, int, hipStream_t);

@@ -117,6 +117,11 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     } else {
         p.gdn_x = mk_null();
     }
+    {
+        static const int fast_on = getenv("LSSVC_FAST_EPI") ? atoi(getenv("LSSVC_FAST_EPI")) : 1;
+        p.fast_epi = fast_on && d->epilogue == LSSVC_EPI_NONE && !d->pixel_shuffle && (d->Cout % 4 == 0) && p.out_vec &&
+                     (!d->residual.ptr || p.res_vec);
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     {
         static const int dbg = getenv("LSSVC_CONV_DEBUG") ? atoi(getenv("LSSVC_CONV_DEBUG")) : 0;
@@ -140,6 +145,7 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         p.w16 = d->weight16;
         p.w16_unscale = d->weight16_unscale != 0.0f ? d->weight16_unscale : 1.0f;
         p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
+        if (vec && sd == 1 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3_f16x3p_wanted(p)) return dispatch_conv3_f16x3p(p, st, kname);
         if (vec && sd == 1 && (ks == 3 || ks == 7)) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, %d, 1>", MF, RPW, ks);
             return ks == 3 ? dispatch_tile_f16x3<3, 1>(p, MF, RPW, st) : dispatch_tile_f16x3<7, 1>(p, MF, RPW, st);

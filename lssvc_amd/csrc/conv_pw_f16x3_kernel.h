@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, RPW == 1 ? 4 : 2) void conv_pw_f16x3_kernel(co
             }
         }
         conv_unscale<MF, RPW>(p, acc);
-        conv_epilogue_flat<MF, RPW>(p, acc, pix, m0, lg);
+        conv_epilogue_flat<MF, RPW, false>(p, acc, pix, m0, lg);
     }
 }
 
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_allm_f16x3_kernel(const ConvP 
                 }
             }
             conv_unscale<MF, RPW>(p, acc);
-            conv_epilogue_flat<MF, RPW>(p, acc, pix, mt * TM, lg);
+            conv_epilogue_flat<MF, RPW, false>(p, acc, pix, mt * TM, lg);
         }
     }
 }
