@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = live ? raw[j] : 0.f;
-                    x = fmaxf(x, 0.f) + in_slope * fminf(x, 0.f);             // LeakyReLU (slope 1 = none), branch-free, exact
+                    x = fmaxf(x, in_slope * x);                               // LeakyReLU for 0 <= slope <= 1 (1 = none): exact
                     x = fminf(fmaxf(x, -65504.f), 65504.f);
                     h[j] = (_Float16)x;
                     l[j] = (_Float16)(x - (float)h[j]);
@@ -249,7 +249,6 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             int oy0, ox0, m0;
             tile_origin(it, oy0, ox0, m0);
             if (!(p.debug & 32)) {
-                conv_unscale<MF, RPW>(p, acc);
                 // two passes of 4 rows: keeps the epilogue's prefetch registers + the 128 accumulators under the cap
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                         const int oy = oy0 + wave * RPW + half * 4 + r, ox = ox0 + li;
                         pix[r] = (oy < p.Hout && ox < p.Wout) ? (long long)oy * p.Wout + ox : -1;
                     }
-                    conv_epilogue_fast<MF, 4>(p, part, pix, m0, lg);       // the dispatcher only sends p.fast_epi convs here
+                    conv_epilogue_fast<MF, 4>(p, part, pix, m0, lg, p.w16_unscale);       // the dispatcher only sends p.fast_epi convs here
                 }
             }
 #pragma unroll
@@ -313,6 +312,7 @@ bool conv3_f16x3p_wanted(const ConvP &p) {
     static const int on = getenv("LSSVC_F16X3_PERSIST") ? atoi(getenv("LSSVC_F16X3_PERSIST")) : 1;
     static const int min_tiles = getenv("LSSVC_F16X3_PERSIST_MIN_TILES") ? atoi(getenv("LSSVC_F16X3_PERSIST_MIN_TILES")) : 1024;
     if (!on || !p.fast_epi) return false;
+    if (p.in_act == LSSVC_INACT_LRELU && !(p.in_slope >= 0.0f && p.in_slope <= 1.0f)) return false;   // max(x, s*x) form
     const int mf = p3_pick_mf(p.M_pad / 16);
     const long long ntiles = (long long)((p.Wout + 15) / 16) * ((p.Hout + 31) / 32) * ((p.M_pad / 16 + mf - 1) / mf);
     return ntiles >= min_tiles;

@@ -120,7 +120,8 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     {
         static const int fast_on = getenv("LSSVC_FAST_EPI") ? atoi(getenv("LSSVC_FAST_EPI")) : 1;
         p.fast_epi = fast_on && d->epilogue == LSSVC_EPI_NONE && !d->pixel_shuffle && (d->Cout % 4 == 0) && p.out_vec &&
-                     (!d->residual.ptr || p.res_vec);
+                     (!d->residual.ptr || p.res_vec) &&
+                     (d->act != LSSVC_ACT_LRELU || (d->slope >= 0.0f && d->slope <= 1.0f));
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     {

@@ -51,25 +51,28 @@ __device__ __forceinline__ void conv_unscale(const ConvP &p, f32x4 (&acc)[MF][RP
         for (int r = 0; r < RPW; ++r) acc[f][r] *= p.w16_unscale;
 }
 
-// Memory-op ordering matters here: on gfx9/CDNA loads and stores share the vmcnt counter, so a wait for a load that
-// was issued AFTER a store also waits for that store's acknowledgement. The bias is therefore loaded once up front,
-// and the side inputs of row r+1 (GDN's x, the residual) are issued BEFORE row r's stores: every wait then names
-// only loads that are older than all stores in flight, and the stores of a tile stream out back to back
-// (measured on the persistent 3x3 kernel: 530 ns per store instruction before, i.e. one full round trip each).
-// Straight-line epilogue for the common case (p.fast_epi): bias -> activation -> residual -> scale -> float4 store.
-// No scalar fallbacks, so no branches for the compiler to hang conservative waits on. LeakyReLU / ReLU / none are
-// one formula, max(v,0) + s*min(v,0) with s = slope / 0 / 1 (exact: one of the two terms is always 0).
+// Straight-line epilogue for the common case (p.fast_epi): unscale -> bias -> activation -> residual -> scale -> float4
+// store. No scalar fallbacks, so no branches for the compiler to hang conservative waits on, and the arithmetic is
+// written on 2-wide vectors so that it compiles to v_pk_mul_f32 / v_pk_add_f32 (the epilogue is VALU-bound on the
+// kernels that keep 128 accumulators per wave). LeakyReLU / ReLU / none are one formula, max(v, s*v) with
+// s = slope / 0 / 1: exact for 0 <= s <= 1 (the host only sets fast_epi then). `unscale` is the f16x3 weight
+// prescale (1 for the fp32 kernels); multiplying by a power of two and by 1.0f is exact.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int MF, int RPW>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
-                                                   int lg) {
+                                                   int lg, float unscale = 1.0f) {
     const float s_neg = p.act == LSSVC_ACT_LRELU ? p.slope : (p.act == LSSVC_ACT_RELU ? 0.0f : 1.0f);
     const bool has_res = p.res.p != nullptr;
-    float4 bb[MF];
+    const f32x2 us = {unscale, unscale}, sn = {s_neg, s_neg}, os = {p.out_scale, p.out_scale};
+    f32x2 bb[MF][2];
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
         const int mb = m0 + f * 16 + 4 * lg;
-        bb[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && mb < p.Cout) bb[f] = *reinterpret_cast<const float4 *>(p.bias + mb);
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && mb < p.Cout && !(p.debug & 128)) t = *reinterpret_cast<const float4 *>(p.bias + mb);
+        bb[f][0] = f32x2{t.x, t.y};
+        bb[f][1] = f32x2{t.z, t.w};
     }
     float4 rs[2][MF];
     auto load_res = [&](int r, float4 (&d)[MF]) {
@@ -84,19 +87,28 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         if (r + 1 < RPW) load_res(r + 1, rs[(r + 1) & 1]);      // issued before row r's stores (see conv_epilogue_flat)
+        float *orow = p.out.p + (size_t)(pix[r] >= 0 ? pix[r] : 0) * p.out.ld + m0 + 4 * lg;
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const int mb = m0 + f * 16 + 4 * lg;
-            float v[4] = {acc[f][r][0] + bb[f].x, acc[f][r][1] + bb[f].y, acc[f][r][2] + bb[f].z, acc[f][r][3] + bb[f].w};
-            const float q[4] = {rs[r & 1][f].x, rs[r & 1][f].y, rs[r & 1][f].z, rs[r & 1][f].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ((fmaxf(v[j], 0.f) + s_neg * fminf(v[j], 0.f)) + q[j]) * p.out_scale;
-            if (pix[r] >= 0 && mb < p.Cout)
-                *reinterpret_cast<float4 *>(p.out.p + (size_t)pix[r] * p.out.ld + mb) = make_float4(v[0], v[1], v[2], v[3]);
+            f32x2 v0 = f32x2{acc[f][r][0], acc[f][r][1]} * us + bb[f][0];
+            f32x2 v1 = f32x2{acc[f][r][2], acc[f][r][3]} * us + bb[f][1];
+            const f32x2 n0 = v0 * sn, n1 = v1 * sn;
+            v0 = f32x2{fmaxf(v0.x, n0.x), fmaxf(v0.y, n0.y)};
+            v1 = f32x2{fmaxf(v1.x, n1.x), fmaxf(v1.y, n1.y)};
+            v0 = (v0 + f32x2{rs[r & 1][f].x, rs[r & 1][f].y}) * os;
+            v1 = (v1 + f32x2{rs[r & 1][f].z, rs[r & 1][f].w}) * os;
+            if (pix[r] >= 0 && mb < p.Cout && (!(p.debug & 64) || v0.x == 1.2345f))   // debug 64: perf ablation, stores off
+                *reinterpret_cast<float4 *>(orow + f * 16) = make_float4(v0.x, v0.y, v1.x, v1.y);
         }
     }
 }
 
+// Memory-op ordering matters here: on gfx9/CDNA loads and stores share the vmcnt counter, so a wait for a load that
+// was issued AFTER a store also waits for that store's acknowledgement. The bias is therefore loaded once up front,
+// and the side inputs of row r+1 (GDN's x, the residual) are issued BEFORE row r's stores: every wait then names
+// only loads that are older than all stores in flight, and the stores of a tile stream out back to back
+// (measured on the persistent 3x3 kernel: 530 ns per store instruction before, i.e. one full round trip each).
 template <int MF>
 struct EpiSide {
     float4 g[MF];     // GDN input x
