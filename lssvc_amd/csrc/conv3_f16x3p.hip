@@ -306,11 +306,11 @@ static int p3_pick_mf(int frags) {
     return frags >= 4 ? 4 : frags;
 }
 
-// Worth it only when every CU gets several tiles (otherwise the 32-row tiles quantise badly and there is nothing
-// to pipeline across).
+// Worth it once every CU gets at least one 32x16 tile (measured on the bench workload: thresholds 256 / 512 / 1024 /
+// 2048 tiles give 14.0 / 13.9 / 13.6 / 13.5 frames/s).
 bool conv3_f16x3p_wanted(const ConvP &p) {
     static const int on = getenv("LSSVC_F16X3_PERSIST") ? atoi(getenv("LSSVC_F16X3_PERSIST")) : 1;
-    static const int min_tiles = getenv("LSSVC_F16X3_PERSIST_MIN_TILES") ? atoi(getenv("LSSVC_F16X3_PERSIST_MIN_TILES")) : 1024;
+    static const int min_tiles = getenv("LSSVC_F16X3_PERSIST_MIN_TILES") ? atoi(getenv("LSSVC_F16X3_PERSIST_MIN_TILES")) : 256;
     if (!on || !p.fast_epi) return false;
     if (p.in_act == LSSVC_INACT_LRELU && !(p.in_slope >= 0.0f && p.in_slope <= 1.0f)) return false;   // max(x, s*x) form
     const int mf = p3_pick_mf(p.M_pad / 16);

@@ -119,9 +119,11 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     }
     {
         static const int fast_on = getenv("LSSVC_FAST_EPI") ? atoi(getenv("LSSVC_FAST_EPI")) : 1;
-        p.fast_epi = fast_on && d->epilogue == LSSVC_EPI_NONE && !d->pixel_shuffle && (d->Cout % 4 == 0) && p.out_vec &&
-                     (!d->residual.ptr || p.res_vec) &&
-                     (d->act != LSSVC_ACT_LRELU || (d->slope >= 0.0f && d->slope <= 1.0f));
+        const bool common = fast_on && d->epilogue == LSSVC_EPI_NONE && (d->Cout % 4 == 0) && p.out_vec &&
+                            (d->act != LSSVC_ACT_LRELU || (d->slope >= 0.0f && d->slope <= 1.0f));
+        p.fast_epi = 0;
+        if (common && !d->pixel_shuffle && (!d->residual.ptr || p.res_vec)) p.fast_epi = 1;
+        if (common && d->pixel_shuffle && !d->residual.ptr && (d->Cout % 16 == 0)) p.fast_epi = 2;   // cps % 4 == 0
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     {

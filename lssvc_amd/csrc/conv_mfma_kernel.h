@@ -74,6 +74,18 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
         bb[f][0] = f32x2{t.x, t.y};
         bb[f][1] = f32x2{t.z, t.w};
     }
+    // pixel-shuffle store (fast_epi == 2): channel m = q*cps + c goes to sub-pixel q = dy*2+dx, channel c (the host
+    // permuted the weights so); a lane's 4 channels never straddle q because cps % 4 == 0
+    int ps_off[MF];
+    if (p.fast_epi == 2) {
+        const int cps = p.Cout >> 2;
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int mb = m0 + f * 16 + 4 * lg;
+            const int q = mb / cps, c = mb - q * cps;
+            ps_off[f] = ((q >> 1) * p.out.W + (q & 1)) * p.out.ld + c;      // < 2 * W * ld: fits int
+        }
+    }
     float4 rs[2][MF];
     auto load_res = [&](int r, float4 (&d)[MF]) {
 #pragma unroll
@@ -87,7 +99,13 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         if (r + 1 < RPW) load_res(r + 1, rs[(r + 1) & 1]);      // issued before row r's stores (see conv_epilogue_flat)
-        float *orow = p.out.p + (size_t)(pix[r] >= 0 ? pix[r] : 0) * p.out.ld + m0 + 4 * lg;
+        const size_t opix = (size_t)(pix[r] >= 0 ? pix[r] : 0);
+        float *orow = p.out.p + opix * p.out.ld + m0 + 4 * lg;
+        float *srow = nullptr;                                   // pixel-shuffle: the 2x2 output block of this conv pixel
+        if (p.fast_epi == 2) {
+            const int oy = (int)(opix / p.Wout), ox = (int)(opix - (size_t)oy * p.Wout);
+            srow = p.out.p + ((size_t)(2 * oy) * p.out.W + 2 * ox) * p.out.ld;
+        }
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const int mb = m0 + f * 16 + 4 * lg;
@@ -98,8 +116,10 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
             v1 = f32x2{fmaxf(v1.x, n1.x), fmaxf(v1.y, n1.y)};
             v0 = (v0 + f32x2{rs[r & 1][f].x, rs[r & 1][f].y}) * os;
             v1 = (v1 + f32x2{rs[r & 1][f].z, rs[r & 1][f].w}) * os;
+            float *dst = orow + f * 16;
+            if (p.fast_epi == 2) dst = srow + ps_off[f];
             if (pix[r] >= 0 && mb < p.Cout && (!(p.debug & 64) || v0.x == 1.2345f))   // debug 64: perf ablation, stores off
-                *reinterpret_cast<float4 *>(orow + f * 16) = make_float4(v0.x, v0.y, v1.x, v1.y);
+                *reinterpret_cast<float4 *>(dst) = make_float4(v0.x, v0.y, v1.x, v1.y);
         }
     }
 }
