@@ -8,10 +8,17 @@ int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name) {
     const int frags = p.M_pad / 16;
     const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
     int mf_fit = kPwMaxLds / (nslot * 1024);          // each 16-channel M fragment costs nslot KiB of LDS (hi + lo planes)
-    if (mf_fit < 1) return fail("conv2d(pw f16x3): Cin too large for the LDS-resident weight tile");
+    if (mf_fit < 1 && kPwBigLds / (nslot * 1024) < 1) return fail("conv2d(pw f16x3): Cin too large for the LDS-resident weight tile");
     int MF = frags < 4 ? frags : 4;
     if (frags % 4 != 0 && frags % 3 == 0) MF = 3;
-    if (MF > mf_fit) MF = mf_fit;
+    if (MF > mf_fit) {
+        // K is large: a bigger M tile (one workgroup per CU, up to 144 KB of weights) halves the re-reads of X from L2
+        static const int big = getenv("LSSVC_PW_BIG_LDS") ? atoi(getenv("LSSVC_PW_BIG_LDS")) : 0;   // measured neutral on the bench workload
+        const int mf_big = kPwBigLds / (nslot * 1024);
+        int want = MF;
+        MF = mf_fit;
+        if (big && mf_big > mf_fit) MF = mf_big < want ? mf_big : want;
+    }
     static const int allm = getenv("LSSVC_PW_ALLM") ? atoi(getenv("LSSVC_PW_ALLM")) : 1;
     {   // small K and the whole weight matrix in LDS: convert the pixels once, loop the M tiles inside the wave
         int mf = frags < 4 ? frags : 4;

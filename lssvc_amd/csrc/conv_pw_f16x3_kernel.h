@@ -20,7 +20,8 @@
 
 namespace lssvc {
 
-constexpr int kPwMaxLds = 64 * 1024;
+constexpr int kPwMaxLds = 64 * 1024;      // two workgroups per CU
+constexpr int kPwBigLds = 144 * 1024;     // one workgroup per CU: taken when it buys a larger M tile (fewer re-reads of X)
 
 template <int MF, int RPW>
 __global__ __launch_bounds__(256, RPW == 1 ? 4 : 2) void conv_pw_f16x3_kernel(const ConvP p) {
@@ -172,7 +173,12 @@ static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
     q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
     const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
     const size_t lds = (size_t)2 * nslot * 16 * MF * CK16 * sizeof(_Float16);
-    if (lds > (size_t)kPwMaxLds) return fail("conv2d(pw f16x3): %zu bytes of weights do not fit LDS", lds);
+    if (lds > (size_t)kPwBigLds) return fail("conv2d(pw f16x3): %zu bytes of weights do not fit LDS", lds);
+    static size_t granted = 64 * 1024;
+    if (lds > granted) {
+        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pw_f16x3_kernel<MF, RPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted = lds;
+    }
     static const int resident = [] {
         int per_cu = 0, dev = 0, cus = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_pw_f16x3_kernel<MF, RPW>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -185,7 +191,9 @@ static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
     const long long npix = (long long)p.Hout * p.Wout;
     const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
     long long per_m = (ngroups + 3) / 4;                                    // workgroups that have work, per M tile
-    const long long cap = resident / q.m_tiles > 0 ? resident / q.m_tiles : 1;
+    long long res = resident;
+    if (lds > (size_t)kPwMaxLds) res = resident / 2 > 0 ? resident / 2 : 1;     // one workgroup per CU fits
+    const long long cap = res / q.m_tiles > 0 ? res / q.m_tiles : 1;
     if (per_m > cap) per_m = cap;
     const long long blocks = per_m * q.m_tiles;
     hipLaunchKernelGGL((conv_pw_f16x3_kernel<MF, RPW>), dim3((unsigned)blocks), dim3(256), lds, st, q);
