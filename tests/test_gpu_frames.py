@@ -117,3 +117,27 @@ def test_gop_drift_vs_oracle(precision):
             assert abs(g["bit_el"] - o["bit_el"]) / (H * W) <= 1e-5, (t, g["bit_el"], o["bit_el"])
             assert abs(psnr(xe, dg["ref_frame_el"].cpu()) - psnr(xe, do["ref_frame_el"])) <= 1e-4, t
             assert abs(psnr(xb, dg["ref_frame_bl"].cpu()) - psnr(xb, do["ref_frame_bl"])) <= 1e-4, t
+
+
+def test_config1_single_iframe_256(precision):
+    """BASELINE configs[0] (SURVEY 8d "Config 1"): IntraSS, one 256x256 frame, x2, estimate mode, the reference's own
+    CPU-runnable case: x_el = rand(1,3,256,256) under manual_seed(0), x_bl = bicubic(x_el, 128x128).clamp(0,1).
+    GPU against the CPU oracle on the same tensors: |dbpp| <= 1e-5, |dPSNR| <= 1e-4 dB."""
+    from lssvc_amd import IntraSS
+    from lssvc_amd.preprocess import imresize_bicubic, psnr
+    from lssvc_amd.synth import synth_state_dict
+    from lssvc_oracle.intra import intra_forward
+    torch.manual_seed(0)
+    x_el = torch.rand(1, 3, 256, 256)
+    x_bl = imresize_bicubic(x_el, (128, 128)).clamp_(0, 1)
+    sd = synth_state_dict("intra_ss", 0, 0.6)
+    with torch.no_grad():
+        want = intra_forward(sd, x_bl, x_el, (256, 256))
+    net = IntraSS.from_state_dict(sd).to(DEV).eval()
+    net.set_scale_information(2.0, (256, 256), (0, 0, 0, 0))
+    got = net.encode_decode(x_bl.to(DEV), x_el.to(DEV), None, None, 128, 128, 256, 256)
+    assert abs(got["bit_bl"] - want["bit_bl"]) / (128 * 128) <= 1e-5 and abs(got["bit_el"] - want["bit_el"]) / (256 * 256) <= 1e-5
+    for k, x in (("x_hat_bl", x_bl), ("x_hat_el", x_el)):
+        g, w = got[k].cpu().clamp(0, 1), want[k].clamp(0, 1)
+        assert abs(psnr(x, g) - psnr(x, w)) <= 1e-4
+        np.testing.assert_allclose(got[k].cpu().numpy(), want[k].numpy(), atol=2e-4, rtol=0)

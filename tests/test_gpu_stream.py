@@ -39,7 +39,8 @@ def _check_rate(bits, est):
     assert abs(bits - est) <= 0.25 * est + 512, (bits, est)
 
 
-@pytest.mark.parametrize("H,W,gain,frames", [(128, 128, 0.6, 3), (128, 256, 0.65, 2), (1152, 1920, 0.55, 2)])
+@pytest.mark.parametrize("H,W,gain,frames", [(128, 128, 0.6, 3), (128, 256, 0.65, 2), (1152, 1920, 0.55, 2),
+                                                (2176, 3840, 0.55, 2)])     # last: BASELINE configs[3], 2160p padded
 def test_stream_round_trip(tmp_path, H, W, gain, frames):
     inet, pnet = _nets(4, gain)
     x_bl, x_el = _clip(frames, H, W, 4)
