@@ -99,8 +99,9 @@ const char *lssvc_conv2d_last_kernel(void);
 /* The per-pixel tail of a DepthConvBlock in one launch (f16x3 arithmetic; src/models/lssvc_modules.py:15-72):
  *     o1  = pre_w * pre_in + pre_bias + ident      (DepthConv.conv2 + identity/adaptor; skipped when pre_w16 == NULL: o1 = x)
  *     out = o1 + lrelu(w2 * lrelu(w1 * o1 + b1) + b2)                          (ConvFFN, both slopes = `slope`)
- * C = out.C in {32, 48, 64}; hidden %% 32 == 0; pre_in.C %% 8 == 0 and <= 64; all weights must fit the 160 KB LDS
- * (lssvc_ffn_f16x3_lds_bytes). Weight blobs are fp16 [hi plane | lo plane] images of w * 2^e in the fragment
+ * C = out.C in {32, 48, 64, 96, 128}; hidden %% 32 == 0; pre_in.C %% 8 == 0 and <= 128. Up to C = 64 / pre_in.C = 64
+ * with all weights within the 160 KB LDS they stay resident; otherwise the hidden dimension is streamed through LDS in
+ * 32-channel slices by LDS-DMA (lssvc_ffn_f16x3_lds_bytes gives the LDS either way; it must be <= 160 KB). Weight blobs are fp16 [hi plane | lo plane] images of w * 2^e in the fragment
  * order the kernel reads (lssvc_amd/weights.py: layout_ffn_f16x3), *_unscale = 2^-e; biases are fp32, padded to
  * 16*ceil(C/16) (b1: hidden). `out` may alias `x` or `ident`. */
 typedef struct {
@@ -122,6 +123,8 @@ typedef struct {
 } lssvc_ffn_desc;
 int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream);
 int64_t lssvc_ffn_f16x3_lds_bytes(int32_t C, int32_t hidden, int32_t pre_cin);
+/* 1 if lssvc_ffn_f16x3 runs the streamed-weights kernel for this shape (profiling label only). */
+int lssvc_ffn_f16x3_is_streamed(int32_t C, int32_t hidden, int32_t pre_cin);
 
 /* Depthwise 3x3, stride 1, pad 1 (lssvc_modules.py:23-24). weight: [9][C], bias: [C]. */
 int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const float *bias, const lssvc_view *out,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "lssvc_conv2d_last_kernel": (C.c_char_p, []),
     "lssvc_ffn_f16x3": (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
     "lssvc_ffn_f16x3_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "lssvc_ffn_f16x3_is_streamed": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "lssvc_dwconv3x3": (C.c_int, [VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
     "lssvc_resize_bilinear": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
     "lssvc_flow_warp": (C.c_int, [VP, VP, VP, C.c_void_p]),

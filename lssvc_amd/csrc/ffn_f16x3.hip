@@ -16,6 +16,8 @@
 // Workgroup = 8 waves sharing the LDS-resident weights (hi/lo fp16 planes of W_pre, W1, W2 + the fp32 biases; up to
 // 147 KB for C = 64, hidden = 256, i.e. one workgroup per CU), persistent over flat 32-pixel groups; no barrier
 // after the staging. Every product is the 3-term split of the f16x3 mode (lo*hi + hi*lo + hi*hi, fp32 accumulate).
+#include <cstdlib>
+
 #include "common.h"
 #include "conv_f16x3_kernel.h"
 
@@ -278,6 +280,222 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Streamed-weights variant for wider blocks (C up to 128, hidden up to 1024: 2*C*hidden fp16 hi/lo weights are up to
+// 1 MB, far beyond LDS). Same arithmetic and register chaining; what changes is where the FFN weights live: the hidden
+// dimension is walked in slices of 32 channels, and slice t+1 of W1/W2 (4S + 2CF KiB, already in fragment order) is
+// moved global -> LDS by LDS-DMA into the other half of a two-slot ring while slice t is in the matrix pipe; one
+// workgroup barrier per slice. Each wave keeps ONE 16-pixel group (o1, the output accumulators and the C -> hidden B
+// fragments: 96 registers at C = 128) for a whole pass over the hidden dimension, so the weights are re-streamed from
+// L2 once per 128 pixels of a workgroup (4 KB per pixel at C = 128, hidden = 512: about twice the activation bytes).
+// The leading conv's weights (<= 64 KB) stay resident.
+template <int CF, bool PRE>
+__global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const FfnP p) {
+    constexpr int S = (CF + 1) / 2;
+    constexpr int SA_MAX = 4;                        // leading conv: at most 128 input channels
+    constexpr int W1_HALFS = 2 * S * 512, W2_HALFS = CF * 512;          // per plane, per 32-channel hidden slice
+    constexpr int SLICE_HALFS = 2 * W1_HALFS + 2 * W2_HALFS;            // [W1 hi | W1 lo | W2 hi | W2 lo]
+    constexpr int NI = SLICE_HALFS / 512;                               // 1 KiB DMA instructions per slice
+    constexpr int NDMA = (NI + kFfnThreads / 64 - 1) / (kFfnThreads / 64);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16 *ring = reinterpret_cast<_Float16 *>(smem);                // 2 slots
+    _Float16 *wph = ring + 2 * SLICE_HALFS;
+    _Float16 *wpl = wph + p.n_pre;
+    float *b1s = reinterpret_cast<float *>(wpl + p.n_pre);
+    float *b2s = b1s + p.hidden;
+    float *bps = b2s + 16 * CF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+    const int a_off = li * 32 + lg * 8;
+    const int C = p.out.C;
+    const int T = p.hidden >> 5;
+    {
+        if (PRE)
+            for (int i = tid * 8; i < 2 * p.n_pre; i += kFfnThreads * 8)
+                *reinterpret_cast<f16x8 *>(wph + i) = *reinterpret_cast<const f16x8 *>(p.pre_w + i);
+        for (int i = tid; i < p.hidden; i += kFfnThreads) b1s[i] = p.b1[i];
+        for (int i = tid; i < 16 * CF; i += kFfnThreads) {
+            b2s[i] = p.b2[i];
+            if (PRE) bps[i] = p.pre_b[i];
+        }
+    }
+    // one hidden slice -> ring slot: the four pieces are contiguous runs of the host blobs ([hi plane | lo plane])
+    auto issue_slice = [&](int t, int slot) {
+        unsigned char *dst = reinterpret_cast<unsigned char *>(ring + slot * SLICE_HALFS);
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) {
+            int j = wave + (kFfnThreads / 64) * q;          // wave-uniform 1 KiB piece of the slice image
+            if (j >= NI) j = NI - 1;
+            const int h0 = j * 512 + lane * 8;              // first half of this lane's 16 bytes, in slice-image halfs
+            const _Float16 *src;
+            if (h0 < W1_HALFS) src = p.w1 + (size_t)t * W1_HALFS + h0;
+            else if (h0 < 2 * W1_HALFS) src = p.w1 + p.n1 + (size_t)t * W1_HALFS + (h0 - W1_HALFS);
+            else if (h0 < 2 * W1_HALFS + W2_HALFS) src = p.w2 + (size_t)t * W2_HALFS + (h0 - 2 * W1_HALFS);
+            else src = p.w2 + p.n2 + (size_t)t * W2_HALFS + (h0 - 2 * W1_HALFS - W2_HALFS);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+
+    const long long npix = (long long)p.out.H * p.out.W;
+    const long long npass = (npix + 127) / 128;             // 8 waves x 16 pixels
+    const long long my_passes = blockIdx.x < npass ? (npass - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (my_passes == 0) return;
+    const long long total = my_passes * T;
+    issue_slice(0, 0);
+    __syncthreads();                                         // resident weights + slice 0 are in LDS
+
+    long long g = 0;
+    for (long long pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+        long long q = pass * 128 + wave * 16 + li;
+        const bool live = q < npix;
+        if (!live) q = 0;
+        // ---- o1 in accumulator layout
+        f32x4 o1[CF];
+        if (PRE) {
+#pragma unroll
+            for (int f = 0; f < CF; ++f) o1[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < SA_MAX; ++s) {
+                if (s < p.sa) {
+                    const int c0 = 32 * s + 8 * lg;
+                    const int left = p.pre_in.C - c0;
+                    const float *tp = p.pre_in.p + (size_t)q * p.pre_in.ld + (left > 0 ? c0 : 0);
+                    const float4 r0 = *reinterpret_cast<const float4 *>(tp);
+                    const float4 r1 = *reinterpret_cast<const float4 *>(tp + (left > 4 ? 4 : 0));
+                    const float raw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = j < left ? raw[j] : 0.f;
+                    f16x8 th[1], tl[1];
+                    split8(v, th[0], tl[0]);
+                    f16x8 ah[CF], al[CF];
+#pragma unroll
+                    for (int f = 0; f < CF; ++f) {
+                        const int o = (f * p.sa + s) * 512 + a_off;
+                        ah[f] = *reinterpret_cast<const f16x8 *>(wph + o);
+                        al[f] = *reinterpret_cast<const f16x8 *>(wpl + o);
+                    }
+                    f32x4 acc1[CF][1];
+#pragma unroll
+                    for (int f = 0; f < CF; ++f) acc1[f][0] = o1[f];
+                    mfma3<CF, 1>(acc1, ah, al, th, tl);
+#pragma unroll
+                    for (int f = 0; f < CF; ++f) o1[f] = acc1[f][0];
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < CF; ++f) {
+                const float4 idv = *reinterpret_cast<const float4 *>(p.ident.p + (size_t)q * p.ident.ld + f * 16 + 4 * lg);
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(bps + f * 16 + 4 * lg);
+                o1[f] = (o1[f] * p.pre_u + b) + f32x4{idv.x, idv.y, idv.z, idv.w};
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < CF; ++f) {
+                const float4 xv = *reinterpret_cast<const float4 *>(p.x.p + (size_t)q * p.x.ld + f * 16 + 4 * lg);
+                o1[f] = f32x4{xv.x, xv.y, xv.z, xv.w};
+            }
+        }
+        f16x8 bh[S][1], bl[S][1];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = o1[2 * s][j];
+                v[4 + j] = (2 * s + 1 < CF) ? o1[(2 * s + 1 < CF) ? 2 * s + 1 : 0][j] : 0.f;
+            }
+            split8(v, bh[s][0], bl[s][0]);
+        }
+        f32x4 oacc[CF][1];
+#pragma unroll
+        for (int f = 0; f < CF; ++f) oacc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int t = 0; t < T; ++t) {
+            const int slot = (int)(g & 1);
+            if (g + 1 < total) issue_slice(t + 1 < T ? t + 1 : 0, slot ^ 1);      // that slot was released by the last barrier
+            const _Float16 *w1h = ring + slot * SLICE_HALFS;
+            const _Float16 *w1l = w1h + W1_HALFS;
+            const _Float16 *w2h = w1l + W1_HALFS;
+            const _Float16 *w2l = w2h + W2_HALFS;
+            f32x4 hacc[2][1];
+            hacc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            hacc[1][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                f16x8 ah[2], al[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int o = (f * S + s) * 512 + a_off;
+                    ah[f] = *reinterpret_cast<const f16x8 *>(w1h + o);
+                    al[f] = *reinterpret_cast<const f16x8 *>(w1l + o);
+                }
+                mfma3<2, 1>(hacc, ah, al, bh[s], bl[s]);
+            }
+            f16x8 hh[1], hl[1];
+            {
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b1s + (2 * t) * 16 + 4 * lg);
+                const f32x4 b1v = *reinterpret_cast<const f32x4 *>(b1s + (2 * t + 1) * 16 + 4 * lg);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = hacc[0][0][j] * p.u1 + b0[j];
+                    const float b = hacc[1][0][j] * p.u1 + b1v[j];
+                    v[j] = a > 0.f ? a : a * p.slope;
+                    v[4 + j] = b > 0.f ? b : b * p.slope;
+                }
+                split8(v, hh[0], hl[0]);
+            }
+            f16x8 ah[CF], al[CF];
+#pragma unroll
+            for (int m = 0; m < CF; ++m) {
+                const int o = m * 512 + a_off;
+                ah[m] = *reinterpret_cast<const f16x8 *>(w2h + o);
+                al[m] = *reinterpret_cast<const f16x8 *>(w2l + o);
+            }
+            mfma3<CF, 1>(oacc, ah, al, hh, hl);
+            __syncthreads();                                 // slice g consumed by everyone; slice g+1 has landed
+            ++g;
+        }
+#pragma unroll
+        for (int f = 0; f < CF; ++f) {
+            if (f * 16 + 4 * lg >= C || !live) continue;
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = oacc[f][0][j] * p.u2 + b[j];
+                v[j] = o1[f][j] + (a > 0.f ? a : a * p.slope);
+            }
+            *reinterpret_cast<float4 *>(p.out.p + (size_t)q * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int CF, bool PRE>
+static int launch_ffn_stream(const FfnP &p, size_t lds, hipStream_t st) {
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+        return 256;
+    }();
+    static size_t granted = 0;
+    if (lds > granted) {
+        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_stream_f16x3_kernel<CF, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted = lds;
+    }
+    const long long npix = (long long)p.out.H * p.out.W;
+    long long blocks = (npix + 127) / 128;
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL((ffn_stream_f16x3_kernel<CF, PRE>), dim3((unsigned)blocks), dim3(kFfnThreads), lds, st, p);
+    return launch_status("ffn_stream_f16x3");
+}
+
 template <int CF, bool PRE>
 static int launch_ffn(const FfnP &p, size_t lds, hipStream_t st) {
     static const int cus = [] {
@@ -302,18 +520,35 @@ static int launch_ffn(const FfnP &p, size_t lds, hipStream_t st) {
 
 using namespace lssvc;
 
-extern "C" int64_t lssvc_ffn_f16x3_lds_bytes(int32_t C, int32_t hidden, int32_t pre_cin) {
+static long long ffn_resident_lds(int C, int hidden, int pre_cin) {
     const int cf = (C + 15) / 16, s = (cf + 1) / 2, t = hidden / 32;
     const long long n1 = (long long)t * 2 * s * 512, n2 = (long long)t * cf * 512;
     const long long npre = pre_cin > 0 ? (long long)cf * ((pre_cin + 31) / 32) * 512 : 0;
     return 2 * 2 * (n1 + n2 + npre) + 4 * ((long long)hidden + 2 * 16 * cf);
+}
+static long long ffn_stream_lds(int C, int hidden, int pre_cin) {
+    const int cf = (C + 15) / 16, s = (cf + 1) / 2;
+    const long long slice = 2 * (2 * s * 512) + 2 * (cf * 512);                      // halfs per ring slot
+    const long long npre = pre_cin > 0 ? (long long)cf * ((pre_cin + 31) / 32) * 512 : 0;
+    return 2 * (2 * slice + 2 * npre) + 4 * ((long long)hidden + 2 * 16 * cf);
+}
+
+/* LDS the fused kernel needs for this shape: the all-resident variant if it fits 160 KB, else the streamed one. */
+extern "C" int64_t lssvc_ffn_f16x3_lds_bytes(int32_t C, int32_t hidden, int32_t pre_cin) {
+    const long long r = ffn_resident_lds(C, hidden, pre_cin);
+    if (r <= 160 * 1024 && C <= 64 && pre_cin <= 64) return r;
+    return ffn_stream_lds(C, hidden, pre_cin);
+}
+
+extern "C" int lssvc_ffn_f16x3_is_streamed(int32_t C, int32_t hidden, int32_t pre_cin) {
+    return !(ffn_resident_lds(C, hidden, pre_cin) <= 160 * 1024 && C <= 64 && pre_cin <= 64);
 }
 
 extern "C" int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream) {
     LSSVC_CHECK(d != nullptr, "ffn_f16x3: null descriptor");
     LSSVC_CHECK(view_ok(&d->out) && vec4_ok(&d->out), "ffn_f16x3: bad out view (needs C %% 4 == 0, 16-byte aligned)");
     const int C = d->out.C;
-    LSSVC_CHECK(C % 16 == 0 && C >= 32 && C <= 64, "ffn_f16x3: C = %d not in {32, 48, 64}", C);
+    LSSVC_CHECK(C % 16 == 0 && C >= 32 && C <= 128, "ffn_f16x3: C = %d must be a multiple of 16 in [32, 128]", C);
     LSSVC_CHECK(d->hidden > 0 && d->hidden % 32 == 0, "ffn_f16x3: hidden = %d must be a positive multiple of 32", d->hidden);
     LSSVC_CHECK(d->w1_16 && d->w2_16 && d->b1 && d->b2, "ffn_f16x3: missing FFN weights");
     const bool pre = d->pre_w16 != nullptr;
@@ -321,7 +556,7 @@ extern "C" int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream) {
     p.out = mk(&d->out);
     if (pre) {
         LSSVC_CHECK(view_ok(&d->pre_in) && vec4_ok(&d->pre_in) && same_hw(&d->pre_in, &d->out), "ffn_f16x3: bad pre_in view");
-        LSSVC_CHECK(d->pre_in.C % 8 == 0 && d->pre_in.C <= 64, "ffn_f16x3: leading conv takes Cin %% 8 == 0, <= 64 (got %d)", d->pre_in.C);
+        LSSVC_CHECK(d->pre_in.C % 8 == 0 && d->pre_in.C <= 128, "ffn_f16x3: leading conv takes Cin %% 8 == 0, <= 128 (got %d)", d->pre_in.C);
         LSSVC_CHECK(view_ok(&d->ident) && vec4_ok(&d->ident) && same_shape(&d->ident, &d->out), "ffn_f16x3: bad ident view");
         LSSVC_CHECK(d->pre_bias != nullptr, "ffn_f16x3: leading conv needs a bias vector");
         p.pre_in = mk(&d->pre_in);
@@ -350,15 +585,26 @@ extern "C" int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream) {
     p.u1 = d->w1_unscale != 0.f ? d->w1_unscale : 1.f;
     p.u2 = d->w2_unscale != 0.f ? d->w2_unscale : 1.f;
     p.slope = d->slope;
-    const size_t lds = (size_t)lssvc_ffn_f16x3_lds_bytes(C, d->hidden, pre ? d->pre_in.C : 0);
-    LSSVC_CHECK(lds <= 160 * 1024, "ffn_f16x3: %zu bytes of weights do not fit the 160 KB LDS (C=%d hidden=%d)", lds, C, d->hidden);
+    const int pre_cin = pre ? d->pre_in.C : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (pre) {
-        if (cf == 4) return launch_ffn<4, true>(p, lds, st);
-        if (cf == 3) return launch_ffn<3, true>(p, lds, st);
-        return launch_ffn<2, true>(p, lds, st);
+    static const int force_stream = getenv("LSSVC_FFN_STREAM") ? atoi(getenv("LSSVC_FFN_STREAM")) : 0;
+    const long long resident = ffn_resident_lds(C, d->hidden, pre_cin);
+    if (resident <= 160 * 1024 && C <= 64 && pre_cin <= 64 && !force_stream) {
+        const size_t lds = (size_t)resident;
+        if (pre) {
+            if (cf == 4) return launch_ffn<4, true>(p, lds, st);
+            if (cf == 3) return launch_ffn<3, true>(p, lds, st);
+            return launch_ffn<2, true>(p, lds, st);
+        }
+        if (cf == 4) return launch_ffn<4, false>(p, lds, st);
+        if (cf == 3) return launch_ffn<3, false>(p, lds, st);
+        return launch_ffn<2, false>(p, lds, st);
     }
-    if (cf == 4) return launch_ffn<4, false>(p, lds, st);
-    if (cf == 3) return launch_ffn<3, false>(p, lds, st);
-    return launch_ffn<2, false>(p, lds, st);
+    const size_t lds = (size_t)ffn_stream_lds(C, d->hidden, pre_cin);
+    LSSVC_CHECK(lds <= 160 * 1024, "ffn_f16x3: %zu bytes do not fit the 160 KB LDS (C=%d hidden=%d pre_cin=%d)", lds, C, d->hidden, pre_cin);
+#define LSSVC_FFN_STREAM_CASE(n) \
+    if (cf == n) return pre ? launch_ffn_stream<n, true>(p, lds, st) : launch_ffn_stream<n, false>(p, lds, st);
+    LSSVC_FFN_STREAM_CASE(2) LSSVC_FFN_STREAM_CASE(3) LSSVC_FFN_STREAM_CASE(4) LSSVC_FFN_STREAM_CASE(6) LSSVC_FFN_STREAM_CASE(8)
+#undef LSSVC_FFN_STREAM_CASE
+    return fail("ffn_f16x3: no streamed kernel for C = %d", C);
 }

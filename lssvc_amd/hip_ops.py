@@ -226,12 +226,12 @@ _FFN_LDS_LIMIT = 160 * 1024
 
 def ffn_fusable(W, ffn_prefix, pre_name, c_out, pre_cin):
     """Can DepthConv.conv2 (+identity) + ConvFFN of this block run as one lssvc_ffn_f16x3 launch?"""
-    if not (FUSE_FFN and CONV_PRECISION == "f16x3" and c_out in (32, 48, 64)):
+    if not (FUSE_FFN and CONV_PRECISION == "f16x3" and c_out in (32, 48, 64, 96, 128)):
         return False
     w1 = W.raw(ffn_prefix + ".conv.0.weight")
     if w1.shape[1] != c_out or w1.shape[0] % 32 or not W.has(ffn_prefix + ".conv.0.bias") or not W.has(ffn_prefix + ".conv.2.bias"):
         return False
-    if pre_name is not None and (pre_cin % 8 or pre_cin > 64 or not W.has(pre_name + ".bias")):
+    if pre_name is not None and (pre_cin % 8 or pre_cin > 128 or not W.has(pre_name + ".bias")):
         return False
     return lib.lssvc_ffn_f16x3_lds_bytes(c_out, w1.shape[0], pre_cin if pre_name else 0) <= _FFN_LDS_LIMIT
 
@@ -266,7 +266,8 @@ def ffn_block(W, ffn_prefix, *, x=None, pre_name=None, pre_in=None, ident=None, 
     npx = out.H * out.W
     OP_LOG.append({"kind": "ffn_fused", "name": ffn_prefix, "macs": npx * (2 * c * hid + pre_cin * c),
                    "hout": out.H, "wout": out.W, "cin": c, "cout": c, "variant": 0, "ks": 1, "stride": 1, "vec": True,
-                   "f16x3": True, "kernel": "ffn_f16x3_kernel<%d, %s>" % (c // 16, "true" if pre_name else "false"),
+                   "f16x3": True, "kernel": "%s<%d, %s>" % ("ffn_stream_f16x3_kernel" if lib.lssvc_ffn_f16x3_is_streamed(c, hid, pre_cin)
+                                                             else "ffn_f16x3_kernel", c // 16, "true" if pre_name else "false"),
                    "bytes": 4 * npx * (2 * c + (pre_cin if pre_name else 0)), "events": (e0, e1)})
     return out
 

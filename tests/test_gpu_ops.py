@@ -382,7 +382,10 @@ def _ffn_ref(sd, o1):
 
 @pytest.mark.parametrize("c,hidden,pre_cin,H,W", [(64, 256, None, 24, 40), (48, 192, None, 19, 23), (32, 128, None, 16, 16),
                                                  (64, 256, 64, 21, 35), (48, 192, 48, 16, 48), (32, 128, 32, 7, 9),
-                                                 (48, 192, 64, 12, 20), (32, 64, 24, 10, 10), (64, 128, 40, 9, 33)])
+                                                 (48, 192, 64, 12, 20), (32, 64, 24, 10, 10), (64, 128, 40, 9, 33),
+                                                 # streamed-weights variant: wide blocks / wide leading conv
+                                                 (128, 512, 128, 18, 30), (128, 512, None, 11, 13), (64, 256, 128, 16, 24),
+                                                 (96, 384, 96, 9, 17), (128, 1024, 128, 8, 16), (96, 384, None, 5, 7)])
 def test_ffn_fused_matches_fp64(hip, c, hidden, pre_cin, H, W):
     """lssvc_ffn_f16x3 (DepthConv.conv2 + identity + ConvFFN in one launch) against an fp64 reference; error budget as
     for the unfused f16x3 convs: within 8x of what the exact-fp32 kernels give for the same chain."""
