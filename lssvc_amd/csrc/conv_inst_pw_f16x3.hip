@@ -32,6 +32,15 @@ int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name) {
             return launch_pw_allm_f16x3<1, 2>(p, st);
         }
     }
+    static const int deepk = getenv("LSSVC_PW_DEEPK") ? atoi(getenv("LSSVC_PW_DEEPK")) : 1;
+    if (deepk && p.n_chunks16 >= 8 && MF <= mf_fit && p.in_act != LSSVC_INACT_SQUARE &&
+        (p.in_act != LSSVC_INACT_LRELU || (p.in_slope >= 0.0f && p.in_slope <= 1.0f))) {
+        snprintf(kernel_name, 96, "conv_pwk_f16x3_kernel<%d, 2>", MF);
+        if (MF == 4) return launch_pwk_f16x3<4, 2>(p, st);
+        if (MF == 3) return launch_pwk_f16x3<3, 2>(p, st);
+        if (MF == 2) return launch_pwk_f16x3<2, 2>(p, st);
+        return launch_pwk_f16x3<1, 2>(p, st);
+    }
     snprintf(kernel_name, 96, "conv_pw_f16x3_kernel<%d, %d>", MF, rpw);
     if (rpw == 1) {
         if (MF == 4) return launch_pw_f16x3<4, 1>(p, st);

@@ -201,6 +201,177 @@ static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
 }
 
 
+// ---- deep-K variant (K >= 128): the K loop above keeps one step in flight and its conditionals make the compiler wait
+// vmcnt(0) before every load group, so with 6-24 MFMAs per 32-channel step it is bound by global-load latency
+// (1024->384 @72x120: 34 TFLOP/s). Here the loop body is straight-line: D = 4 register sets form a ring, step s+D is
+// loaded right after step s has been consumed (addresses past the end are clamped, their B operand zeroed by a
+// select, so there is no tail branch), the input LeakyReLU is max(x, s*x), and the single-input case (every FFN
+// contraction) gets its own instantiation without the segment lookup.
+template <int MF, int RPW, bool MULTI>
+__global__ __launch_bounds__(256, 2) void conv_pwk_f16x3_kernel(const ConvP p) {
+    constexpr int TM = 16 * MF;
+    constexpr int D = MF >= 4 ? 2 : 4;       // ring depth: 16 * D registers; MF = 4 already holds 32 accumulators + 64 fragment registers
+    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+    const int tsel = lg >> 1;
+    const int ch8 = (lg & 1) * 8;
+    const int nchunk = p.n_chunks16;
+    const int nstep = (nchunk + 1) >> 1;
+    const int nslot = nstep * 2;
+    const int m_tile = blockIdx.x % p.m_tiles;
+    const int m0 = m_tile * TM;
+    const int plane = nslot * TM * CK16;
+    {
+        const _Float16 *g_h = reinterpret_cast<const _Float16 *>(p.w16);
+        const _Float16 *g_l = g_h + p.w16_plane;
+        const int items = nslot * TM * 2;
+        for (int idx = tid; idx < items; idx += 256) {
+            const int c = idx / (TM * 2);
+            const int r = idx - c * (TM * 2);
+            const int m = r >> 1, half = r & 1;
+            f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < nchunk && m0 + m < p.M_pad) {
+                const size_t o = ((size_t)c * p.M_pad + m0 + m) * CK16 + half * 8;
+                h = *reinterpret_cast<const f16x8 *>(g_h + o);
+                l = *reinterpret_cast<const f16x8 *>(g_l + o);
+            }
+            const int d = (c * TM + m) * CK16 + half * 8;
+            *reinterpret_cast<f16x8 *>(wlds + d) = h;
+            *reinterpret_cast<f16x8 *>(wlds + plane + d) = l;
+        }
+    }
+    __syncthreads();
+
+    const float in_slope = p.in_act == LSSVC_INACT_LRELU ? p.in_slope : 1.0f;
+    const long long npix = (long long)p.Hout * p.Wout;
+    const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
+    const long long wave_id = (long long)(blockIdx.x / p.m_tiles) * 4 + wave;
+    const long long wave_stride = (long long)(gridDim.x / p.m_tiles) * 4;
+    const int n0 = (p.in[0].C + 15) >> 4, n1 = p.n_in > 1 ? (p.in[1].C + 15) >> 4 : 0;
+    const int nstep_pad = (nstep + D - 1) / D * D;
+
+    for (long long grp = wave_id; grp < ngroups; grp += wave_stride) {
+        long long pix[RPW];
+        size_t poff[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const long long q = (grp * RPW + r) * 16 + li;
+            pix[r] = q < npix ? q : -1;
+            poff[r] = (size_t)(q < npix ? q : 0);
+        }
+        f32x4 acc[MF][RPW];
+#pragma unroll
+        for (int a = 0; a < MF; ++a)
+#pragma unroll
+            for (int b = 0; b < RPW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        float4 raw[D][RPW][2];
+        int left_of[D];
+        auto load_step = [&](int s, float4 (&dst)[RPW][2], int &left8) {
+            int c = 2 * s + tsel;
+            const bool in_range = c < nchunk;
+            c = in_range ? c : nchunk - 1;
+            const float *base = p.in[0].p;
+            int ld = p.in[0].ld, cfirst = 0, cseg = p.in[0].C;
+            if (MULTI) {                                   // selects, not branches
+                const bool s1 = c >= n0, s2 = c >= n0 + n1;
+                base = s2 ? p.in[2].p : (s1 ? p.in[1].p : base);
+                ld = s2 ? p.in[2].ld : (s1 ? p.in[1].ld : ld);
+                cseg = s2 ? p.in[2].C : (s1 ? p.in[1].C : cseg);
+                cfirst = s2 ? n0 + n1 : (s1 ? n0 : 0);
+            }
+            const int c0 = (c - cfirst) * 16;
+            const int avail = cseg - c0 - ch8;             // channels from this lane's first channel to the end of the segment
+            left8 = in_range ? avail : 0;
+            const int cc = avail > 0 ? c0 + ch8 : 0;
+            const int second = avail > 4 ? 4 : 0;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float *src = base + poff[r] * ld + cc;
+                dst[r][0] = *reinterpret_cast<const float4 *>(src);
+                dst[r][1] = *reinterpret_cast<const float4 *>(src + second);
+            }
+        };
+        auto compute_step = [&](int s, const float4 (&src)[RPW][2], int left8) {
+            f16x8 bh[RPW], bl[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float v[8] = {src[r][0].x, src[r][0].y, src[r][0].z, src[r][0].w, src[r][1].x, src[r][1].y, src[r][1].z, src[r][1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = (pix[r] >= 0 && j < left8) ? v[j] : 0.f;
+                    x = fmaxf(x, in_slope * x);
+                    x = fminf(fmaxf(x, -65504.f), 65504.f);
+                    const _Float16 h = (_Float16)x;
+                    bh[r][j] = h;
+                    bl[r][j] = (_Float16)(x - (float)h);
+                }
+            }
+            const int sc = s < nstep ? s : nstep - 1;      // steps of the padded tail re-read the last slot against B = 0
+            const int slot = 2 * sc + tsel;
+            f16x8 ah[MF], al[MF];
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int o = (slot * TM + f * 16 + li) * CK16 + ch8;
+                ah[f] = *reinterpret_cast<const f16x8 *>(wlds + o);
+                al[f] = *reinterpret_cast<const f16x8 *>(wlds + plane + o);
+            }
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][r], 0, 0, 0);
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_step(d, raw[d], left_of[d]);
+        for (int s = 0; s < nstep_pad; s += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                compute_step(s + d, raw[d], (s + d) < nstep ? left_of[d] : 0);
+                load_step(s + d + D, raw[d], left_of[d]);
+            }
+        }
+        conv_unscale<MF, RPW>(p, acc);
+        conv_epilogue_flat<MF, RPW, false>(p, acc, pix, m0, lg);
+    }
+}
+
+template <int MF, int RPW>
+static int launch_pwk_f16x3(const ConvP &p, hipStream_t st) {
+    ConvP q = p;
+    q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
+    const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
+    const size_t lds = (size_t)2 * nslot * 16 * MF * CK16 * sizeof(_Float16);
+    if (lds > (size_t)kPwMaxLds) return fail("conv2d(pwk f16x3): %zu bytes of weights do not fit LDS", lds);
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+        return 256;
+    }();
+    const long long npix = (long long)p.Hout * p.Wout;
+    const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
+    long long per_m = (ngroups + 3) / 4;
+    const long long res = 2LL * cus;
+    const long long cap = res / q.m_tiles > 0 ? res / q.m_tiles : 1;
+    if (per_m > cap) per_m = cap;
+    const long long blocks = per_m * q.m_tiles;
+    if (p.n_in > 1) hipLaunchKernelGGL((conv_pwk_f16x3_kernel<MF, RPW, true>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    else hipLaunchKernelGGL((conv_pwk_f16x3_kernel<MF, RPW, false>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    return launch_status("conv2d(pwk f16x3)");
+}
+
+
 // ---- "all-M" variant for small K (<= 64 input channels, i.e. <= 2 K-steps) whose whole weight matrix fits LDS:
 // the wave converts its pixel fragments ONCE, keeps them in registers and walks every M tile itself (so X is
 // read and split once instead of once per M tile, and all output channels of a pixel are written by one wave),

@@ -28,6 +28,9 @@ SHAPES = [
     ("3x3 384->384 @72x120", [384], 384, 3, 1, 72, 120),
     ("1x1 384->384 @72x120", [384], 384, 1, 1, 72, 120),
     ("3x3 128->128 @72x120", [128], 128, 3, 1, 72, 120),
+    ("1x1 1024->384 @72x120", [1024], 384, 1, 1, 72, 120),
+    ("1x1 384->1024 @72x120", [384], 1024, 1, 1, 72, 120),
+    ("1x1 512->128 @288x480", [512], 128, 1, 1, 288, 480),
     ("3x3 192->192 @36x60", [192], 192, 3, 1, 36, 60),
     ("big 3x3 64->64 @2304x3840", [64], 64, 3, 1, 2304, 3840),
     ("big 7x7 32->64 @2304x3840", [32], 64, 7, 1, 2304, 3840),
