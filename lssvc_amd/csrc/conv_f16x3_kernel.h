@@ -30,6 +30,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
     constexpr int TM = 16 * MF;
     constexpr int TH = 4 * RPW;
     constexpr int PH = (TH - 1) * S + KS, PW = 15 * S + KS;
+    // stride 2: fragment column li reads patch column 2*li + kx, a 64-byte lane stride that would be a 4-way bank
+    // conflict on ds_read_b128; the even and the odd columns of a patch row are therefore stored as two runs
+    // ([even 0,2,.. | odd 1,3,..]) so that the read is unit-stride again: column c lives at (c & 1) * PWE + (c >> 1)
+    constexpr int PWE = (PW + 1) / 2;
     constexpr int RPP = (KS <= 3) ? KS : 1;                     // kernel rows per phase
     constexpr int NTAP = RPP * KS;                              // taps per phase
     constexpr int NSTEP = (NTAP + 1) / 2;                       // MFMA K-steps (2 taps each) per phase
@@ -132,7 +136,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
                 h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
                 l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
                 l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-                const int o = ((tid >> 2) + i * 64) * CK16 + quad4;
+                int pixi = (tid >> 2) + i * 64;
+                if (S == 2) {
+                    const int py = pixi / PW, px = pixi - py * PW;
+                    pixi = py * PW + (px & 1) * PWE + (px >> 1);
+                }
+                const int o = pixi * CK16 + quad4;
                 *reinterpret_cast<f16x4 *>(patch_h + o) = h;
                 *reinterpret_cast<f16x4 *>(patch_l + o) = l;
             }
@@ -211,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int row = wave * RPW + r;
-                const int o = dbg_u * ((row * S + ky) * PW + li * S + kx) * CK16 + ch8;
+                const int col = (S == 2) ? (kx & 1) * PWE + li + (kx >> 1) : li + kx;
+                const int o = dbg_u * ((row * S + ky) * PW + col) * CK16 + ch8;
                 bh[r] = *reinterpret_cast<const f16x8 *>(patch_h + o);
                 bl[r] = *reinterpret_cast<const f16x8 *>(patch_l + o);
             }
@@ -269,6 +279,17 @@ int dispatch_tile_f16x3(const ConvP &p, int MF, int RPW, hipStream_t st) {
 #undef LSSVC_CONV_CASE
     return fail("conv2d(f16x3): no kernel for MF=%d RPW=%d", MF, RPW);
 }
+
+template <int KS>
+int dispatch_tile_f16x3_s2(const ConvP &p, int MF, int RPW, hipStream_t st) {
+#define LSSVC_CONV_CASE(mf, rpw) \
+    if (MF == mf && RPW == rpw) return launch_f16x3<mf, rpw, KS, 2>(p, st);
+    LSSVC_CONV_CASE(1, 1) LSSVC_CONV_CASE(1, 2) LSSVC_CONV_CASE(2, 1) LSSVC_CONV_CASE(2, 2)
+    LSSVC_CONV_CASE(3, 1) LSSVC_CONV_CASE(3, 2) LSSVC_CONV_CASE(4, 1) LSSVC_CONV_CASE(4, 2)
+#undef LSSVC_CONV_CASE
+    return fail("conv2d(f16x3, stride 2): no kernel for MF=%d RPW=%d", MF, RPW);
+}
+extern template int dispatch_tile_f16x3_s2<3>(const ConvP &, int, int, hipStream_t);
 
 // persistent double-buffered 3x3 variant for large images (conv3_f16x3p.hip)
 bool conv3_f16x3p_wanted(const ConvP &p);

@@ -149,6 +149,11 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         p.w16_unscale = d->weight16_unscale != 0.0f ? d->weight16_unscale : 1.0f;
         p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
         if (vec && sd == 1 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3_f16x3p_wanted(p)) return dispatch_conv3_f16x3p(p, st, kname);
+        static const int s2_on = getenv("LSSVC_F16X3_S2") ? atoi(getenv("LSSVC_F16X3_S2")) : 1;
+        if (s2_on && vec && sd == 2 && ks == 3 && RPW <= 2) {
+            snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, 3, 2>", MF, RPW);
+            return dispatch_tile_f16x3_s2<3>(p, MF, RPW, st);
+        }
         if (vec && sd == 1 && (ks == 3 || ks == 7)) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, %d, 1>", MF, RPW, ks);
             return ks == 3 ? dispatch_tile_f16x3<3, 1>(p, MF, RPW, st) : dispatch_tile_f16x3<7, 1>(p, MF, RPW, st);

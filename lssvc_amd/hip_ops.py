@@ -177,7 +177,8 @@ def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slo
     if out is None:
         out = T.empty(hout * 2, wout * 2, cout // 4, x.device) if pixel_shuffle else T.empty(hout, wout, cout, x.device)
     w16 = None
-    if CONV_PRECISION == "f16x3" and stride == 1 and KH in (1, 3, 7) and all(t.C % 4 == 0 and t.ld % 4 == 0 for t in inputs):
+    if CONV_PRECISION == "f16x3" and (stride == 1 and KH in (1, 3, 7) or stride == 2 and KH == 3) \
+            and all(t.C % 4 == 0 and t.ld % 4 == 0 for t in inputs):
         w16 = W.conv_f16x3(name, [t.C for t in inputs], pixel_shuffle)
     return _conv_launch(inputs, (w_dev, b_dev, cout, m_pad), KH, KW, stride, pad, pad, out, in_act=in_act,
                         in_slope=in_slope, act=act, slope=slope, residual=residual, out_scale=out_scale,

@@ -309,6 +309,30 @@ def test_conv_f16x3_matches_fp64(hip, cins, cout, k, H, W):
     assert e16 <= e_half / 100, (e16, e_half)
 
 
+@pytest.mark.parametrize("cins,cout,H,W", [([48], 64, 64, 96), ([64], 96, 35, 51), ([64, 64], 128, 20, 36), ([96], 192, 18, 30),
+                                          ([16], 16, 9, 9), ([48, 48], 48, 130, 66)])
+def test_conv3x3_stride2_f16x3_matches_fp64(hip, cins, cout, H, W):
+    """Stride-2 3x3 convs in the f16x3 mode (even/odd patch columns de-interleaved in LDS): same error bar as stride 1,
+    with an input LeakyReLU, output activation and odd sizes in the mix."""
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, H)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    w = torch.randn(cout, sum(cins), 3, 3, generator=g) / math.sqrt(sum(cins) * 9)
+    b = torch.randn(cout, generator=g)
+    ref = F.leaky_relu(F.conv2d(F.leaky_relu(torch.cat(xs, 1).double(), 0.1), w.double(), b.double(), stride=2, padding=1), 0.01)
+    Wt = FakeW({"c.weight": w, "c.bias": b})
+    out = {}
+    for mode in ("f16x3", "f32"):
+        try:
+            hip.set_conv_precision(mode)
+            out[mode] = back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], stride=2, in_act="lrelu", in_slope=0.1, act="lrelu", slope=0.01))
+        finally:
+            hip.set_conv_precision("f32")
+    assert out["f16x3"].shape == ref.shape
+    e16 = (out["f16x3"].double() - ref).abs().max().item()
+    e32 = (out["f32"].double() - ref).abs().max().item()
+    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
+
+
 def test_conv_f16x3_fused_paths(hip):
     g = torch.Generator().manual_seed(21)
     x = torch.randn(1, 64, 24, 40, generator=g)
