@@ -402,8 +402,8 @@ class LSSVC_extend(_HostModel):
         assert (xe.H, xe.W) == self.shape_hr, "x_el is %dx%d but shape_hr is %s" % (xe.H, xe.W, self.shape_hr)
         bl = self._bl_codec(nhwc(x_bl), nhwc(ref_frame_bl), nhwc(ref_feature_bl))
         feature, recon_el, mv_hat, warp_frame = self._el_codec(xe, bl, nhwc(ref_frame_el), nhwc(ref_feature_el))
-        dpb = {"ref_frame_bl": bl["recon"].to_nchw(), "ref_feature_bl": bl["feature"].to_nchw(),
-               "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()}
+        dpb = {"ref_frame_bl": bl["recon"].to_nchw(remember=True), "ref_feature_bl": bl["feature"].to_nchw(remember=True),
+               "ref_frame_el": recon_el.to_nchw(remember=True), "ref_feature_el": feature.to_nchw(remember=True)}
         out = {"dpb": dpb, "mv_hat": mv_hat.to_nchw(), "warp_frame": warp_frame.to_nchw(),
                "encoding_time_EL": 0.0, "decoding_time_EL": 0.0, "encoding_time_BL": 0.0, "decoding_time_BL": 0.0}
         s = self.slots.fetch()

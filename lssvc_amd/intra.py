@@ -222,7 +222,7 @@ class IntraSS(_HostModel):
         assert (xe.H, xe.W) == (H, Wd), "x_el is %dx%d but shape_hr is %dx%d" % (xe.H, xe.W, H, Wd)
         x_hat_bl, y_hat_bl = self._bl_codec(xb)
         feature, x_hat = self._el_codec(xe, x_hat_bl, y_hat_bl)
-        out = {"x_hat_bl": x_hat_bl.to_nchw(), "x_hat_el": x_hat.to_nchw(), "feature_el": feature.to_nchw()}
+        out = {"x_hat_bl": x_hat_bl.to_nchw(remember=True), "x_hat_el": x_hat.to_nchw(remember=True), "feature_el": feature.to_nchw(remember=True)}
         s = self.slots.fetch()
         out["bit_bl"] = (s[0] + s[1]) / (-math.log(2))
         out["bit_el"] = (s[2] + s[3]) / (-math.log(2))

@@ -141,3 +141,19 @@ def test_config1_single_iframe_256(precision):
         g, w = got[k].cpu().clamp(0, 1), want[k].clamp(0, 1)
         assert abs(psnr(x, g) - psnr(x, w)) <= 1e-4
         np.testing.assert_allclose(got[k].cpu().numpy(), want[k].numpy(), atol=2e-4, rtol=0)
+
+
+def test_dpb_nhwc_cache_is_invalidated_by_in_place_edits():
+    """The NHWC view remembered for tensors handed to the caller (hip_ops.T.to_nchw(remember=True)) is reused only for
+    the same, unmodified tensor object: an in-place edit (test.py:249-250 clamps the frames) or a different tensor with
+    equal contents must be re-read."""
+    from lssvc_amd.hip_ops import T
+    x = torch.rand(1, 8, 6, 10, device=DEV) * 3 - 1
+    t = T.from_nchw(x)
+    y = t.to_nchw(remember=True)
+    assert T.from_nchw(y) is t                                  # untouched -> the remembered view
+    y.clamp_(0, 1)
+    t2 = T.from_nchw(y)
+    assert t2 is not t and torch.equal(t2.to_nchw(), y)         # edited in place -> transposed again, sees the clamp
+    z = y.clone()
+    assert T.from_nchw(z) is not t2 and torch.equal(T.from_nchw(z).to_nchw(), z)
