@@ -126,6 +126,14 @@ int64_t lssvc_ffn_f16x3_lds_bytes(int32_t C, int32_t hidden, int32_t pre_cin);
 /* 1 if lssvc_ffn_f16x3 runs the streamed-weights kernel for this shape (profiling label only). */
 int lssvc_ffn_f16x3_is_streamed(int32_t C, int32_t hidden, int32_t pre_cin);
 
+/* DepthConv's front half in one launch (f16x3 arithmetic; src/models/lssvc_modules.py:15-44):
+ *     out = depthwise3x3(act(conv1x1(in...) + bias)) + dw_bias
+ * `d` describes the leading 1x1 conv exactly as for lssvc_conv2d (precision F16X3, up to 3 concatenated inputs with at
+ * most 64 channels in 16-channel chunks, Cout = C in {32, 48, 64}, act none / LeakyReLU, no residual / GDN / shuffle);
+ * d->out is the FINAL H x W x C view. dw_weight is [9][C] (tap-major), dw_bias [C], as for lssvc_dwconv3x3. Results
+ * are bit-identical to lssvc_conv2d followed by lssvc_dwconv3x3. */
+int lssvc_conv1x1_dw3x3_f16x3(const lssvc_conv_desc *d, const float *dw_weight, const float *dw_bias, void *stream);
+
 /* Depthwise 3x3, stride 1, pad 1 (lssvc_modules.py:23-24). weight: [9][C], bias: [C]. */
 int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const float *bias, const lssvc_view *out,
                     void *stream);

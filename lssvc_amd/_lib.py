@@ -58,6 +58,7 @@ SIGNATURES = {
     "lssvc_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "lssvc_conv2d_variant": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "lssvc_conv2d_last_kernel": (C.c_char_p, []),
+    "lssvc_conv1x1_dw3x3_f16x3": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_ffn_f16x3": (C.c_int, [C.POINTER(FfnDesc), C.c_void_p]),
     "lssvc_ffn_f16x3_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "lssvc_ffn_f16x3_is_streamed": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),

@@ -46,8 +46,10 @@ def depth_conv_block(W, p, inputs, out=None):
     else:
         assert isinstance(inputs, T), "DepthConv without adaptor needs a materialised input"
         ident = inputs
-    t = ops.conv(W, q + ".conv1.0", inputs, act="lrelu", slope=0.01)
-    t = ops.dwconv3x3(W, q + ".depth_conv", t)
+    t = ops.conv1x1_dw3x3(W, q + ".conv1.0", q + ".depth_conv", inputs, slope=0.01)     # one launch when the shape allows
+    if t is None:
+        t = ops.conv(W, q + ".conv1.0", inputs, act="lrelu", slope=0.01)
+        t = ops.dwconv3x3(W, q + ".depth_conv", t)
     f = p + ".block.1"
     if ops.ffn_fusable(W, f, q + ".conv2", ident.C, t.C):
         # conv2 + identity + the whole ConvFFN in one launch; the 4C-wide hidden tensor never reaches HBM

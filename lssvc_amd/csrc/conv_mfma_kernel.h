@@ -59,9 +59,9 @@ __device__ __forceinline__ void conv_unscale(const ConvP &p, f32x4 (&acc)[MF][RP
 // prescale (1 for the fp32 kernels); multiplying by a power of two and by 1.0f is exact.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int MF, int RPW>
-__device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
-                                                   int lg, float unscale = 1.0f) {
+template <int MF, int RPW, bool PS>
+__device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
+                                                        int lg, float unscale) {
     const float s_neg = p.act == LSSVC_ACT_LRELU ? p.slope : (p.act == LSSVC_ACT_RELU ? 0.0f : 1.0f);
     const bool has_res = p.res.p != nullptr;
     const f32x2 us = {unscale, unscale}, sn = {s_neg, s_neg}, os = {p.out_scale, p.out_scale};
@@ -76,8 +76,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
     }
     // pixel-shuffle store (fast_epi == 2): channel m = q*cps + c goes to sub-pixel q = dy*2+dx, channel c (the host
     // permuted the weights so); a lane's 4 channels never straddle q because cps % 4 == 0
-    int ps_off[MF];
-    if (p.fast_epi == 2) {
+    int ps_off[PS ? MF : 1];
+    if (PS) {
         const int cps = p.Cout >> 2;
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
@@ -102,7 +102,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
         const size_t opix = (size_t)(pix[r] >= 0 ? pix[r] : 0);
         float *orow = p.out.p + opix * p.out.ld + m0 + 4 * lg;
         float *srow = nullptr;                                   // pixel-shuffle: the 2x2 output block of this conv pixel
-        if (p.fast_epi == 2) {
+        if (PS) {
             const int oy = (int)(opix / p.Wout), ox = (int)(opix - (size_t)oy * p.Wout);
             srow = p.out.p + ((size_t)(2 * oy) * p.out.W + 2 * ox) * p.out.ld;
         }
@@ -117,11 +117,18 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
             v0 = (v0 + f32x2{rs[r & 1][f].x, rs[r & 1][f].y}) * os;
             v1 = (v1 + f32x2{rs[r & 1][f].z, rs[r & 1][f].w}) * os;
             float *dst = orow + f * 16;
-            if (p.fast_epi == 2) dst = srow + ps_off[f];
+            if (PS) dst = srow + ps_off[f];
             if (pix[r] >= 0 && mb < p.Cout && (!(p.debug & 64) || v0.x == 1.2345f))   // debug 64: perf ablation, stores off
                 *reinterpret_cast<float4 *>(dst) = make_float4(v0.x, v0.y, v1.x, v1.y);
         }
     }
+}
+
+template <int MF, int RPW>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
+                                                   int lg, float unscale = 1.0f) {
+    if (p.fast_epi == 2) conv_epilogue_fast_impl<MF, RPW, true>(p, acc, pix, m0, lg, unscale);      // pixel-shuffle store
+    else conv_epilogue_fast_impl<MF, RPW, false>(p, acc, pix, m0, lg, unscale);
 }
 
 // Memory-op ordering matters here: on gfx9/CDNA loads and stores share the vmcnt counter, so a wait for a load that

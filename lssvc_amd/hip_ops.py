@@ -234,6 +234,58 @@ def dwconv3x3(W, name, x, out=None):
     return out
 
 
+FUSE_DW = _os.environ.get("LSSVC_FUSE_DW", "1") == "1"
+
+
+def conv1x1_dw3x3(W, conv_name, dw_name, inputs, *, slope=0.01, out=None):
+    """depthwise3x3(lrelu(conv1x1(cat(inputs)))) in one launch (DepthConv.conv1 -> depth_conv, lssvc_modules.py:15-44),
+    or None if this shape is not covered (the caller then issues the two ops)."""
+    if isinstance(inputs, T):
+        inputs = [inputs]
+    if not (FUSE_DW and CONV_PRECISION == "f16x3") or len(inputs) > 3:
+        return None
+    if any(t.C % 4 or t.ld % 4 for t in inputs) or sum((t.C + 15) // 16 for t in inputs) > 4:
+        return None
+    w_dev, b_dev, cout, m_pad, KH, KW = W.conv(conv_name, [t.C for t in inputs], False)
+    if KH != 1 or cout not in (32, 48, 64) or b_dev is None:
+        return None
+    w16 = W.conv_f16x3(conv_name, [t.C for t in inputs], False)
+    dw_w, dw_b = W.dwconv(dw_name)
+    x = inputs[0]
+    if out is None:
+        out = T.empty(x.H, x.W, cout, x.device)
+    d = ConvDesc()
+    for i, t in enumerate(inputs):
+        d.inp[i] = t.v
+    d.n_in = len(inputs)
+    d.weight, d.bias = w_dev.data_ptr(), b_dev.data_ptr()
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l = 1, 1, 1, 0, 0
+    d.Cout, d.M_pad = cout, m_pad
+    d.in_act, d.in_slope = _INACT[None], 0.01
+    d.epilogue = 0
+    d.gdn_x = _NULL_VIEW
+    d.act, d.slope = _ACT["lrelu"], slope
+    d.residual = _NULL_VIEW
+    d.out_scale = 1.0
+    d.pixel_shuffle = 0
+    d.out = out.v
+    d.precision, d.weight16, d.weight16_unscale = _lib.PREC_F16X3, w16[0].data_ptr(), w16[1]
+    args = (C.byref(d), C.c_void_p(dw_w.data_ptr()), C.c_void_p(dw_b.data_ptr()), stream_ptr())
+    if OP_LOG is None:
+        check(lib.lssvc_conv1x1_dw3x3_f16x3(*args))
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.lssvc_conv1x1_dw3x3_f16x3(*args))
+    e1.record()
+    cin = sum(t.C for t in inputs)
+    OP_LOG.append({"kind": "conv1x1+dw3x3", "name": conv_name, "macs": out.H * out.W * cout * (cin + 9), "hout": out.H, "wout": out.W,
+                   "cin": cin, "cout": cout, "variant": 0, "ks": 1, "stride": 1, "vec": True, "f16x3": True,
+                   "kernel": "dwpre_f16x3_kernel<%d, %d, 16>" % (cout // 16, (sum((t.C + 15) // 16 for t in inputs) + 1) // 2),
+                   "bytes": 4 * out.H * out.W * (cin + cout), "events": (e0, e1)})
+    return out
+
+
 FUSE_FFN = _os.environ.get("LSSVC_FUSE_FFN", "1") == "1"
 _FFN_LDS_LIMIT = 160 * 1024
 

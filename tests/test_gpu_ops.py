@@ -484,3 +484,42 @@ def test_depth_conv_block_fused_equals_unfused(hip):
         hip.FUSE_FFN = True
         hip.set_conv_precision("f32")
     close(outs[True], outs[False], rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------- fused DepthConv front half
+@pytest.mark.parametrize("cins,c,H,W", [([64], 64, 37, 45), ([48], 48, 16, 16), ([32], 32, 50, 18), ([32, 32], 64, 33, 70),
+                                        ([16, 16, 16], 48, 19, 21), ([24], 32, 7, 5), ([64], 64, 128, 96)])
+def test_conv1x1_dw3x3_fused_is_bit_identical(hip, cins, c, H, W):
+    """lssvc_conv1x1_dw3x3_f16x3 == lssvc_conv2d (1x1, LeakyReLU) followed by lssvc_dwconv3x3, bit for bit: same K order
+    in the 1x1, same tap order in the depthwise conv, zero padding applied to the intermediate."""
+    g = torch.Generator().manual_seed(sum(cins) * 100 + H)
+    cin = sum(cins)
+    sd = {"c.weight": torch.randn(c, cin, 1, 1, generator=g) / math.sqrt(cin), "c.bias": torch.randn(c, generator=g) * 0.2,
+          "d.weight": torch.randn(c, 1, 3, 3, generator=g) / 3, "d.bias": torch.randn(c, generator=g) * 0.2}
+    Wt = FakeW(sd)
+    xs = [torch.randn(1, ci, H, W, generator=g) for ci in cins]
+    try:
+        hip.set_conv_precision("f16x3")
+        ins = [nhwc(hip, x) for x in xs]
+        fused = hip.conv1x1_dw3x3(Wt, "c", "d", ins, slope=0.01)
+        assert fused is not None
+        t = hip.conv(Wt, "c", ins, act="lrelu", slope=0.01)
+        two = hip.dwconv3x3(Wt, "d", t)
+    finally:
+        hip.set_conv_precision("f32")
+    assert torch.equal(back(fused), back(two))
+    ref = F.conv2d(F.leaky_relu(F.conv2d(torch.cat(xs, 1), sd["c.weight"], sd["c.bias"]), 0.01), sd["d.weight"], sd["d.bias"], padding=1, groups=c)
+    close(back(fused), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_conv1x1_dw3x3_declines_uncovered_shapes(hip):
+    g = torch.Generator().manual_seed(1)
+    sd = {"c.weight": torch.randn(128, 128, 1, 1, generator=g), "c.bias": torch.randn(128, generator=g),
+          "d.weight": torch.randn(128, 1, 3, 3, generator=g), "d.bias": torch.randn(128, generator=g)}
+    try:
+        hip.set_conv_precision("f16x3")
+        assert hip.conv1x1_dw3x3(FakeW(sd), "c", "d", nhwc(hip, torch.randn(1, 128, 8, 8, generator=g))) is None
+        hip.set_conv_precision("f32")
+        assert hip.conv1x1_dw3x3(FakeW(sd), "c", "d", nhwc(hip, torch.randn(1, 128, 8, 8, generator=g))) is None
+    finally:
+        hip.set_conv_precision("f32")
