@@ -30,7 +30,7 @@ PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = 64 FLOP/clk/SIMD
 
 
-DTYPE = {"f32": "f32", "f16x3": "f16x3 (3x3/7x7 convs: fp16 MFMA on hi/lo-split operands, fp32 accumulate; everything else f32)"}
+DTYPE = {"f32": "f32", "f16x3": "f16x3 (convolutions: fp16 MFMA on hi/lo-split operands, fp32 accumulate, fp32-class results; GDN and pointwise/entropy kernels f32)"}
 
 
 def log(*a):

@@ -176,12 +176,28 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
     return out
 
 
+PAD_NARROW_INPUTS = _os.environ.get("LSSVC_PAD_NARROW", "1") == "1"
+
+
+def pad4(t):
+    """A 4-channel copy of a 1-3 channel view (extra channels zero). Not cached: the source may be rewritten in place."""
+    wide = T.zeros(t.H, t.W, 4, t.device)
+    copy(t, wide.slice(0, t.C))
+    return wide
+
+
 def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slope=0.01, residual=None,
          pixel_shuffle=False, out_scale=1.0, out=None, pad=None):
     """nn.Conv2d (+ optional fused pieces). `inputs`: a T or a list of up to 3 T's read as torch.cat(dim=1)."""
     if isinstance(inputs, T):
         inputs = [inputs]
-    w_dev, b_dev, cout, m_pad, KH, KW = W.conv(name, [t.C for t in inputs], pixel_shuffle)
+    splits = [t.C for t in inputs]                      # what the weights are laid out for
+    if CONV_PRECISION == "f16x3" and PAD_NARROW_INPUTS and any(t.C < 4 for t in inputs):
+        # RGB / flow inputs (2-3 channels) would force the whole conv onto the exact-fp32 kernel (its loads are not
+        # 16-byte addressable); a zero 4th channel costs one small copy and meets zero weights (every concat segment
+        # is zero-padded to its chunk size in both weight layouts), so the result is unchanged
+        inputs = [pad4(t) if t.C < 4 else t for t in inputs]
+    w_dev, b_dev, cout, m_pad, KH, KW = W.conv(name, splits, pixel_shuffle)
     if pad is None:
         pad = KH // 2
     x = inputs[0]
@@ -192,7 +208,7 @@ def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slo
     w16 = None
     if CONV_PRECISION == "f16x3" and (stride == 1 and KH in (1, 3, 7) or stride == 2 and KH == 3) \
             and all(t.C % 4 == 0 and t.ld % 4 == 0 for t in inputs):
-        w16 = W.conv_f16x3(name, [t.C for t in inputs], pixel_shuffle)
+        w16 = W.conv_f16x3(name, splits, pixel_shuffle)
     return _conv_launch(inputs, (w_dev, b_dev, cout, m_pad), KH, KW, stride, pad, pad, out, in_act=in_act,
                         in_slope=in_slope, act=act, slope=slope, residual=residual, out_scale=out_scale,
                         pixel_shuffle=pixel_shuffle, name=name, w16=w16)

@@ -523,3 +523,33 @@ def test_conv1x1_dw3x3_declines_uncovered_shapes(hip):
         assert hip.conv1x1_dw3x3(FakeW(sd), "c", "d", nhwc(hip, torch.randn(1, 128, 8, 8, generator=g))) is None
     finally:
         hip.set_conv_precision("f32")
+
+
+@pytest.mark.parametrize("cins,cout,k,stride", [([3, 48], 64, 3, 2), ([2], 64, 3, 2), ([3], 64, 3, 1), ([64, 3], 32, 3, 1), ([2, 2, 4], 16, 7, 1),
+                                                ([3, 64], 64, 1, 1)])
+def test_narrow_inputs_take_the_f16x3_path(hip, cins, cout, k, stride):
+    """2-3 channel inputs (RGB, flow) are padded to 4 channels so the conv can run in the f16x3 mode; the result must
+    match the exact-fp32 kernel on the unpadded views within the usual f16x3 error budget."""
+    g = torch.Generator().manual_seed(sum(cins) + cout + k)
+    H, W = 22, 38
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double(), stride=stride, padding=k // 2)
+    Wt = FakeW({"c.weight": w, "c.bias": b})
+    out = {}
+    for mode in ("f16x3", "f32"):
+        try:
+            hip.set_conv_precision(mode)
+            hip.OP_LOG = []
+            out[mode] = back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], stride=stride))
+            kernel = hip.OP_LOG[-1]["kernel"]
+        finally:
+            hip.OP_LOG = None
+            hip.set_conv_precision("f32")
+        if mode == "f16x3":
+            assert "f16x3" in kernel, kernel                   # really left the fp32 kernel
+    e16 = (out["f16x3"].double() - ref).abs().max().item()
+    e32 = (out["f32"].double() - ref).abs().max().item()
+    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
