@@ -6,6 +6,10 @@ resolved, importing this module raises -- loudly -- instead of silently computin
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: PyTorch-ROCm carries its own libamdhip64; whichever HIP runtime is loaded first serves
+#                the whole process, and device memory / streams handed to this library come from torch's. Loading
+#                liblssvc_hip.so before torch binds the system runtime instead ("no ROCm-capable device is detected").
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblssvc_hip.so")
 
