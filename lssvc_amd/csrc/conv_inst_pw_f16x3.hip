@@ -32,6 +32,21 @@ int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name) {
             return launch_pw_allm_f16x3<1, 2>(p, st);
         }
     }
+    // large K on a small map: K-sliced kernel with a full-height M tile (X is re-read M/64 instead of M/16 times)
+    static const int ksliced = getenv("LSSVC_PW_KSLICED") ? atoi(getenv("LSSVC_PW_KSLICED")) : 1;
+    {
+        int mfw = frags < 4 ? frags : 4;
+        if (frags % 4 != 0 && frags % 3 == 0) mfw = 3;
+        const long long groups64 = ((long long)p.Hout * p.Wout + 63) / 64;
+        if (ksliced && p.n_chunks16 >= 16 && mfw > mf_fit && groups64 * ((frags + mfw - 1) / mfw) <= 4096 &&
+            p.in_act != LSSVC_INACT_SQUARE && (p.in_act != LSSVC_INACT_LRELU || (p.in_slope >= 0.0f && p.in_slope <= 1.0f))) {
+            snprintf(kernel_name, 96, "conv_pwks_f16x3_kernel<%d>", mfw);
+            if (mfw == 4) return launch_pwks_f16x3<4>(p, st);
+            if (mfw == 3) return launch_pwks_f16x3<3>(p, st);
+            if (mfw == 2) return launch_pwks_f16x3<2>(p, st);
+            return launch_pwks_f16x3<1>(p, st);
+        }
+    }
     static const int deepk = getenv("LSSVC_PW_DEEPK") ? atoi(getenv("LSSVC_PW_DEEPK")) : 1;
     if (deepk && p.n_chunks16 >= 8 && MF <= mf_fit && p.in_act != LSSVC_INACT_SQUARE &&
         (p.in_act != LSSVC_INACT_LRELU || (p.in_slope >= 0.0f && p.in_slope <= 1.0f))) {

@@ -372,6 +372,165 @@ static int launch_pwk_f16x3(const ConvP &p, hipStream_t st) {
 }
 
 
+// ---- K-sliced variant for large K on small maps (e.g. 1024 -> 384 @72x120): with all of K resident only a 16-row M tile
+// fits LDS, so X is re-read M/16 times and those layers are L2-bound. Here the M tile keeps its full 16*MF rows and
+// K is cut into slices of 256 channels (8 K-steps, 16*MF KiB of hi/lo weights): the workgroup re-stages the weight
+// slice every 8 steps (two barriers), while each wave owns ONE 64-pixel group whose MF x 4 accumulators live in
+// registers across all slices; the X ring prefetch runs straight through the slice boundaries. One group per wave,
+// no persistence: meant for launches with few pixel groups.
+template <int MF, bool MULTI>
+__global__ __launch_bounds__(256, 2) void conv_pwks_f16x3_kernel(const ConvP p) {
+    constexpr int TM = 16 * MF, RPW = 4, D = 2, SLICE_STEPS = 8, SLICE_SLOTS = 2 * SLICE_STEPS;
+    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];     // [hi|lo][slot in slice][TM][16]
+    constexpr int plane = SLICE_SLOTS * TM * CK16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+    const int tsel = lg >> 1;
+    const int ch8 = (lg & 1) * 8;
+    const int nchunk = p.n_chunks16;
+    const int nstep = (nchunk + 1) >> 1;
+    const int m_tile = blockIdx.x % p.m_tiles;
+    const int m0 = m_tile * TM;
+    const float in_slope = p.in_act == LSSVC_INACT_LRELU ? p.in_slope : 1.0f;
+    const long long npix = (long long)p.Hout * p.Wout;
+    const long long grp = (long long)(blockIdx.x / p.m_tiles) * 4 + wave;          // this wave's 64-pixel group (may be past the end)
+    const int n0 = (p.in[0].C + 15) >> 4, n1 = p.n_in > 1 ? (p.in[1].C + 15) >> 4 : 0;
+    const int nstep_pad = (nstep + SLICE_STEPS - 1) / SLICE_STEPS * SLICE_STEPS;
+
+    long long pix[RPW];
+    size_t poff[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const long long q = (grp * RPW + r) * 16 + li;
+        pix[r] = q < npix ? q : -1;
+        poff[r] = (size_t)(q < npix ? q : 0);
+    }
+    f32x4 acc[MF][RPW];
+#pragma unroll
+    for (int a = 0; a < MF; ++a)
+#pragma unroll
+        for (int b = 0; b < RPW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stage_slice = [&](int s0) {                       // weights of K-steps s0 .. s0+7 for this M tile
+        const _Float16 *g_h = reinterpret_cast<const _Float16 *>(p.w16);
+        const _Float16 *g_l = g_h + p.w16_plane;
+        for (int idx = tid; idx < SLICE_SLOTS * TM * 2; idx += 256) {
+            const int c = idx / (TM * 2);
+            const int r = idx - c * (TM * 2);
+            const int m = r >> 1, half = r & 1;
+            const int cg = 2 * s0 + c;
+            f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (cg < nchunk && m0 + m < p.M_pad) {
+                const size_t o = ((size_t)cg * p.M_pad + m0 + m) * CK16 + half * 8;
+                h = *reinterpret_cast<const f16x8 *>(g_h + o);
+                l = *reinterpret_cast<const f16x8 *>(g_l + o);
+            }
+            const int d = (c * TM + m) * CK16 + half * 8;
+            *reinterpret_cast<f16x8 *>(wlds + d) = h;
+            *reinterpret_cast<f16x8 *>(wlds + plane + d) = l;
+        }
+    };
+    float4 raw[D][RPW][2];
+    int left_of[D];
+    auto load_step = [&](int s, float4 (&dst)[RPW][2], int &left8) {
+        int c = 2 * s + tsel;
+        const bool in_range = c < nchunk;
+        c = in_range ? c : nchunk - 1;
+        const float *base = p.in[0].p;
+        int ld = p.in[0].ld, cfirst = 0, cseg = p.in[0].C;
+        if (MULTI) {
+            const bool s1 = c >= n0, s2 = c >= n0 + n1;
+            base = s2 ? p.in[2].p : (s1 ? p.in[1].p : base);
+            ld = s2 ? p.in[2].ld : (s1 ? p.in[1].ld : ld);
+            cseg = s2 ? p.in[2].C : (s1 ? p.in[1].C : cseg);
+            cfirst = s2 ? n0 + n1 : (s1 ? n0 : 0);
+        }
+        const int c0 = (c - cfirst) * 16;
+        const int avail = cseg - c0 - ch8;
+        left8 = in_range ? avail : 0;
+        const int cc = avail > 0 ? c0 + ch8 : 0;
+        const int second = avail > 4 ? 4 : 0;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float *src = base + poff[r] * ld + cc;
+            dst[r][0] = *reinterpret_cast<const float4 *>(src);
+            dst[r][1] = *reinterpret_cast<const float4 *>(src + second);
+        }
+    };
+    auto compute_step = [&](int slot_step, const float4 (&src)[RPW][2], int left8) {
+        f16x8 bh[RPW], bl[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float v[8] = {src[r][0].x, src[r][0].y, src[r][0].z, src[r][0].w, src[r][1].x, src[r][1].y, src[r][1].z, src[r][1].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = (pix[r] >= 0 && j < left8) ? v[j] : 0.f;
+                x = fmaxf(x, in_slope * x);
+                x = fminf(fmaxf(x, -65504.f), 65504.f);
+                const _Float16 h = (_Float16)x;
+                bh[r][j] = h;
+                bl[r][j] = (_Float16)(x - (float)h);
+            }
+        }
+        const int slot = 2 * slot_step + tsel;
+        f16x8 ah[MF], al[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int o = (slot * TM + f * 16 + li) * CK16 + ch8;
+            ah[f] = *reinterpret_cast<const f16x8 *>(wlds + o);
+            al[f] = *reinterpret_cast<const f16x8 *>(wlds + plane + o);
+        }
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][r], 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_step(d, raw[d], left_of[d]);
+    for (int s0 = 0; s0 < nstep_pad; s0 += SLICE_STEPS) {
+        __syncthreads();                                   // every wave is done with the previous slice
+        stage_slice(s0);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SLICE_STEPS; u += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int s = s0 + u + d;
+                compute_step(u + d, raw[d], s < nstep ? left_of[d] : 0);      // padded-tail slots hold zero weights
+                load_step(s + D, raw[d], left_of[d]);
+            }
+        }
+    }
+    conv_unscale<MF, RPW>(p, acc);
+    conv_epilogue_flat<MF, RPW, false>(p, acc, pix, m0, lg);
+}
+
+template <int MF>
+static int launch_pwks_f16x3(const ConvP &p, hipStream_t st) {
+    ConvP q = p;
+    q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
+    const size_t lds = (size_t)2 * 16 * 16 * MF * CK16 * sizeof(_Float16);          // 16 KiB per M fragment
+    const long long npix = (long long)p.Hout * p.Wout;
+    const long long ngroups = (npix + 63) / 64;
+    const long long blocks = ((ngroups + 3) / 4) * q.m_tiles;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return fail("conv2d(pwks f16x3): bad grid %lld", blocks);
+    if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    return launch_status("conv2d(pwks f16x3)");
+}
+
+
 // ---- "all-M" variant for small K (<= 64 input channels, i.e. <= 2 K-steps) whose whole weight matrix fits LDS:
 // the wave converts its pixel fragments ONCE, keeps them in registers and walks every M tile itself (so X is
 // read and split once instead of once per M tile, and all output channels of a pixel are written by one wave),
