@@ -1,7 +1,9 @@
 """For one golden case, find which coded symbols of the first P frame differ between the GPU path and the
 CPU oracle, and how close to a rounding tie the oracle's pre-round value was (debug aid)."""
-import sys, numpy as np, torch
-sys.path.insert(0, "tests"); sys.path.insert(0, "."); sys.path.insert(0, "oracle")
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for _p in ("tests", "", "oracle"):
+    sys.path.insert(0, os.path.join(ROOT, _p))
 from helpers import load_case
 from lssvc_amd import IntraSS, LSSVC_extend
 from lssvc_amd.hip_ops import T

@@ -4,8 +4,10 @@ Patches torch.nn.functional.conv2d (dense, stride-1 3x3/7x7/1x1 only - what the 
 both operands are split into fp16 hi + lo and the three kept products are accumulated, with optional power-of-two
 prescaling of x (sx) and w (per layer, max|w| -> 2^wexp).  Reports max |pre_round - exact| on one golden case's
 first P frame.  usage: sim_f16x3.py CASE [sx_log2 [wexp]]   (omit scales for the unscaled split)"""
-import sys, numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
+import os, sys, numpy as np, torch, torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for _p in ("tests", "", "oracle"):
+    sys.path.insert(0, os.path.join(ROOT, _p))
 from helpers import load_case
 from lssvc_amd.synth import synth_state_dict
 from lssvc_oracle.intra import intra_forward
