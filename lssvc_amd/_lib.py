@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- FIRST: PyTorch-ROCm carries its own libamdhip64; 
 #                liblssvc_hip.so before torch binds the system runtime instead ("no ROCm-capable device is detected").
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblssvc_hip.so")
+LIB_PATH = os.environ.get("LSSVC_HIP_LIB") or os.path.join(_HERE, "lib", "liblssvc_hip.so")     # override: A/B of two builds
 
 CONV_MAX_INPUTS = 3
 CONV_CK = 8

@@ -42,6 +42,14 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8 &h, f16x8 &l) 
     }
 }
 
+// lrelu(acc * u + b) for one accumulator fragment, written on 4-wide vectors so it compiles to packed fp32 ops; the
+// LeakyReLU is max(y, s*y) (exact for 0 <= s <= 1, which the host guarantees for this kernel)
+__device__ __forceinline__ f32x4 act4(const f32x4 acc, float u, const f32x4 b, float slope) {
+    const f32x4 y = acc * u + b;
+    const f32x4 n = y * slope;
+    return f32x4{fmaxf(y[0], n[0]), fmaxf(y[1], n[1]), fmaxf(y[2], n[2]), fmaxf(y[3], n[3])};
+}
+
 template <int NA, int RPW>
 __device__ __forceinline__ void mfma3(f32x4 (&acc)[NA][RPW], const f16x8 (&ah)[NA], const f16x8 (&al)[NA], const f16x8 (&bh)[RPW],
                                       const f16x8 (&bl)[RPW]) {
@@ -237,14 +245,8 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
                 const f32x4 b1v = *reinterpret_cast<const f32x4 *>(b1s + (2 * t + 1) * 16 + 4 * lg);
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float a = hacc[0][r][j] * p.u1 + b0[j];
-                        const float b = hacc[1][r][j] * p.u1 + b1v[j];
-                        v[j] = a > 0.f ? a : a * p.slope;
-                        v[4 + j] = b > 0.f ? b : b * p.slope;
-                    }
+                    const f32x4 ya = act4(hacc[0][r], p.u1, b0, p.slope), yb = act4(hacc[1][r], p.u1, b1v, p.slope);
+                    const float v[8] = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
                     split8(v, hh[r], hl[r]);
                 }
             }
@@ -441,14 +443,8 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
             {
                 const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b1s + (2 * t) * 16 + 4 * lg);
                 const f32x4 b1v = *reinterpret_cast<const f32x4 *>(b1s + (2 * t + 1) * 16 + 4 * lg);
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = hacc[0][0][j] * p.u1 + b0[j];
-                    const float b = hacc[1][0][j] * p.u1 + b1v[j];
-                    v[j] = a > 0.f ? a : a * p.slope;
-                    v[4 + j] = b > 0.f ? b : b * p.slope;
-                }
+                const f32x4 ya = act4(hacc[0][0], p.u1, b0, p.slope), yb = act4(hacc[1][0], p.u1, b1v, p.slope);
+                const float v[8] = {ya[0], ya[1], ya[2], ya[3], yb[0], yb[1], yb[2], yb[3]};
                 split8(v, hh[0], hl[0]);
             }
             f16x8 ah[CF], al[CF];
@@ -551,6 +547,7 @@ extern "C" int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream) {
     LSSVC_CHECK(C % 16 == 0 && C >= 32 && C <= 128, "ffn_f16x3: C = %d must be a multiple of 16 in [32, 128]", C);
     LSSVC_CHECK(d->hidden > 0 && d->hidden % 32 == 0, "ffn_f16x3: hidden = %d must be a positive multiple of 32", d->hidden);
     LSSVC_CHECK(d->w1_16 && d->w2_16 && d->b1 && d->b2, "ffn_f16x3: missing FFN weights");
+    LSSVC_CHECK(d->slope >= 0.0f && d->slope <= 1.0f, "ffn_f16x3: LeakyReLU slope %g outside [0, 1]", (double)d->slope);
     const bool pre = d->pre_w16 != nullptr;
     FfnP p{};
     p.out = mk(&d->out);
