@@ -452,6 +452,22 @@ class LSSVC_extend(_HostModel):
                 "encoder_side": {"ref_frame_bl": bl_e["recon"].to_nchw(), "ref_feature_bl": bl_e["feature"].to_nchw(),
                                  "ref_frame_el": recon_e.to_nchw(), "ref_feature_el": feature_e.to_nchw()}}
 
+    def decode(self, dpb, input_path_bl, input_path_el):
+        """Decoder only: reconstruct a P-frame from its two layer files and the previous frame's DPB (the decode half
+        of encode_decode_extend = DMCExtend.decompress dmc_net_extend.py:106-146 + LSSVC_extend.decompress
+        LSSVC_net_extend.py:88-136). Returns {"dpb": ...} like encode_decode."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        nhwc = lambda t: None if t is None else T.from_nchw(t)
+        ref_bl, ref_el = nhwc(dpb["ref_frame_bl"]), nhwc(dpb["ref_frame_el"])
+        feat_bl, feat_el = nhwc(dpb["ref_feature_bl"]), nhwc(dpb["ref_feature_el"])
+        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(input_path_bl)))
+        recon_bl = bl["recon"].to_nchw().clamp_(0, 1)                         # dmc_net_extend.py:138
+        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(input_path_el)))
+        return {"dpb": {"ref_frame_bl": recon_bl, "ref_feature_bl": bl["feature"].to_nchw(remember=True),
+                        "ref_frame_el": recon_el.to_nchw(remember=True), "ref_feature_el": feature.to_nchw(remember=True)}}
+
     def encode_decode(self, x_bl, x_el, dpb, output_path_bl=None, output_path_el=None,
                       pic_width=None, pic_height=None, pic_width_bl=None, pic_height_bl=None):
         """LSSVC.encode_decode (LSSVC_net.py:172-185). output_path_el None <=> estimate mode."""

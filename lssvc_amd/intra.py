@@ -262,6 +262,23 @@ class IntraSS(_HostModel):
                 "bit_bl_estimate": (est[0] + est[1]) / (-math.log(2)), "bit_el_estimate": (est[2] + est[3]) / (-math.log(2)),
                 "encoder_side": {"x_hat_bl": x_hat_bl_e.to_nchw(), "x_hat_el": x_hat_e.to_nchw(), "feature_el": feature_e.to_nchw()}}
 
+    def decode(self, bin_path_bl, bin_path_el):
+        """Decoder only: reconstruct an I-frame from its two layer files (the decode half of encode_decode above =
+        IntraNoAR.decompress priors.py:439-452 + IntraSS.decompress IntraSS.py:316-336). Needs set_scale_information()
+        and update() like the encoder; everything else comes from the streams (their headers carry the picture size).
+        Returns the same keys a caller builds the DPB from: x_hat_bl, x_hat_el, feature_el."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        h, w, y_string, z_string = bitstream.decode_i(bin_path_bl)
+        x_hat_bl, y_hat_bl = self._bl_codec(None, sources=(SymbolSource(y_string), SymbolSource(z_string)),
+                                            lat_hw=bitstream.get_downsampled_shape(h, w, 64))
+        h, w, y_string, z_string = bitstream.decode_i(bin_path_el)
+        feature, x_hat = self._el_codec(None, x_hat_bl, y_hat_bl, sources=(SymbolSource(y_string), SymbolSource(z_string)),
+                                        lat_hw=bitstream.get_downsampled_shape(h, w, 64))
+        return {"x_hat_bl": x_hat_bl.to_nchw(remember=True), "x_hat_el": x_hat.to_nchw(remember=True),
+                "feature_el": feature.to_nchw(remember=True)}
+
     def update(self, force=False):
         """IntraSS.update (IntraSS.py:234-237): build the CDF tables the real bitstream needs (test.py:561-564)."""
         if self._tables is not None and not force:

@@ -166,3 +166,51 @@ def test_symbol_and_index_planes_match_oracle():
             fold_s[:, :, r::2, c::2] = sh[:, ch * 32:(ch + 1) * 32, r::2, c::2]
         _agree(rec.items[3 + step][0], flat(fold_q), "y_w%d symbols" % step, tol=5e-3)
         _agree(rec.items[3 + step][1], flat(E.laplace_indexes(fold_s)), "y_w%d indexes" % step, tol=5e-3)
+
+
+def test_fresh_decoder_reconstructs_gop_from_files_only(tmp_path):
+    """A decoder that never saw the encoder: new model instances (same checkpoint) rebuild a 3-frame GOP from the .bin
+    files alone -- I-frame from its two streams, P-frames from theirs plus the decoder's OWN previous output -- and must
+    land bit-exactly on what the encoder side kept as its DPB (closed-loop coding diverges otherwise)."""
+    H = W = 128
+    frames = 3
+    inet, pnet = _nets(7, 0.6)
+    x_bl, x_el = _clip(frames, H, W, 7)
+    want, dpb = [], None
+    for t in range(frames):
+        pb, pe = str(tmp_path / ("bl_%d.bin" % t)), str(tmp_path / ("el_%d.bin" % t))
+        inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+        pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+        if t == 0:
+            r = inet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], pb, pe, H // 2, W // 2, H, W)
+            dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+        else:
+            dpb = pnet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], dpb, pb, pe, W, H, W // 2, H // 2)["dpb"]
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        want.append({k: (None if v is None else v.clone()) for k, v in dpb.items()})
+    del inet, pnet
+    dec_i, dec_p = _nets(7, 0.6)                                  # fresh instances: nothing carried over but the files
+    dpb = None
+    for t in range(frames):
+        pb, pe = str(tmp_path / ("bl_%d.bin" % t)), str(tmp_path / ("el_%d.bin" % t))
+        dec_i.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+        dec_p.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+        if t == 0:
+            r = dec_i.decode(pb, pe)
+            dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+        else:
+            dpb = dec_p.decode(dpb, pb, pe)["dpb"]
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        for k in ("ref_frame_bl", "ref_frame_el", "ref_feature_el"):
+            assert torch.equal(dpb[k], want[t][k]), (t, k)
+        if t > 0:
+            assert torch.equal(dpb["ref_feature_bl"], want[t]["ref_feature_bl"])
+    cut = str(tmp_path / "cut.bin")
+    with open(str(tmp_path / "el_1.bin"), "rb") as f:
+        data = f.read()
+    with open(cut, "wb") as f:
+        f.write(data[:len(data) // 2])
+    with pytest.raises(ValueError):                                # the framing notices a truncated stream
+        dec_p.decode(dpb, str(tmp_path / "bl_1.bin"), cut)
