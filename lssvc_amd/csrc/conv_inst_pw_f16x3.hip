@@ -19,6 +19,16 @@ int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name) {
         MF = mf_fit;
         if (big && mf_big > mf_fit) MF = mf_big < want ? mf_big : want;
     }
+    if (p.epilogue != LSSVC_EPI_NONE || p.in_act == LSSVC_INACT_SQUARE) {
+        // GDN / IGDN (square input, normalising epilogue): the generic streaming kernel with the GDN epilogue compiled in
+        if (MF > mf_fit) MF = mf_fit;
+        if (MF < 1) return fail("conv2d(pw f16x3): Cin too large for the LDS-resident weight tile");
+        snprintf(kernel_name, 96, "conv_pw_f16x3_kernel<%d, 2, true>", MF);
+        if (MF == 4) return launch_pw_f16x3<4, 2, true>(p, st);
+        if (MF == 3) return launch_pw_f16x3<3, 2, true>(p, st);
+        if (MF == 2) return launch_pw_f16x3<2, 2, true>(p, st);
+        return launch_pw_f16x3<1, 2, true>(p, st);
+    }
     static const int allm = getenv("LSSVC_PW_ALLM") ? atoi(getenv("LSSVC_PW_ALLM")) : 1;
     {   // small K and the whole weight matrix in LDS: convert the pixels once, loop the M tiles inside the wave
         int mf = frags < 4 ? frags : 4;

@@ -159,7 +159,8 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
             return ks == 3 ? dispatch_tile_f16x3<3, 1>(p, MF, RPW, st) : dispatch_tile_f16x3<7, 1>(p, MF, RPW, st);
         }
         // 1x1: streaming kernel with LDS-resident weights; GDN (square + normalise) stays on the exact path
-        if (vec && sd == 1 && ks == 1 && d->epilogue == LSSVC_EPI_NONE && ((chunks16 + 1) / 2) * 2 * 1024 <= kPwBigLds)
+        if (vec && sd == 1 && ks == 1 && ((chunks16 + 1) / 2) * 2 * 1024 <= kPwBigLds &&
+            (d->epilogue == LSSVC_EPI_NONE || ((chunks16 + 1) / 2) * 2 * 1024 <= kPwMaxLds))
             return dispatch_pw_f16x3(p, st, kname);
     }
     snprintf(kname, 96, "conv_mfma_kernel<%d, %d, %d, %d, %s>", MF, RPW, ks, sd, vec ? "true" : "false");

@@ -23,7 +23,7 @@ namespace lssvc {
 constexpr int kPwMaxLds = 64 * 1024;      // two workgroups per CU
 constexpr int kPwBigLds = 144 * 1024;     // one workgroup per CU: taken when it buys a larger M tile (fewer re-reads of X)
 
-template <int MF, int RPW>
+template <int MF, int RPW, bool GDN = false>
 __global__ __launch_bounds__(256, RPW == 1 ? 4 : 2) void conv_pw_f16x3_kernel(const ConvP p) {
     constexpr int TM = 16 * MF;
     extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];     // [plane hi|lo][chunk16 (padded to even)][TM][16]
@@ -163,11 +163,11 @@ __global__ __launch_bounds__(256, RPW == 1 ? 4 : 2) void conv_pw_f16x3_kernel(co
             }
         }
         conv_unscale<MF, RPW>(p, acc);
-        conv_epilogue_flat<MF, RPW, false>(p, acc, pix, m0, lg);
+        conv_epilogue_flat<MF, RPW, GDN>(p, acc, pix, m0, lg);
     }
 }
 
-template <int MF, int RPW>
+template <int MF, int RPW, bool GDN = false>
 static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
     ConvP q = p;
     q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
@@ -176,12 +176,12 @@ static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
     if (lds > (size_t)kPwBigLds) return fail("conv2d(pw f16x3): %zu bytes of weights do not fit LDS", lds);
     static size_t granted = 64 * 1024;
     if (lds > granted) {
-        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pw_f16x3_kernel<MF, RPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pw_f16x3_kernel<MF, RPW, GDN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         granted = lds;
     }
     static const int resident = [] {
         int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_pw_f16x3_kernel<MF, RPW>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_pw_f16x3_kernel<MF, RPW, GDN>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) == hipSuccess) {
             int v = 0;
             if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
@@ -196,7 +196,7 @@ static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
     const long long cap = res / q.m_tiles > 0 ? res / q.m_tiles : 1;
     if (per_m > cap) per_m = cap;
     const long long blocks = per_m * q.m_tiles;
-    hipLaunchKernelGGL((conv_pw_f16x3_kernel<MF, RPW>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    hipLaunchKernelGGL((conv_pw_f16x3_kernel<MF, RPW, GDN>), dim3((unsigned)blocks), dim3(256), lds, st, q);
     return launch_status("conv2d(pw f16x3)");
 }
 

@@ -232,14 +232,20 @@ _GDN_EPI = {("intra", False): _lib.EPI_X_MUL_RSQRT, ("intra", True): _lib.EPI_X_
             ("inter", False): _lib.EPI_X_DIV_SQRT, ("inter", True): _lib.EPI_X_MUL_SQRT}
 
 
+GDN_F16X3 = _os.environ.get("LSSVC_GDN_F16X3", "1") == "1"
+
+
 def gdn(W, name, x, flavour, inverse=False, *, residual=None, act=None, slope=0.01, out=None):
     """GDN / IGDN as a 1x1 conv on x^2 with the normalisation fused into the epilogue."""
     w_dev, b_dev, cout, m_pad, _, _ = W.gdn(name, flavour)
     if out is None:
         out = x.like()
+    w16 = None
+    if CONV_PRECISION == "f16x3" and GDN_F16X3 and x.C % 4 == 0 and x.ld % 4 == 0:
+        w16 = W.gdn_f16x3(name, flavour)
     return _conv_launch([x], (w_dev, b_dev, cout, m_pad), 1, 1, 1, 0, 0, out, in_act="square",
                         epilogue=_GDN_EPI[(flavour, inverse)], gdn_x=x, act=act, slope=slope, residual=residual,
-                        name=name)
+                        name=name, w16=w16)
 
 
 def dwconv3x3(W, name, x, out=None):

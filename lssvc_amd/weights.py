@@ -254,8 +254,14 @@ class WeightStore:
                 gamma = torch.max(gamma, torch.ones_like(gamma) * _REPARAM_OFFSET) ** 2 - _PEDESTAL
             c = gamma.shape[0]
             wp, bp, cout, m_pad = layout_conv(gamma.reshape(c, c, 1, 1), beta, [c], False)
+            planes, unscale = layout_conv_f16x3(gamma.reshape(c, c, 1, 1), [c], False)
             self._cache[key] = (self._dev(wp), self._dev(bp), cout, m_pad, 1, 1)
+            self._cache[("gdn16", name, flavour)] = (self._dev(planes), unscale)
         return self._cache[key]
+
+    def gdn_f16x3(self, name, flavour):
+        self.gdn(name, flavour)
+        return self._cache[("gdn16", name, flavour)]
 
     def vector(self, key):
         k = ("vec", key)

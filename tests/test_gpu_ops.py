@@ -127,8 +127,17 @@ def test_gdn(hip, flavour, inverse):
     r = torch.randn(1, c, 20, 28, generator=torch.Generator().manual_seed(6))
     fn = gdn_intra if flavour == "intra" else gdn_inter
     want = fn(x, Params(sd), "g", inverse=inverse) + r
-    got = back(hip.gdn(FakeW(sd), "g", nhwc(hip, x), flavour, inverse=inverse, residual=nhwc(hip, r)))
-    close(got, want, rtol=1e-5, atol=1e-5)
+    for mode in ("f32", "f16x3"):                     # the exact kernel, and GDN on the f16x3 streaming kernel
+        try:
+            hip.set_conv_precision(mode)
+            hip.OP_LOG = []
+            got = back(hip.gdn(FakeW(sd), "g", nhwc(hip, x), flavour, inverse=inverse, residual=nhwc(hip, r)))
+            kernel = hip.OP_LOG[-1]["kernel"]
+        finally:
+            hip.OP_LOG = None
+            hip.set_conv_precision("f32")
+        assert ("f16x3" in kernel) == (mode == "f16x3"), kernel
+        close(got, want, rtol=1e-5, atol=1e-5)
 
 
 def test_dwconv(hip):
