@@ -431,7 +431,7 @@ class LSSVC_extend(_HostModel):
         bit_bl = bitstream.filesize(output_path_bl) * 8
         sync(); t1 = time.time()
         bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(output_path_bl)))
-        recon_bl = bl["recon"].to_nchw().clamp_(0, 1)                         # dmc_net_extend.py:138
+        recon_bl = bl["recon"].to_nchw(copy=True).clamp_(0, 1)                         # dmc_net_extend.py:138
         sync(); t2 = time.time()
         # ---- enhancement layer ----
         sink = SymbolSink()
@@ -463,7 +463,7 @@ class LSSVC_extend(_HostModel):
         ref_bl, ref_el = nhwc(dpb["ref_frame_bl"]), nhwc(dpb["ref_frame_el"])
         feat_bl, feat_el = nhwc(dpb["ref_feature_bl"]), nhwc(dpb["ref_feature_el"])
         bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(input_path_bl)))
-        recon_bl = bl["recon"].to_nchw().clamp_(0, 1)                         # dmc_net_extend.py:138
+        recon_bl = bl["recon"].to_nchw(copy=True).clamp_(0, 1)                         # dmc_net_extend.py:138
         feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(input_path_el)))
         return {"dpb": {"ref_frame_bl": recon_bl, "ref_feature_bl": bl["feature"].to_nchw(remember=True),
                         "ref_frame_el": recon_el.to_nchw(remember=True), "ref_feature_el": feature.to_nchw(remember=True)}}

@@ -143,17 +143,24 @@ def test_config1_single_iframe_256(precision):
         np.testing.assert_allclose(got[k].cpu().numpy(), want[k].numpy(), atol=2e-4, rtol=0)
 
 
-def test_dpb_nhwc_cache_is_invalidated_by_in_place_edits():
-    """The NHWC view remembered for tensors handed to the caller (hip_ops.T.to_nchw(remember=True)) is reused only for
-    the same, unmodified tensor object: an in-place edit (test.py:249-250 clamps the frames) or a different tensor with
-    equal contents must be re-read."""
+def test_boundary_tensors_are_zero_copy_channels_last():
+    """What the model hands to the caller (hip_ops.T.to_nchw) is a channels_last view of its NHWC buffer: same storage,
+    NCHW shape. Handing it back costs no transpose, in-place edits by the caller (test.py:249-250 clamps the frames)
+    are seen, and a plain NCHW-contiguous tensor with equal contents still goes through the transpose."""
     from lssvc_amd.hip_ops import T
     x = torch.rand(1, 8, 6, 10, device=DEV) * 3 - 1
-    t = T.from_nchw(x)
-    y = t.to_nchw(remember=True)
-    assert T.from_nchw(y) is t                                  # untouched -> the remembered view
-    y.clamp_(0, 1)
+    t = T.from_nchw(x)                                          # NCHW-contiguous input: transposed once
+    y = t.to_nchw()
+    assert y.shape == x.shape and torch.equal(y, x) and y.is_contiguous(memory_format=torch.channels_last)
+    assert y.data_ptr() == t.buf.data_ptr()                     # no copy on the way out ...
     t2 = T.from_nchw(y)
-    assert t2 is not t and torch.equal(t2.to_nchw(), y)         # edited in place -> transposed again, sees the clamp
-    z = y.clone()
-    assert T.from_nchw(z) is not t2 and torch.equal(T.from_nchw(z).to_nchw(), z)
+    assert t2.buf.data_ptr() == t.buf.data_ptr()                # ... and none on the way back in
+    y.clamp_(0, 1)
+    assert torch.equal(T.from_nchw(y).to_nchw(), x.clamp(0, 1)) and torch.equal(t.to_nchw(), x.clamp(0, 1))
+    z = y.contiguous()                                          # an NCHW-contiguous copy takes the transpose path
+    tz = T.from_nchw(z)
+    assert tz.buf.data_ptr() != t.buf.data_ptr() and torch.equal(tz.to_nchw(), y)
+    c = t.to_nchw(copy=True)
+    assert c.is_contiguous() and c.data_ptr() != t.buf.data_ptr() and torch.equal(c, y)
+    s = t.slice(0, 4).to_nchw()                                 # a channel slice cannot be a dense view: copied
+    assert s.is_contiguous() and torch.equal(s, y[:, 0:4])
