@@ -164,3 +164,36 @@ def test_boundary_tensors_are_zero_copy_channels_last():
     assert c.is_contiguous() and c.data_ptr() != t.buf.data_ptr() and torch.equal(c, y)
     s = t.slice(0, 4).to_nchw()                                 # a channel slice cannot be a dense view: copied
     assert s.is_contiguous() and torch.equal(s, y[:, 0:4])
+
+
+def test_full_size_runs_are_bit_deterministic():
+    """BASELINE configs[1] shape (EL 1152x1920 / BL 576x960): an I-frame and a P-frame coded twice from the same inputs
+    must agree bit for bit (bits, reconstructions, features). The persistent / warp-specialised kernels hand data
+    between waves through LDS rings and barriers; a missing fence would show up here as run-to-run noise long before
+    it moved a PSNR."""
+    from lssvc_amd import IntraSS, LSSVC_extend
+    from lssvc_amd.preprocess import make_layers
+    from lssvc_amd.synth import synth_clip, synth_state_dict
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, 0.55)).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", 0, 0.55))
+    pnet.to(DEV).eval()
+    clip = synth_clip(2, 1080, 1920, seed=2).to(DEV).float() / 255.0
+    runs = []
+    for _ in range(2):
+        xb0, xe0, pad = make_layers(clip[0:1], 2.0)
+        xb1, xe1, _ = make_layers(clip[1:2], 2.0)
+        inet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))
+        pnet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))
+        ri = inet.encode_decode(xb0, xe0, None, None)
+        dpb = {"ref_frame_bl": ri["x_hat_bl"].clone().clamp_(0, 1), "ref_frame_el": ri["x_hat_el"].clone().clamp_(0, 1),
+               "ref_feature_bl": None, "ref_feature_el": ri["feature_el"]}
+        rp = pnet.encode_decode(xb1, xe1, dpb)
+        runs.append((ri["bit_bl"], ri["bit_el"], rp["bit_bl"], rp["bit_el"], ri["x_hat_el"].clone(), ri["feature_el"].clone(),
+                     rp["dpb"]["ref_frame_el"].clone(), rp["dpb"]["ref_feature_el"].clone(), rp["dpb"]["ref_feature_bl"].clone(),
+                     rp["mv_hat"].clone()))
+    a, b = runs
+    assert a[:4] == b[:4], (a[:4], b[:4])
+    for x, y in zip(a[4:], b[4:]):
+        assert torch.equal(x, y)
+    assert 0.0 < a[3] / (1152 * 1920) < 8.0                      # sane bpp
