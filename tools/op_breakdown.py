@@ -1,5 +1,5 @@
 """Per-layer conv time of P frames at the bench workload (debug/profiling aid): runs an I + N P frames with the
-op log on and prints total time per (layer name, shape, kernel)."""
+op log on (bench.encode_gop logs P-frames 1..8) and prints total time per (layer name, shape, kernel)."""
 import sys, collections, torch
 sys.path.insert(0, ".")
 import bench
@@ -14,10 +14,9 @@ x_bls, x_els, pad = bench.build_inputs(dev, 0, frames)
 with torch.no_grad():
     bench.encode_gop(inet, pnet, x_bls, x_els, pad["HR_padded_size"])
     torch.cuda.synchronize()
-    hip_ops.OP_LOG = []
-    bench.encode_gop(inet, pnet, x_bls[:1] + x_bls[1:], x_els, pad["HR_padded_size"])
+    log = []
+    bench.encode_gop(inet, pnet, x_bls, x_els, pad["HR_padded_size"], op_log=log)
     torch.cuda.synchronize()
-log, hip_ops.OP_LOG = hip_ops.OP_LOG, None
 agg = collections.OrderedDict()
 for e in log:
     ms = e["events"][0].elapsed_time(e["events"][1])
