@@ -98,7 +98,8 @@ const char *lssvc_conv2d_last_kernel(void);
 
 /* The per-pixel tail of a DepthConvBlock in one launch (f16x3 arithmetic; src/models/lssvc_modules.py:15-72):
  *     o1  = pre_w * pre_in + pre_bias + ident      (DepthConv.conv2 + identity/adaptor; skipped when pre_w16 == NULL: o1 = x)
- *     out = o1 + lrelu(w2 * lrelu(w1 * o1 + b1) + b2)                          (ConvFFN, both slopes = `slope`)
+ *     out = o1 + lrelu(w2 * lrelu(w1 * o1 + b1) + b2) [+ skip]                 (ConvFFN, both slopes = `slope`; `skip`,
+ *           when its ptr is not NULL, is an outer skip connection added last, e.g. lssvc_modules.py:363)
  * C = out.C in {32, 48, 64, 96, 128}; hidden %% 32 == 0; pre_in.C %% 8 == 0 and <= 128. Up to C = 64 / pre_in.C = 64
  * with all weights within the 160 KB LDS they stay resident; otherwise the hidden dimension is streamed through LDS in
  * 32-channel slices by LDS-DMA (lssvc_ffn_f16x3_lds_bytes gives the LDS either way; it must be <= 160 KB). Weight blobs are fp16 [hi plane | lo plane] images of w * 2^e in the fragment
@@ -120,6 +121,7 @@ typedef struct {
     const float *b2;
     float slope;
     lssvc_view out;
+    lssvc_view skip;   /* optional, same shape as out; may alias out */
 } lssvc_ffn_desc;
 int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream);
 int64_t lssvc_ffn_f16x3_lds_bytes(int32_t C, int32_t hidden, int32_t pre_cin);

@@ -45,7 +45,7 @@ class FfnDesc(C.Structure):
     _fields_ = [
         ("x", View), ("pre_in", View), ("pre_w16", C.c_void_p), ("pre_unscale", C.c_float), ("pre_bias", C.c_void_p),
         ("ident", View), ("w1_16", C.c_void_p), ("w1_unscale", C.c_float), ("b1", C.c_void_p), ("hidden", C.c_int32),
-        ("w2_16", C.c_void_p), ("w2_unscale", C.c_float), ("b2", C.c_void_p), ("slope", C.c_float), ("out", View),
+        ("w2_16", C.c_void_p), ("w2_unscale", C.c_float), ("b2", C.c_void_p), ("slope", C.c_float), ("out", View), ("skip", View),
     ]
 
 

@@ -37,9 +37,10 @@ def residual_block_upsample(W, p, x):
     return ops.gdn(W, p + ".igdn", t, "intra", inverse=True, residual=skip)
 
 
-def depth_conv_block(W, p, inputs, out=None):
+def depth_conv_block(W, p, inputs, out=None, skip=None):
     """DepthConvBlock (lssvc_modules.py:15-72). `inputs` may be a list (virtual concat) when the
-    block has a 1x1 adaptor (Cin != Cout); otherwise a single T (it is also the identity branch)."""
+    block has a 1x1 adaptor (Cin != Cout); otherwise a single T (it is also the identity branch).
+    `skip`: an outer skip connection added to the block's result (block(x) + skip), folded into the last launch."""
     q = p + ".block.0"
     if W.has(q + ".adaptor.weight"):
         ident = ops.conv(W, q + ".adaptor", inputs)
@@ -53,10 +54,12 @@ def depth_conv_block(W, p, inputs, out=None):
     f = p + ".block.1"
     if ops.ffn_fusable(W, f, q + ".conv2", ident.C, t.C):
         # conv2 + identity + the whole ConvFFN in one launch; the 4C-wide hidden tensor never reaches HBM
-        return ops.ffn_block(W, f, pre_name=q + ".conv2", pre_in=t, ident=ident, slope=0.1, out=out)
+        return ops.ffn_block(W, f, pre_name=q + ".conv2", pre_in=t, ident=ident, slope=0.1, out=out, skip=skip)
     o1 = ops.conv(W, q + ".conv2", t, residual=ident)
     t = ops.conv(W, f + ".conv.0", o1, act="lrelu", slope=0.1)
-    return ops.conv(W, f + ".conv.2", t, act="lrelu", slope=0.1, residual=o1, out=out)
+    if skip is None:
+        return ops.conv(W, f + ".conv.2", t, act="lrelu", slope=0.1, residual=o1, out=out)
+    return ops.add(ops.conv(W, f + ".conv.2", t, act="lrelu", slope=0.1, residual=o1), skip, out=out)
 
 
 def pyramid_extractor(W, p, f):

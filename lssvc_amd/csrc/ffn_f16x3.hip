@@ -24,7 +24,7 @@
 namespace lssvc {
 
 struct FfnP {
-    V x, pre_in, ident, out;
+    V x, pre_in, ident, out, skip;     // skip (optional): added to the block's result, e.g. the resamplers' outer skip connection
     const _Float16 *pre_w, *w1, *w2;     // each: [hi plane | lo plane], already in the LDS image order
     const float *pre_b, *b1, *b2;
     float pre_u, u1, u2, slope;
@@ -270,10 +270,13 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
                 if (pix[r] < 0) continue;
                 float4 o;
                 float v[4];
+                float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.skip.p) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)pix[r] * p.skip.ld + f * 16 + 4 * lg);
+                const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float a = oacc[f][r][j] * p.u2 + b[j];
-                    v[j] = o1[f][r][j] + (a > 0.f ? a : a * p.slope);
+                    v[j] = (o1[f][r][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
                 }
                 o = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4 *>(p.out.p + (size_t)pix[r] * p.out.ld + f * 16 + 4 * lg) = o;
@@ -463,10 +466,13 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
             if (f * 16 + 4 * lg >= C || !live) continue;
             const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
             float v[4];
+            float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.skip.p) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)q * p.skip.ld + f * 16 + 4 * lg);
+            const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = oacc[f][0][j] * p.u2 + b[j];
-                v[j] = o1[f][j] + (a > 0.f ? a : a * p.slope);
+                v[j] = (o1[f][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
             }
             *reinterpret_cast<float4 *>(p.out.p + (size_t)q * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -566,6 +572,12 @@ extern "C" int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream) {
         p.pre_in = mk_null();
         p.ident = mk_null();
         p.sa = 0;
+    }
+    if (d->skip.ptr) {
+        LSSVC_CHECK(view_ok(&d->skip) && vec4_ok(&d->skip) && same_shape(&d->skip, &d->out), "ffn_f16x3: bad skip view");
+        p.skip = mk(&d->skip);
+    } else {
+        p.skip = mk_null();
     }
     const int cf = C / 16, s = (cf + 1) / 2, t = d->hidden / 32;
     p.hidden = d->hidden;

@@ -323,7 +323,7 @@ def ffn_fusable(W, ffn_prefix, pre_name, c_out, pre_cin):
     return lib.lssvc_ffn_f16x3_lds_bytes(c_out, w1.shape[0], pre_cin if pre_name else 0) <= _FFN_LDS_LIMIT
 
 
-def ffn_block(W, ffn_prefix, *, x=None, pre_name=None, pre_in=None, ident=None, slope=0.1, out=None):
+def ffn_block(W, ffn_prefix, *, x=None, pre_name=None, pre_in=None, ident=None, slope=0.1, out=None, skip=None):
     """out = o1 + lrelu(conv.2(lrelu(conv.0(o1)))) with o1 = x, or o1 = pre_name(pre_in) + ident, in one launch
     (DepthConvBlock's per-pixel tail, lssvc_modules.py:38-72)."""
     rec = W.ffn_f16x3(ffn_prefix, pre_name)
@@ -341,6 +341,7 @@ def ffn_block(W, ffn_prefix, *, x=None, pre_name=None, pre_in=None, ident=None, 
     d.w2_16, d.w2_unscale, d.b2 = rec["w2"].data_ptr(), rec["u2"], rec["b2"].data_ptr()
     d.slope = slope
     d.out = out.v
+    d.skip = skip.v if skip is not None else _NULL_VIEW
     if OP_LOG is None:
         check(lib.lssvc_ffn_f16x3(C.byref(d), stream_ptr()))
         return out

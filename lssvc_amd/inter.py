@@ -159,8 +159,8 @@ class LSSVC_extend(_HostModel):
         """conv2 (conv-lrelu-conv) -> 2 DepthConvBlocks -> + skip (lssvc_modules.py:361-363,394-396,426-428)."""
         W = self.W
         up = ops.conv(W, p + ".conv2.2", ops.conv(W, p + ".conv2.0", up, act="lrelu"))
-        ref = B.depth_conv_block(W, p + ".feature_refine.1", B.depth_conv_block(W, p + ".feature_refine.0", up))
-        return ops.add(ref, up, out=out)
+        # feature_refine(up) + up: the outer skip rides on the second block's fused tail
+        return B.depth_conv_block(W, p + ".feature_refine.1", B.depth_conv_block(W, p + ".feature_refine.0", up), out=out, skip=up)
 
     def _mv_resampler(self, mv_bl):
         """MvResampler (lssvc_modules.py:339-365); the trailing `s * mv` is the last conv's output scale."""

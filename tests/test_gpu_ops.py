@@ -562,3 +562,23 @@ def test_narrow_inputs_take_the_f16x3_path(hip, cins, cout, k, stride):
     e16 = (out["f16x3"].double() - ref).abs().max().item()
     e32 = (out["f32"].double() - ref).abs().max().item()
     assert e16 <= 8 * e32 + 1e-6, (e16, e32)
+
+
+@pytest.mark.parametrize("c,hidden,H,W", [(64, 256, 21, 35), (128, 512, 11, 13)])
+def test_ffn_fused_outer_skip(hip, c, hidden, H, W):
+    """The optional `skip` operand of lssvc_ffn_f16x3 (block(x) + skip, lssvc_modules.py:363): equals the fused block
+    followed by a separate add, bit for bit, on both the resident and the streamed kernel; `out` may alias `skip`."""
+    g = torch.Generator().manual_seed(c + hidden)
+    sd = _ffn_weights(g, c, hidden, c)
+    Wt = FakeW(sd)
+    t, ident, skip = (torch.randn(1, c, H, W, generator=g) for _ in range(3))
+    try:
+        hip.set_conv_precision("f16x3")
+        plain = hip.ffn_block(Wt, "f", pre_name="p", pre_in=nhwc(hip, t), ident=nhwc(hip, ident))
+        want = back(hip.add(plain, nhwc(hip, skip)))
+        got = back(hip.ffn_block(Wt, "f", pre_name="p", pre_in=nhwc(hip, t), ident=nhwc(hip, ident), skip=nhwc(hip, skip)))
+        sk = nhwc(hip, skip)
+        inplace = back(hip.ffn_block(Wt, "f", pre_name="p", pre_in=nhwc(hip, t), ident=nhwc(hip, ident), skip=sk, out=sk))
+    finally:
+        hip.set_conv_precision("f32")
+    assert torch.equal(got, want) and torch.equal(inplace, want)
