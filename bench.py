@@ -218,6 +218,7 @@ def main():
     pnet.load_dict(synth_state_dict("lssvc_extend", 0, GAIN))
     pnet.to(device).eval()
 
+    hip_ops.reserve_device_memory(device)          # one hipMalloc up front instead of pool growth during the first GOPs
     t0 = time.time()
     x_bls, x_els, pad = build_inputs(device, seed=rank, frames=args.frames)   # each rank codes its own GOP
     shape_hr = pad["HR_padded_size"]

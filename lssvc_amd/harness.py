@@ -288,7 +288,9 @@ def _load_nets(job, device):
     """encode_one's model set-up (test.py:541-564), cached per worker process."""
     key = (job["i_path"], job["p_path"], job["force_intra"], job["write_stream"], str(device))
     if key not in _NETS:
-        from . import IntraSS, LSSVC_extend
+        from . import IntraSS, LSSVC_extend, hip_ops
+        if not _NETS:
+            hip_ops.reserve_device_memory(torch.device(device))
         sd = torch.load(job["i_path"], map_location="cpu")
         i_net = IntraSS.from_state_dict(sd.get("state_dict", sd) if isinstance(sd, dict) else sd).to(device).eval()
         p_net = None
