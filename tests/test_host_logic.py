@@ -136,3 +136,51 @@ def test_interlayer_padding_1080p():
     assert p["HR_padded_size"] == (1152, 1920) and p["LR_padded_size"] == (576, 960) and p["LR_size"] == (540, 960)
     p = interlayer_padding(1080, 1920, 1.5)
     assert p["HR_padded_size"][0] % 96 == 0 and p["LR_padded_size"][0] % 64 == 0
+
+
+def test_f16x3_layout_reconstructs_weights_and_prescales():
+    """layout_conv_f16x3: hi + lo (times the returned power-of-two unscale) gives the fp32 weights back to ~2^-21
+    relative, in the [chunk16][ky][kx][m][16] order, concat segments zero-padded to 16; the prescale keeps the lo plane
+    out of fp16's subnormal range for typical weight magnitudes."""
+    import math
+    from lssvc_amd.weights import layout_conv_f16x3
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(40, 24 + 8, 3, 3, generator=g) * 0.02
+    planes, unscale = layout_conv_f16x3(w, [24, 8], False)
+    assert planes.shape == (2, 3, 3, 3, 48, 16) and planes.dtype == torch.float16            # 24 -> 2 chunks, 8 -> 1 chunk; M 40 -> 48
+    assert math.log2(unscale) == round(math.log2(unscale)) and 2 ** 11 <= float(w.abs().max()) / unscale < 2 ** 12
+    rec = (planes[0].float() + planes[1].float()) * unscale                                  # [chunk][ky][kx][m][16]
+    seg0 = rec[0:2].permute(3, 0, 4, 1, 2).reshape(48, 32, 3, 3)[:40, :24]
+    seg1 = rec[2].permute(2, 3, 0, 1)[:40, :8]
+    assert (seg0 - w[:, :24]).abs().max() <= 2 ** -20 * w.abs().max() and (seg1 - w[:, 24:]).abs().max() <= 2 ** -20 * w.abs().max()
+    assert rec[0:2].permute(3, 0, 4, 1, 2).reshape(48, 32, 3, 3)[:, 24:].abs().max() == 0   # segment padding is zero
+    assert rec[:, :, :, 40:].abs().max() == 0                                                 # M padding is zero
+    lo = planes[1].float().abs()
+    assert (lo[lo > 0] >= 2.0 ** -14).float().mean() > 0.99                                  # lo parts are normal fp16 numbers
+
+
+def test_ffn_layout_chained_k_order():
+    """layout_ffn_f16x3 puts W1 / W2 in the K order in which ffn_f16x3.hip chains accumulator fragments into B
+    operands: K position (pair p, k = 8g + j) <-> channel 16 * (2p + (j >> 2)) + 4g + (j & 3)."""
+    from lssvc_amd.weights import layout_ffn_f16x3, layout_pw_natural_f16x3
+    g = torch.Generator().manual_seed(4)
+    c, hidden = 48, 192
+    w1 = torch.randn(hidden, c, 1, 1, generator=g) * 0.05
+    w2 = torch.randn(c, hidden, 1, 1, generator=g) * 0.05
+    (a, ua), (b, ub) = layout_ffn_f16x3(w1, w2)
+    t, cf, s = hidden // 32, c // 16, 2
+    A = ((a[:a.numel() // 2].float() + a[a.numel() // 2:].float()) * ua).reshape(t, 2, s, 16, 32)
+    B = ((b[:b.numel() // 2].float() + b[b.numel() // 2:].float()) * ub).reshape(t, cf, 16, 32)
+    for tt, f, ss, i, k in [(0, 0, 0, 0, 0), (5, 1, 1, 15, 31), (2, 1, 0, 7, 13), (3, 0, 1, 3, 5), (4, 1, 1, 9, 20)]:
+        gg, j = k // 8, k % 8
+        ic = (2 * ss + (j >> 2)) * 16 + 4 * gg + (j & 3)
+        want = w1[(2 * tt + f) * 16 + i, ic, 0, 0].item() if ic < c else 0.0
+        assert abs(A[tt, f, ss, i, k].item() - want) <= 1e-6
+    for tt, m, i, k in [(0, 0, 0, 0), (5, 2, 15, 31), (2, 1, 7, 13), (1, 0, 4, 22)]:
+        gg, j = k // 8, k % 8
+        hc = (2 * tt + (j >> 2)) * 16 + 4 * gg + (j & 3)
+        assert abs(B[tt, m, i, k].item() - w2[m * 16 + i, hc, 0, 0].item()) <= 1e-6
+    wp = torch.randn(48, 40, 1, 1, generator=g) * 0.05                                        # leading conv: natural K order, K padded to 64
+    blob, up = layout_pw_natural_f16x3(wp)
+    P = ((blob[:blob.numel() // 2].float() + blob[blob.numel() // 2:].float()) * up).reshape(3, 2, 16, 32)
+    assert abs(P[2, 1, 5, 3].item() - wp[37, 35, 0, 0].item()) <= 1e-6 and P[:, 1, :, 8:].abs().max() == 0
