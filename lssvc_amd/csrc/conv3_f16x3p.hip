@@ -6,15 +6,16 @@
 // same part at the same time, so the matrix pipe idles while they stage. Ablations on MI355X (3x3 64->64): loads
 // -19 %, conversion -8 %, fragment reads -7 %, epilogue -16 %, loop bookkeeping -26 %; the kernel ran at 215-255
 // TFLOP/s where a bare LDS-fed MFMA loop sustains ~620 (f16x3-equivalent; tools/probes/mfma_probe.hip).
-// Here the work is split by wave role, one workgroup of 8 waves per CU, persistent over 32x16-pixel x 16*MF-channel tiles:
-//   * waves 0-3, one per SIMD, are CONSUMERS: ds_read_b128 fragments + MFMA, nothing else, 8 pixel rows x MF channel
-//     fragments each (up to 128 accumulator registers); after a tile's last phase they run the fused epilogue;
-//   * waves 4-7, one per SIMD, are PRODUCERS: they fetch the next phase's 34x18x16-channel fp32 halo patch, apply the
+// Here the work is split by wave role, one workgroup of 8 waves per CU, persistent over (4*RPW)x16-pixel x 16*MF-channel
+// tiles (RPW = 6 rows per consumer by default: 24x16 pixels, 96 accumulator registers):
+//   * waves 0-3, one per SIMD, are CONSUMERS: ds_read_b128 fragments + MFMA, nothing else, RPW pixel rows x MF channel
+//     fragments each; after a tile's last phase they run the fused epilogue;
+//   * waves 4-7, one per SIMD, are PRODUCERS: they fetch the next phase's (4*RPW+2)x18x16-channel fp32 halo patch, apply the
 //     input activation, split it into fp16 hi/lo planes in LDS, and move the next phase's weights (already fp16 in LDS
 //     image order) global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write). Their VALU / VMEM issue
 //     slots interleave with the consumer's MFMAs on the same SIMD (an MFMA holds the issue port 8 of its 16 cycles);
 //     their memory latency is hidden by not being on the consumers' path at all.
-//   * both operand images are double-buffered in LDS (2 x (39 KB patch + 37 KB weights) = 152 KB): ONE workgroup
+//   * both operand images are double-buffered in LDS (2 x (30 KB patch + 37 KB weights) = 134 KB at RPW = 6): ONE workgroup
 //     barrier per phase (phase = one 16-channel chunk, all 9 taps), and the phase sequence runs on across tile
 //     boundaries, so tiles have no head or tail.
 // Arithmetic, operand order inside a K-step, accumulator layout and the fused epilogue are those of
@@ -24,13 +25,16 @@
 
 namespace lssvc {
 
+#ifndef LSSVC_P3_RPW
+#define LSSVC_P3_RPW 6      // rows per consumer wave (Makefile P3_RPW); even
+#endif
 constexpr int kP3Threads = 512;
 constexpr int kP3Consumers = 4;          // waves 0..3
 constexpr int kP3ProducerThreads = kP3Threads - 64 * kP3Consumers;
 
 template <int MF>
 struct P3Geom {
-    static constexpr int RPW = 8, TH = RPW * kP3Consumers, TM = 16 * MF;
+    static constexpr int RPW = LSSVC_P3_RPW, HALF = RPW / 2, TH = RPW * kP3Consumers, TM = 16 * MF;
     static constexpr int PH = TH + 2, PW = 18, NTAP = 9, NSTEP = 5;
     static constexpr int PATCH_HALFS = PH * PW * CK16;            // per plane
     static constexpr int PATCH_ITEMS = PH * PW * 4;               // float4 items
@@ -215,10 +219,10 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                f16x8 bh[4], bl[4];
+                f16x8 bh[G::HALF], bl[G::HALF];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wave * RPW + half * 4 + r;
+                for (int r = 0; r < G::HALF; ++r) {
+                    const int row = wave * RPW + half * G::HALF + r;
                     const int o = ((row + ky) * PW + li + kx) * CK16 + ch8;
                     bh[r] = *reinterpret_cast<const f16x8 *>(ph_ + o);
                     bl[r] = *reinterpret_cast<const f16x8 *>(pl_ + o);
@@ -230,18 +234,18 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
 #pragma unroll
                 for (int f = 0; f < MF; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[f][half * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][half * 4 + r], 0, 0, 0);
+                    for (int r = 0; r < G::HALF; ++r)
+                        acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][half * G::HALF + r], 0, 0, 0);
 #pragma unroll
                 for (int f = 0; f < MF; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[f][half * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][half * 4 + r], 0, 0, 0);
+                    for (int r = 0; r < G::HALF; ++r)
+                        acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][half * G::HALF + r], 0, 0, 0);
 #pragma unroll
                 for (int f = 0; f < MF; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[f][half * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][half * 4 + r], 0, 0, 0);
+                    for (int r = 0; r < G::HALF; ++r)
+                        acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][half * G::HALF + r], 0, 0, 0);
             }
         }
         __syncthreads();                                   // (B_k)
@@ -252,18 +256,18 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 // two passes of 4 rows: keeps the epilogue's prefetch registers + the 128 accumulators under the cap
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    f32x4 part[MF][4];
+                    f32x4 part[MF][G::HALF];
 #pragma unroll
                     for (int f = 0; f < MF; ++f)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) part[f][r] = acc[f][half * 4 + r];
-                    long long pix[4];
+                        for (int r = 0; r < G::HALF; ++r) part[f][r] = acc[f][half * G::HALF + r];
+                    long long pix[G::HALF];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int oy = oy0 + wave * RPW + half * 4 + r, ox = ox0 + li;
+                    for (int r = 0; r < G::HALF; ++r) {
+                        const int oy = oy0 + wave * RPW + half * G::HALF + r, ox = ox0 + li;
                         pix[r] = (oy < p.Hout && ox < p.Wout) ? (long long)oy * p.Wout + ox : -1;
                     }
-                    conv_epilogue_fast<MF, 4>(p, part, pix, m0, lg, p.w16_unscale);       // the dispatcher only sends p.fast_epi convs here
+                    conv_epilogue_fast<MF, G::HALF>(p, part, pix, m0, lg, p.w16_unscale);       // the dispatcher only sends p.fast_epi convs here
                 }
             }
 #pragma unroll
@@ -314,7 +318,7 @@ bool conv3_f16x3p_wanted(const ConvP &p) {
     if (!on || !p.fast_epi) return false;
     if (p.in_act == LSSVC_INACT_LRELU && !(p.in_slope >= 0.0f && p.in_slope <= 1.0f)) return false;   // max(x, s*x) form
     const int mf = p3_pick_mf(p.M_pad / 16);
-    const long long ntiles = (long long)((p.Wout + 15) / 16) * ((p.Hout + 31) / 32) * ((p.M_pad / 16 + mf - 1) / mf);
+    const long long ntiles = (long long)((p.Wout + 15) / 16) * ((p.Hout + 4 * LSSVC_P3_RPW - 1) / (4 * LSSVC_P3_RPW)) * ((p.M_pad / 16 + mf - 1) / mf);
     return ntiles >= min_tiles;
 }
 
