@@ -98,6 +98,8 @@ SIGNATURES = {
     "lssvc_rans_decoder_set_stream": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "lssvc_rans_decode_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, TP, C.c_void_p]),
     "lssvc_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lssvc_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
+    "lssvc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "lssvc_last_error": (C.c_char_p, []),
     "lssvc_version": (C.c_int, []),
 }

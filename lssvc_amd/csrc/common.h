@@ -1,6 +1,7 @@
 // Shared host/device helpers for liblssvc_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -48,5 +49,42 @@ inline V mk(const lssvc_view *v) { return V{v->ptr, v->H, v->W, v->C, v->ld}; }
 inline V mk_null() { return V{nullptr, 0, 0, 0, 0}; }
 
 constexpr int kReduceMaxBlocks = 1024;  // partial-sum slots in the reduction workspace
+
+// ---- per-device launch state. A process may drive several GPUs (one stream each); the CU count and the
+// dynamic-LDS grant of a kernel (hipFuncSetAttribute acts on the CURRENT device) are therefore cached per
+// device ordinal, not per process.
+constexpr int kMaxDevices = 16;
+inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+inline int device_cus() {
+    static std::atomic<int> cus[kMaxDevices];
+    const int d = current_device();
+    int v = cus[d].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    cus[d].store(v, std::memory_order_relaxed);
+    return v;
+}
+// One instance per kernel instantiation (a function-local static): raises the kernel's dynamic-LDS limit on the
+// current device when this launch needs more than was granted there so far (`base` = what needs no grant).
+struct LdsGrant {
+    std::atomic<size_t> granted[kMaxDevices];
+    int ensure(const void *fn, size_t bytes, size_t base = 0) {
+        const int d = current_device();
+        size_t g = granted[d].load(std::memory_order_relaxed);
+        if (g < base) g = base;
+        if (bytes <= g) return 0;
+        LSSVC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        granted[d].store(bytes, std::memory_order_relaxed);
+        return 0;
+    }
+};
+
+// runtime tuning switches (lssvc_set_option / environment), see conv_mfma.hip
+int option_get(int which);
+enum { OPT_P3_ON = 0, OPT_P3_MIN_TILES = 1, OPT_COUNT = 2 };
 
 }  // namespace lssvc

@@ -66,9 +66,11 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
 
     // ---- this workgroup's tiles: the XCD it runs on owns a contiguous range, its workgroups interleave inside it
     const int ntiles = p.tiles_x * p.tiles_y * p.m_tiles;
-    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
-    const int nb_x = ((int)gridDim.x - xcd + 7) >> 3;
-    const int tq = ntiles >> 3, tr = ntiles & 7;
+    // (grids smaller than 8 workgroups split the tiles into gridDim.x ranges instead of 8, so none is orphaned)
+    const int nx = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+    const int xcd = blockIdx.x % nx, kb = blockIdx.x / nx;
+    const int nb_x = ((int)gridDim.x - xcd + nx - 1) / nx;
+    const int tq = ntiles / nx, tr = ntiles % nx;
     const int t_begin = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int t_cnt = tq + (xcd < tr ? 1 : 0);
     const int n_it = kb < t_cnt ? (t_cnt - kb + nb_x - 1) / nb_x : 0;
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
 
         P3Phase ph{0, KState{0, 0, 0, 0}};
         fill(ph, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of this wave has landed (made explicit, see below)
         __syncthreads();                                   // (A) phase 0 is in buffer 0
         const int total = n_it * phases_per_tile;
         for (int k = 0; k < total; ++k) {
@@ -179,6 +182,9 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 ph = next_phase(ph);
                 fill(ph, (k + 1) & 1);                     // the consumers read buffer k & 1 meanwhile
             }
+            // LDS-DMA data is ordered for the consumers' ds_reads only by the issuing wave's vmcnt wait + a barrier;
+            // the compiler emits that wait today, this line makes it a property of the source
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                               // (B_k) buffer (k+1)&1 complete, buffer k&1 released
         }
         return;
@@ -283,16 +289,9 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
 template <int MF>
 static int launch_p3(const ConvP &p, hipStream_t st) {
     using G = P3Geom<MF>;
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
-        return 256;
-    }();
-    static bool attr_set = false;
-    if (!attr_set) {
-        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-        attr_set = true;
-    }
+    const int cus = device_cus();
+    static LdsGrant grant;
+    if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF>), G::LDS_BYTES)) return 1;
     ConvP q = p;
     q.tiles_x = (p.Wout + 15) / 16;
     q.tiles_y = (p.Hout + G::TH - 1) / G::TH;
@@ -313,8 +312,7 @@ static int p3_pick_mf(int frags) {
 // Worth it once every CU gets at least one 32x16 tile (measured on the bench workload: thresholds 256 / 512 / 1024 /
 // 2048 tiles give 14.0 / 13.9 / 13.6 / 13.5 frames/s).
 bool conv3_f16x3p_wanted(const ConvP &p) {
-    static const int on = getenv("LSSVC_F16X3_PERSIST") ? atoi(getenv("LSSVC_F16X3_PERSIST")) : 1;
-    static const int min_tiles = getenv("LSSVC_F16X3_PERSIST_MIN_TILES") ? atoi(getenv("LSSVC_F16X3_PERSIST_MIN_TILES")) : 256;
+    const int on = option_get(OPT_P3_ON), min_tiles = option_get(OPT_P3_MIN_TILES);
     if (!on || !p.fast_epi) return false;
     if (p.in_act == LSSVC_INACT_LRELU && !(p.in_slope >= 0.0f && p.in_slope <= 1.0f)) return false;   // max(x, s*x) form
     const int mf = p3_pick_mf(p.M_pad / 16);

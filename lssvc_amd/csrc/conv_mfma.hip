@@ -23,6 +23,21 @@
 
 namespace lssvc {
 
+// ---- runtime tuning switches: environment at first use, lssvc_set_option() afterwards ----------------
+static std::atomic<int> g_opt[OPT_COUNT];
+static std::atomic<bool> g_opt_set[OPT_COUNT];
+static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES"};
+static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles"};
+static const int kOptDefault[OPT_COUNT] = {1, 256};
+int option_get(int which) {
+    if (!g_opt_set[which].load(std::memory_order_acquire)) {
+        const char *e = getenv(kOptEnv[which]);
+        g_opt[which].store(e ? atoi(e) : kOptDefault[which], std::memory_order_relaxed);
+        g_opt_set[which].store(true, std::memory_order_release);
+    }
+    return g_opt[which].load(std::memory_order_relaxed);
+}
+
 static char *last_kernel_name() {
     static thread_local char name[96] = {0};
     return name;
@@ -49,6 +64,26 @@ static void pick_variant(const ConvP &p, int &MF, int &RPW) {
 using namespace lssvc;
 
 extern "C" const char *lssvc_conv2d_last_kernel(void) { return last_kernel_name(); }
+
+extern "C" int lssvc_set_option(const char *name, int32_t value) {
+    LSSVC_CHECK(name != nullptr, "set_option: null name");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, kOptName[i])) {
+            g_opt[i].store(value, std::memory_order_relaxed);
+            g_opt_set[i].store(true, std::memory_order_release);
+            return 0;
+        }
+    return fail("set_option: unknown option '%s'", name);
+}
+extern "C" int lssvc_get_option(const char *name, int32_t *value) {
+    LSSVC_CHECK(name != nullptr && value != nullptr, "get_option: null argument");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, kOptName[i])) {
+            *value = option_get(i);
+            return 0;
+        }
+    return fail("get_option: unknown option '%s'", name);
+}
 
 extern "C" int lssvc_conv2d_variant(int32_t Hout, int32_t Wout, int32_t M_pad, int32_t stride) {
     ConvP p;

@@ -174,20 +174,14 @@ static int launch_pw_f16x3(const ConvP &p, hipStream_t st) {
     const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
     const size_t lds = (size_t)2 * nslot * 16 * MF * CK16 * sizeof(_Float16);
     if (lds > (size_t)kPwBigLds) return fail("conv2d(pw f16x3): %zu bytes of weights do not fit LDS", lds);
-    static size_t granted = 64 * 1024;
-    if (lds > granted) {
-        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_pw_f16x3_kernel<MF, RPW, GDN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted = lds;
-    }
-    static const int resident = [] {
-        int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_pw_f16x3_kernel<MF, RPW, GDN>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        }
-        return per_cu * cus;
+    static LdsGrant grant;
+    if (grant.ensure(reinterpret_cast<const void *>(conv_pw_f16x3_kernel<MF, RPW, GDN>), lds, 64 * 1024)) return 1;
+    static const int per_cu = [] {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_pw_f16x3_kernel<MF, RPW, GDN>, 256, 0) != hipSuccess || v < 1) v = 1;
+        return v;
     }();
+    const int resident = per_cu * device_cus();
     const long long npix = (long long)p.Hout * p.Wout;
     const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
     long long per_m = (ngroups + 3) / 4;                                    // workgroups that have work, per M tile
@@ -354,11 +348,7 @@ static int launch_pwk_f16x3(const ConvP &p, hipStream_t st) {
     const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
     const size_t lds = (size_t)2 * nslot * 16 * MF * CK16 * sizeof(_Float16);
     if (lds > (size_t)kPwMaxLds) return fail("conv2d(pwk f16x3): %zu bytes of weights do not fit LDS", lds);
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
-        return 256;
-    }();
+    const int cus = device_cus();
     const long long npix = (long long)p.Hout * p.Wout;
     const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
     long long per_m = (ngroups + 3) / 4;
@@ -684,15 +674,12 @@ static int launch_pw_allm_f16x3(const ConvP &p, hipStream_t st) {
     const int nslot = ((p.n_chunks16 + 1) / 2) * 2;
     const size_t lds = (size_t)2 * nslot * q.m_tiles * 16 * MF * CK16 * sizeof(_Float16);
     if (lds > (size_t)kPwMaxLds || p.n_chunks16 > 4) return fail("conv2d(pw all-M f16x3): shape does not fit");
-    static const int resident = [] {
-        int per_cu = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_pw_allm_f16x3_kernel<MF, RPW>, 256, kPwMaxLds) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        }
-        return per_cu * cus;
+    static const int per_cu = [] {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_pw_allm_f16x3_kernel<MF, RPW>, 256, kPwMaxLds) != hipSuccess || v < 1) v = 1;
+        return v;
     }();
+    const int resident = per_cu * device_cus();
     const long long npix = (long long)p.Hout * p.Wout;
     const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
     long long blocks = (ngroups + 3) / 4;

@@ -213,16 +213,9 @@ static int launch_dwpre(const DwPreP &p, hipStream_t st) {
     constexpr int C = 16 * CF;
     constexpr size_t lds = (size_t)(TH + 2) * 18 * (C + 4) * 4 + (size_t)2 * (2 * NS) * C * CK16 * 2;
     static_assert(lds <= 160 * 1024, "dwpre tile does not fit LDS");
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
-        return 256;
-    }();
-    static bool attr_set = false;
-    if (!attr_set) {
-        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dwpre_f16x3_kernel<CF, NS, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    const int cus = device_cus();
+    static LdsGrant grant;
+    if (grant.ensure(reinterpret_cast<const void *>(dwpre_f16x3_kernel<CF, NS, TH>), lds)) return 1;
     DwPreP q = p;
     q.tiles_x = (p.out.W + 15) / 16;
     q.tiles_y = (p.out.H + TH - 1) / TH;

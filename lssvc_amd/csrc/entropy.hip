@@ -196,28 +196,31 @@ __global__ void bottleneck_kernel(V z, const float *__restrict__ P, V z_hat, V z
 }
 
 // ---- sigma -> table index --------------------------------------------------------------------------
+// sigma -> table index exactly as the reference computes it in fp32 (video_entropy_models.py:309-313):
+// (log(max(s, 1e-5)) - log_min) / step + add, clamp, truncate. The logarithm is taken in fp64 and rounded once:
+// that is the correctly rounded fp32 log, which ATen's CPU log returns for all but ~2e-4 of inputs, whereas the
+// device logf (1 ulp) differs from it for ~10 % of inputs -- and a 1-ulp difference next to a level boundary
+// changes the integer (the decoder of another implementation would then pick a different CDF).
+__device__ __forceinline__ int32_t sigma_index(float sigma, float log_min, float log_step, float add, int levels) {
+    const float s = fmaxf(sigma, 1e-5f);
+    float v = ((float)log((double)s) - log_min) / log_step + add;
+    v = fminf(fmaxf(v, 0.f), (float)(levels - 1));
+    return (int32_t)v;
+}
+
 __global__ void build_indexes_kernel(V sigma, float log_min, float log_step, float add, int levels, int32_t *idx_out,
                                      long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % sigma.C);
     const size_t pix = (size_t)(idx / sigma.C);
-    const float s = fmaxf(sigma.p[pix * sigma.ld + c], 1e-5f);
-    float v = (logf(s) - log_min) / log_step + add;
-    v = fminf(fmaxf(v, 0.f), (float)(levels - 1));
-    idx_out[pix * sigma.C + c] = (int32_t)v;
+    idx_out[pix * sigma.C + c] = sigma_index(sigma.p[pix * sigma.ld + c], log_min, log_step, add, levels);
 }
 
 
 // ---- symbol / index planes for the host coder (write_stream = 1) -------------------------------------
 // The host coder consumes flat NCHW-ordered int32 planes, exactly the order in which the reference flattens
 // its tensors (x.reshape(-1) of an NCHW tensor, video_entropy_models.py:234-236,315-319).
-__device__ __forceinline__ int32_t sigma_index(float sigma, float log_min, float log_step, float add, int levels) {
-    const float s = fmaxf(sigma, 1e-5f);
-    float v = (logf(s) - log_min) / log_step + add;
-    v = fminf(fmaxf(v, 0.f), (float)(levels - 1));
-    return (int32_t)v;
-}
 
 // chunk_of_mask < 0: plain export of a C-channel tensor. Otherwise the 4-step fold (LSSVC_net.py:432-442):
 // out channel j at 2x2 position m takes channel chunk_of_mask[m]*C4 + j of the C-channel inputs.

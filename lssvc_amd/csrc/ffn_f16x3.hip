@@ -352,6 +352,7 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
     if (my_passes == 0) return;
     const long long total = my_passes * T;
     issue_slice(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's LDS-DMA pieces have landed (explicit: see dma_fence note)
     __syncthreads();                                         // resident weights + slice 0 are in LDS
 
     long long g = 0;
@@ -458,6 +459,10 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
                 al[m] = *reinterpret_cast<const f16x8 *>(w2l + o);
             }
             mfma3<CF, 1>(oacc, ah, al, hh, hl);
+            // LDS-DMA data is ordered for other waves' ds_reads only by the ISSUING wave's vmcnt wait followed by a
+            // barrier. hipcc (ROCm 7.2) happens to emit that wait before s_barrier on its own; spelled out so a
+            // toolchain change cannot turn it into an LDS race.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                 // slice g consumed by everyone; slice g+1 has landed
             ++g;
         }
@@ -481,16 +486,9 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
 
 template <int CF, bool PRE>
 static int launch_ffn_stream(const FfnP &p, size_t lds, hipStream_t st) {
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
-        return 256;
-    }();
-    static size_t granted = 0;
-    if (lds > granted) {
-        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_stream_f16x3_kernel<CF, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted = lds;
-    }
+    const int cus = device_cus();
+    static LdsGrant grant;
+    if (grant.ensure(reinterpret_cast<const void *>(ffn_stream_f16x3_kernel<CF, PRE>), lds)) return 1;
     const long long npix = (long long)p.out.H * p.out.W;
     long long blocks = (npix + 127) / 128;
     if (blocks > cus) blocks = cus;
@@ -500,16 +498,9 @@ static int launch_ffn_stream(const FfnP &p, size_t lds, hipStream_t st) {
 
 template <int CF, bool PRE>
 static int launch_ffn(const FfnP &p, size_t lds, hipStream_t st) {
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
-        return 256;
-    }();
-    static size_t granted = 0;
-    if (lds > granted) {
-        LSSVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_f16x3_kernel<CF, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted = lds;
-    }
+    const int cus = device_cus();
+    static LdsGrant grant;
+    if (grant.ensure(reinterpret_cast<const void *>(ffn_f16x3_kernel<CF, PRE>), lds)) return 1;
     const long long npix = (long long)p.out.H * p.out.W;
     const long long ngroups = (npix + 31) / 32;
     long long blocks = (ngroups + kFfnThreads / 64 - 1) / (kFfnThreads / 64);

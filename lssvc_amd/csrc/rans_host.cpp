@@ -77,6 +77,18 @@ extern "C" int lssvc_rans_encode_with_indexes(void *h, const int32_t *symbols, c
     Encoder *e = static_cast<Encoder *>(h);
     e->syms.reserve(e->syms.size() + (size_t)n + 16);
     e->is_raw.reserve(e->is_raw.size() + (size_t)n + 16);
+    // an error part-way through a plane leaves the pending list as it was at entry (no half-appended plane)
+    struct Rollback {
+        Encoder *e;
+        size_t n0;
+        bool armed;
+        ~Rollback() {
+            if (armed) {
+                e->syms.resize(n0);
+                e->is_raw.resize(n0);
+            }
+        }
+    } rollback{e, e->syms.size(), true};
     for (int64_t i = 0; i < n; ++i) {
         const int32_t ci = indexes[i];
         LSSVC_CHECK(ci >= 0 && ci < t->n_cdfs, "rans_encode_with_indexes: index %d out of range [0,%d) at %lld", ci, t->n_cdfs,
@@ -93,10 +105,18 @@ extern "C" int lssvc_rans_encode_with_indexes(void *h, const int32_t *symbols, c
             raw = (uint32_t)(2 * ((int64_t)v - escape));
             v = escape;
         }
+        // a zero-width or out-of-range slot would wrap to a huge frequency and write a corrupt stream silently
+        // (the reference divides by zero in Rans64EncPut here): refuse it
+        LSSVC_CHECK(cdf[v] >= 0 && cdf[v + 1] > cdf[v] && cdf[v + 1] <= (1 << kProbBits),
+                    "rans_encode_with_indexes: cdf row %d is not strictly increasing within [0, 2^%d] at slot %d (%d, %d)", ci,
+                    (int)kProbBits, v, cdf[v], cdf[v + 1]);
         e->push((uint32_t)cdf[v], (uint32_t)(cdf[v + 1] - cdf[v]), false);
         if (v == escape) {
+            // (64-bit shifts: a 32-bit value with its top digit set needs 8 digits, and `raw >> 32` on a uint32_t is
+            // undefined -- on x86 it is `raw >> 0`, i.e. an endless loop. The reference has that hazard for
+            // |symbol - offset| >= 2^27, rans_interface.cpp:121-123; here such symbols code and decode correctly.)
             uint32_t digits = 0;
-            while ((raw >> (digits * kRawBits)) != 0) ++digits;
+            while (((uint64_t)raw >> (digits * kRawBits)) != 0) ++digits;
             uint32_t count = digits;                          // digit count, unary-ish in base 15
             while (count >= kRawMax) {
                 e->push(kRawMax, 1, true);
@@ -106,6 +126,7 @@ extern "C" int lssvc_rans_encode_with_indexes(void *h, const int32_t *symbols, c
             for (uint32_t j = 0; j < digits; ++j) e->push((raw >> (j * kRawBits)) & kRawMax, 1, true);
         }
     }
+    rollback.armed = false;
     return 0;
 }
 

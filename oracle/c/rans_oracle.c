@@ -113,7 +113,10 @@ void oracle_encode_with_indexes(void *h, const int32_t *symbols, const int32_t *
         push(e, (uint16_t)cdf[value], (uint16_t)(cdf[value + 1] - cdf[value]), 0);
         if (value == max_value) {
             int32_t n_bypass = 0;
-            while ((raw_val >> (n_bypass * BYPASS_PRECISION)) != 0) ++n_bypass;
+            /* 64-bit shift: the reference's 32-bit `raw_val >> 32` (rans_interface.cpp:121-123) is undefined for raw
+             * values with the top digit set (|symbol - offset| >= 2^27) and loops forever on x86; outside that range
+             * the two forms are identical */
+            while (((uint64_t)raw_val >> (n_bypass * BYPASS_PRECISION)) != 0) ++n_bypass;
             int32_t val = n_bypass;
             while (val >= MAX_BYPASS_VAL) { push(e, MAX_BYPASS_VAL, MAX_BYPASS_VAL + 1, 1); val -= MAX_BYPASS_VAL; }
             push(e, (uint16_t)val, (uint16_t)(val + 1), 1);

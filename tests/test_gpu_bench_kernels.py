@@ -1,0 +1,213 @@
+"""Parity of the kernel instantiations the BENCHMARK runs (round-1 verdict, "What's weak" 1).
+
+The dispatcher picks a kernel by tile count: conv3_f16x3p_kernel<MF> (persistent, warp-specialised) only for 3x3
+stride-1 convs with >= 256 tiles, the RPW = 4 instantiations of the tiled kernels only for grids of >= 512
+workgroups. The small shapes of test_gpu_ops.py never reach those, so every case here is sized to DISPATCH the
+kernel under test (asserted through the op log) and compared with an fp64 reference of the same op:
+max |err| of the f16x3 kernel <= 8x the exact-fp32 kernel's own error (the error budget of DESIGN.md section 9).
+A second set pins "persistent == tiled, bit for bit" by running the same launch with the dispatch threshold
+moved (lssvc_set_option)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lssvc_amd import hip_ops
+    return hip_ops
+
+
+def _W(sd):
+    from lssvc_amd.weights import WeightStore
+    return WeightStore(sd, torch.device(DEV))
+
+
+def nhwc(hip, x):
+    return hip.T.from_nchw(x.to(DEV))
+
+
+def back(t):
+    return t.to_nchw().cpu()
+
+
+def _set(name, value):
+    from lssvc_amd._lib import lib, check
+    check(lib.lssvc_set_option(name.encode(), value))
+
+
+def _get(name):
+    from lssvc_amd._lib import lib, check
+    v = C.c_int32()
+    check(lib.lssvc_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def _run(hip, mode, fn):
+    """fn() under conv precision `mode` with the op log on -> (result, kernel name of the last conv launch)."""
+    try:
+        hip.set_conv_precision(mode)
+        hip.OP_LOG = []
+        out = fn()
+        return out, hip.OP_LOG[-1]["kernel"]
+    finally:
+        hip.OP_LOG = None
+        hip.set_conv_precision("f32")
+
+
+# cins, cout, H, W, in_act, act, residual, pixel_shuffle, expected persistent instantiation
+P3_CASES = [
+    ([64], 64, 300, 340, None, None, False, False, 4),            # the dominant kernel of the bench
+    ([64], 64, 293, 331, "lrelu", "lrelu", True, False, 4),       # ResBlock.conv2 form, H % 24 != 0, W % 16 != 0
+    ([48], 48, 300, 340, "lrelu", "lrelu", False, False, 3),      # ResBlock.conv1 @ full resolution
+    ([48], 48, 301, 333, None, None, True, False, 3),
+    ([96], 48, 300, 340, None, None, False, False, 3),            # context_fusion conv1_out (two 48-ch inputs below)
+    ([48, 48], 48, 290, 350, None, None, False, False, 3),
+    ([64, 16], 48, 300, 340, None, None, False, False, 3),        # recon first_conv: 80 -> 48, two-input concat
+    ([128], 192, 170, 180, None, None, False, False, 4),          # 3 M tiles
+    ([128], 64, 300, 340, "lrelu", None, False, False, 4),
+    ([128], 256, 150, 170, None, "lrelu", False, True, 4),        # subpel: pixel-shuffle epilogue (conv2_up.0 form)
+    ([96], 256, 130, 170, None, None, False, True, 4),
+    ([32], 32, 300, 340, None, "relu", False, False, 2),
+    ([16], 16, 300, 340, None, None, True, False, 1),
+    ([192], 96, 200, 260, None, "lrelu", False, False, 3),        # res_encoder.res2.conv1 form
+]
+
+
+@pytest.mark.parametrize("cins,cout,H,W,in_act,act,residual,shuffle,mf", P3_CASES)
+def test_persistent_3x3_matches_fp64(hip, cins, cout, H, W, in_act, act, residual, shuffle, mf):
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, H, W)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(1, cout, H, W, generator=g) if residual else None
+    x64 = torch.cat(xs, 1).double()
+    if in_act == "lrelu":
+        x64 = F.leaky_relu(x64, 0.1)
+    ref = F.conv2d(x64, w.double(), b.double(), padding=1)
+    if shuffle:
+        ref = F.pixel_shuffle(ref, 2)
+    if act == "lrelu":
+        ref = F.leaky_relu(ref, 0.01)
+    elif act == "relu":
+        ref = F.relu(ref)
+    if residual:
+        ref = ref + r.double()
+    name = "s.0" if shuffle else "c"
+    Wt = _W({name + ".weight": w, name + ".bias": b})
+
+    def launch():
+        kw = dict(in_act=in_act, in_slope=0.1, act=act, slope=0.01, residual=nhwc(hip, r) if residual else None)
+        ins = [nhwc(hip, x) for x in xs]
+        return back(hip.subpel(Wt, "s", ins, **kw) if shuffle else hip.conv(Wt, "c", ins, **kw))
+
+    got16, k16 = _run(hip, "f16x3", launch)
+    got32, k32 = _run(hip, "f32", launch)
+    assert k16 == "conv3_f16x3p_kernel<%d>" % mf, k16                 # really the persistent kernel
+    assert k32.startswith("conv_mfma_kernel"), k32
+    assert got16.shape == ref.shape
+    e16 = (got16.double() - ref).abs().max().item()
+    e32 = (got32.double() - ref).abs().max().item()
+    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
+    # and a second, kernel-independent bar: fp32-class absolute accuracy
+    assert e16 <= 2e-5 * max(1.0, ref.abs().max().item()), e16
+
+
+@pytest.mark.parametrize("cins,cout,H,W,in_act,act,residual,shuffle,mf", P3_CASES[:2] + P3_CASES[4:7] + P3_CASES[9:10])
+def test_persistent_3x3_is_bit_identical_to_tiled(hip, cins, cout, H, W, in_act, act, residual, shuffle, mf):
+    """DESIGN section 10 claims the persistent kernel reproduces the tiled kernel bit for bit (same K order inside a
+    step, same accumulator layout, same epilogue). Pinned here by running one launch under both dispatch decisions."""
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, H)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(1, cout, H, W, generator=g) if residual else None
+    name = "s.0" if shuffle else "c"
+    Wt = _W({name + ".weight": w, name + ".bias": b})
+
+    def launch():
+        kw = dict(in_act=in_act, in_slope=0.1, act=act, slope=0.01, residual=nhwc(hip, r) if residual else None)
+        ins = [nhwc(hip, x) for x in xs]
+        return back(hip.subpel(Wt, "s", ins, **kw) if shuffle else hip.conv(Wt, "c", ins, **kw))
+
+    old = _get("f16x3_persist")
+    try:
+        _set("f16x3_persist", 1)
+        a, ka = _run(hip, "f16x3", launch)
+        _set("f16x3_persist", 0)
+        b_, kb = _run(hip, "f16x3", launch)
+    finally:
+        _set("f16x3_persist", old)
+    assert ka.startswith("conv3_f16x3p_kernel") and kb.startswith("conv_f16x3_kernel"), (ka, kb)
+    assert torch.equal(a, b_)
+
+
+def test_persistent_3x3_small_grids(hip):
+    """Grids with fewer than 8 workgroups (tile ranges keyed by blockIdx & 7 left tiles uncomputed): force
+    the persistent kernel onto convs with 1..7 tiles and compare with the tiled kernel."""
+    old_min, old_on = _get("f16x3_persist_min_tiles"), _get("f16x3_persist")
+    try:
+        for H, W, cout in ((24, 16, 64), (24, 48, 64), (48, 48, 64), (30, 70, 48), (24, 16, 128), (50, 20, 16)):
+            g = torch.Generator().manual_seed(H * W + cout)
+            x = torch.randn(1, 64, H, W, generator=g)
+            w = torch.randn(cout, 64, 3, 3, generator=g) / 24
+            b = torch.randn(cout, generator=g)
+            Wt = _W({"c.weight": w, "c.bias": b})
+            _set("f16x3_persist", 1)
+            _set("f16x3_persist_min_tiles", 1)
+            a, ka = _run(hip, "f16x3", lambda: back(hip.conv(Wt, "c", nhwc(hip, x))))
+            _set("f16x3_persist", 0)
+            b_, kb = _run(hip, "f16x3", lambda: back(hip.conv(Wt, "c", nhwc(hip, x))))
+            assert ka.startswith("conv3_f16x3p_kernel") and kb.startswith("conv_f16x3_kernel"), (ka, kb)
+            assert torch.equal(a, b_), (H, W, cout)
+    finally:
+        _set("f16x3_persist_min_tiles", old_min)
+        _set("f16x3_persist", old_on)
+
+
+# ---- RPW = 4 instantiations of the tiled f16x3 kernels (7x7 SpyNet convs; 3x3 with 2-3 output channels) -----------
+TILED_CASES = [
+    # cins, cout, k, H, W, act, residual, expected kernel
+    ([8], 32, 7, 384, 400, "relu", False, "conv_f16x3_kernel<2, 4, 7, 1>"),       # moduleBasic.conv1
+    ([32], 64, 7, 260, 520, "relu", False, "conv_f16x3_kernel<4, 4, 7, 1>"),      # conv2
+    ([64], 32, 7, 260, 520, "relu", False, "conv_f16x3_kernel<2, 4, 7, 1>"),      # conv3 (2.4 % of a P-frame each)
+    ([32], 16, 7, 384, 400, "relu", False, "conv_f16x3_kernel<1, 4, 7, 1>"),      # conv4
+    ([16], 2, 7, 384, 400, None, True, "conv_f16x3_kernel<1, 4, 7, 1>"),          # conv5 + flow residual
+    ([64], 2, 3, 384, 400, None, False, "conv_f16x3_kernel<1, 4, 3, 1>"),         # mv_resampler.recon_conv / weight maps
+    ([48], 3, 3, 384, 400, None, False, "conv_f16x3_kernel<1, 4, 3, 1>"),         # recon_conv
+]
+
+
+@pytest.mark.parametrize("cins,cout,k,H,W,act,residual,kernel", TILED_CASES)
+def test_tiled_rpw4_matches_fp64(hip, cins, cout, k, H, W, act, residual, kernel):
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, k, H)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(1, cout, H, W, generator=g) if residual else None
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double(), padding=k // 2)
+    if act == "relu":
+        ref = F.relu(ref)
+    if residual:
+        ref = ref + r.double()
+    Wt = _W({"c.weight": w, "c.bias": b})
+
+    def launch():
+        return back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], act=act, residual=nhwc(hip, r) if residual else None))
+
+    got16, k16 = _run(hip, "f16x3", launch)
+    got32, _ = _run(hip, "f32", launch)
+    assert k16 == kernel, k16
+    e16 = (got16.double() - ref).abs().max().item()
+    e32 = (got32.double() - ref).abs().max().item()
+    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
+    assert e16 <= 2e-5 * max(1.0, ref.abs().max().item()), e16
