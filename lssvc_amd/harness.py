@@ -12,7 +12,10 @@ scripts keep working. What is different, deliberately:
   * work is sharded at GOP granularity, not per sequence (a GOP restarts from an I-frame with no carried state,
     test.py:219-227, so results are identical): with --worker 8 a single 96-frame sequence keeps 3 GPUs busy instead of
     1, and `--worker N` processes are pinned `process_idx % gpu_num` exactly like test.py:648-656;
-  * MS-SSIM (pytorch_msssim, absent here and out of scope per SURVEY section 2) is reported as 0.0.
+  * MS-SSIM (pytorch_msssim, absent here and out of scope per SURVEY section 2) is not computed: every *_msssim field is
+    written as JSON null, so a script that plots it fails loudly instead of silently consuming zeros;
+  * encoder-side RDO and the MV / warp-frame / context PNG dumps are not built: their flags parse (command lines written
+    for test.py keep working) but switching one on is an error.
 There is no CPU mode: --cuda must be on.
 """
 import argparse
@@ -57,6 +60,15 @@ def parse_args(argv=None):
     p.add_argument("--intra_rdo", type=str2bool, nargs="?", const=True, default=False)
     p.add_argument("--inter_mv_rdo", type=str2bool, nargs="?", const=True, default=False)
     p.add_argument("--inter_feature_rdo", type=str2bool, nargs="?", const=True, default=False)
+    # accepted for command-line compatibility (test.py:45-56); they only parameterise the encoder-side RDO, which is off
+    p.add_argument("--intra_lmbda", type=float, nargs="+")
+    p.add_argument("--intra_rdo_iter_to_exit", type=int, default=60)
+    p.add_argument("--intra_rdo_iter_to_reduce", type=int, default=20)
+    p.add_argument("--inter_lmbda", type=float, nargs="+")
+    p.add_argument("--inter_mv_rdo_iter_to_exit", type=int, default=60)
+    p.add_argument("--inter_mv_rdo_iter_to_reduce", type=int, default=20)
+    p.add_argument("--inter_feature_rdo_iter_to_exit", type=int, default=60)
+    p.add_argument("--inter_feature_rdo_iter_to_reduce", type=int, default=20)
     p.add_argument("--model_path", type=str, nargs="+")
     p.add_argument("--model_name", type=str, default="LSSVC_net")
     p.add_argument("--test_config", type=str, required=True)
@@ -67,12 +79,22 @@ def parse_args(argv=None):
     p.add_argument("--stream_path", type=str, default="out_bin")
     p.add_argument("--save_decoded_frame", type=str2bool, default=False)
     p.add_argument("--decoded_frame_path", type=str, default="decoded_frames")
+    # dump options of test.py:67-73 other than decoded frames: accepted, must stay off (MV / warp / context PNG dumps)
+    p.add_argument("--save_decoded_mv", type=str2bool, default=False)
+    p.add_argument("--save_warp_frame", type=str2bool, default=False)
+    p.add_argument("--save_decoded_context", type=str2bool, default=False)
+    p.add_argument("--decoded_mv_path", type=str, default="decoded_mv")
+    p.add_argument("--warp_frame_path", type=str, default="warp_frame")
+    p.add_argument("--decoded_context_path", type=str, default="decoded_context")
+    p.add_argument("--decoding_profiling", type=str2bool, default=False)
     p.add_argument("--output_path", type=str, required=True)
     p.add_argument("--verbose", type=int, default=0)
     p.add_argument("--precision", type=str, default=None, choices=[None, "f16x3", "f32"], help="conv arithmetic (DESIGN.md 9)")
     args = p.parse_args(argv)
     if args.intra_rdo or args.inter_mv_rdo or args.inter_feature_rdo:
         p.error("encoder-side RDO is not part of the hot path this build covers")
+    if args.save_decoded_mv or args.save_warp_frame or args.save_decoded_context:
+        p.error("only --save_decoded_frame is supported (MV / warp-frame / context dumps are debugging aids outside the hot path)")
     if args.force_intra:
         args.model_path = args.i_frame_model_path
     if not args.model_path:
@@ -230,15 +252,15 @@ def aggregate(records, pix_bl, pix_el, test_time):
             out["ave_%s_frame_rgb_psnr" % name] = tot(rs, lambda r: r["rgb_psnr_" + tag]) / k if k else 0
             if not fl:
                 out["ave_%s_frame_YUV_psnr" % name] = [tot(rs, lambda r, c=c: r["yuv_" + tag][c]) / k if k else 0 for c in range(3)]
-            out["ave_%s_frame_msssim" % name] = 0.0
-            out["ave_%s_frame_rgb_msssim" % name] = 0.0
+            out["ave_%s_frame_msssim" % name] = None          # not computed (below): null, so RD scripts fail loudly
+            out["ave_%s_frame_rgb_msssim" % name] = None
         out["ave_all_frame_bpp"] = tot(records, bits) / (n * pix)
         out["ave_all_frame_psnr"] = tot(records, yuv) / n
         out["ave_all_frame_rgb_psnr"] = tot(records, lambda r: r["rgb_psnr_" + tag]) / n
         if not fl:
             out["ave_all_frame_YUV_psnr"] = [tot(records, lambda r, c=c: r["yuv_" + tag][c]) / n for c in range(3)]
-        out["ave_all_frame_msssim"] = 0.0
-        out["ave_all_frame_rgb_msssim"] = 0.0
+        out["ave_all_frame_msssim"] = None
+        out["ave_all_frame_rgb_msssim"] = None
         kp = max(len(p_rec), 1)
         if fl:
             out["encoding_time"] = tot(p_rec, lambda r: r["enc_bl"] + r["enc_el"]) / kp
@@ -276,7 +298,8 @@ def build_jobs(args, config):
                                      "i_path": args.i_frame_model_path[model_idx], "p_path": args.model_path[model_idx],
                                      "force_intra": args.force_intra, "write_stream": args.write_stream,
                                      "bin_folder": os.path.join(args.stream_path, seq, str(model_idx)) if args.write_stream else None,
-                                     "png_folder": os.path.join(args.decoded_frame_path, seq, str(model_idx)) if args.save_decoded_frame else None,
+                                     "png_folder": os.path.join("%s_%s_LSSVC" % (args.decoded_frame_path, args.i_frame_model_name), seq,
+                                                                str(model_idx)) if args.save_decoded_frame else None,     # test.py:577-579,727-728
                                      "precision": args.precision})
     return jobs
 

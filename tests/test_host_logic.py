@@ -184,3 +184,28 @@ def test_ffn_layout_chained_k_order():
     blob, up = layout_pw_natural_f16x3(wp)
     P = ((blob[:blob.numel() // 2].float() + blob[blob.numel() // 2:].float()) * up).reshape(3, 2, 16, 32)
     assert abs(P[2, 1, 5, 3].item() - wp[37, 35, 0, 0].item()) <= 1e-6 and P[:, 1, :, 8:].abs().max() == 0
+
+
+def test_framing_matches_reference_fixture(tmp_path):
+    """tests/golden/framing.json was written by the reference's own stream_helper.py (make_framing_golden.py imports it
+    from /root/reference): our framing must produce the same file bytes from the same strings, parse the reference's
+    files back, and agree on get_downsampled_shape."""
+    import json
+    from lssvc_amd import bitstream as B
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "framing.json")))
+    assert len(fx["i_frames"]) >= 5 and len(fx["p_frames"]) >= 4 and len(fx["shapes"]) >= 10
+    p = str(tmp_path / "f.bin")
+    for c in fx["i_frames"]:
+        y, z, want = bytes.fromhex(c["y"]), bytes.fromhex(c["z"]), bytes.fromhex(c["file"])
+        B.encode_i(c["height"], c["width"], y, z, p)
+        assert open(p, "rb").read() == want
+        with open(p, "wb") as f:
+            f.write(want)
+        assert B.decode_i(p) == (c["height"], c["width"], y, z) and B.filesize(p) == len(want)
+    for c in fx["p_frames"]:
+        s, want = bytes.fromhex(c["string"]), bytes.fromhex(c["file"])
+        B.encode_p(s, p)
+        assert open(p, "rb").read() == want
+        assert B.decode_p(p) == s
+    for c in fx["shapes"]:
+        assert list(B.get_downsampled_shape(*c["args"])) == c["out"]
