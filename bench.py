@@ -7,8 +7,10 @@
 
 One "step" = one GOP (32 frames) per rank. GOPs are independent (each restarts from an I-frame), so
 ranks shard GOPs with no data-path collective ("weak" scaling: one GOP per GPU per step); the only
-communication is the barrier / max-reduce of the timing. Inputs (padded EL + BL frames) are resident
-in HBM before the timed region. Prints ONE JSON line on rank 0.
+communication is the barrier / max-reduce of the timing. `value` is measured with the inputs (padded EL + BL
+frames) resident in HBM before the timed region; a second, shorter timed loop repeats the GOP with everything
+BASELINE.md section 3 counts on the GPU side -- per-frame H2D of the 8-bit frame from pinned host memory, u8 -> fp32,
+padding, the bicubic base layer -- and is reported beside it as `h2d_inclusive`. Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -38,16 +40,34 @@ def log(*a):
 
 
 def build_inputs(device, seed, frames):
+    """-> (BL frames, EL frames, padding info, the 8-bit host clip in pinned memory)."""
     from lssvc_amd.synth import synth_clip
     from lssvc_amd.preprocess import make_layers
-    clip = synth_clip(frames, HEIGHT, WIDTH, seed=seed)
+    clip = synth_clip(frames, HEIGHT, WIDTH, seed=seed).pin_memory()
     x_els, x_bls = [], []
     for t in range(frames):
         rgb = (clip[t:t + 1].to(device).float() / 255.0)
         x_bl, x_el, pad = make_layers(rgb, RATIO)
         x_els.append(x_el.contiguous())
         x_bls.append(x_bl.contiguous())
-    return x_bls, x_els, pad
+    return x_bls, x_els, pad, clip
+
+
+class HostFrames:
+    """Frame source of the h2d-inclusive loop: frame t is copied up from pinned host memory (8-bit RGB, 6.2 MB),
+    converted and split into the two layers on the device, every time it is asked for (test.py:185-199)."""
+
+    def __init__(self, clip_u8, device):
+        self.clip, self.device = clip_u8, device
+
+    def __len__(self):
+        return self.clip.shape[0]
+
+    def layers(self, t):
+        from lssvc_amd.preprocess import make_layers
+        rgb = self.clip[t:t + 1].to(self.device, non_blocking=True).float().div_(255.0)
+        x_bl, x_el, _ = make_layers(rgb, RATIO)
+        return x_bl, x_el
 
 
 EVENT_FRAMES = 8      # per-launch HIP events are sampled on P-frames 1..8 of the last timed GOP only: the event markers cost
@@ -55,22 +75,25 @@ EVENT_FRAMES = 8      # per-launch HIP events are sampled on P-frames 1..8 of th
 #                       P-frames, so this is the GOP's launch mix) already hold >650 launches of the dominant kernel
 
 
-def encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log=None):
+def encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log=None, host_frames=None):
     """test.py's frame loop (test.py:182-250) for one GOP: I-frame, then P-frames chained through the DPB.
-    op_log: list that receives the per-launch records (with HIP events) of P-frames 1..EVENT_FRAMES."""
+    op_log: list that receives the per-launch records (with HIP events) of P-frames 1..EVENT_FRAMES.
+    host_frames: a HostFrames -- take every frame from host memory instead of the resident x_bls / x_els."""
     from lssvc_amd import hip_ops
     bits = []
     dpb = None
-    for t in range(len(x_els)):
+    n = len(host_frames) if host_frames is not None else len(x_els)
+    for t in range(n):
         hip_ops.OP_LOG = op_log if (op_log is not None and 1 <= t <= EVENT_FRAMES) else None
         inet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
         pnet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
+        x_bl, x_el = host_frames.layers(t) if host_frames is not None else (x_bls[t], x_els[t])
         if t == 0:
-            r = inet.encode_decode(x_bls[t], x_els[t], None, None)
+            r = inet.encode_decode(x_bl, x_el, None, None)
             dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None,
                    "ref_feature_el": r["feature_el"]}
         else:
-            r = pnet.encode_decode(x_bls[t], x_els[t], dpb)
+            r = pnet.encode_decode(x_bl, x_el, dpb)
             dpb = r["dpb"]
         dpb["ref_frame_bl"].clamp_(0, 1)
         dpb["ref_frame_el"].clamp_(0, 1)
@@ -151,22 +174,13 @@ def pmc_traffic(kernel):
     return None
 
 
-def cpu_baseline():
-    """The CPU oracle (a port of the reference's PyTorch CPU path, pinned bit-exact to it) timed on this
-    box's host cores on a bounded sample: 1 I + 1 P frame at EL 384x640 / BL 192x320 = 1/9 of the
-    1152x1920 workload's pixels; conv work is linear in pixels, so frames/s is scaled by 1/9."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+def _oracle_frames(H, W, threads):
+    """Seconds the CPU oracle takes for one I-frame and one (first) P-frame at EL HxW / BL (H/2)x(W/2)."""
     from lssvc_oracle.intra import intra_forward
     from lssvc_oracle.inter import inter_forward
     from lssvc_amd.synth import synth_state_dict, synth_clip
     from lssvc_amd.preprocess import imresize_bicubic
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
-    cores = max(1, min(cores, 16))
-    torch.set_num_threads(cores)
-    H, W = 384, 640
+    torch.set_num_threads(threads)
     sd_i, sd_p = synth_state_dict("intra_ss", 0, GAIN), synth_state_dict("lssvc_extend", 0, GAIN)
     clip = synth_clip(2, H, W, seed=0).float() / 255.0
     x_bl = imresize_bicubic(clip, (H // 2, W // 2)).clamp_(0, 1)
@@ -176,14 +190,41 @@ def cpu_baseline():
         t_i = time.time() - t0
         dpb = {"ref_frame_bl": o["x_hat_bl"].clamp_(0, 1), "ref_frame_el": o["x_hat_el"].clamp_(0, 1),
                "ref_feature_bl": None, "ref_feature_el": o["feature_el"]}
+        del o
         t0 = time.time()
         inter_forward(sd_p, x_bl[1:2], clip[1:2], dpb, (H, W), RATIO)
         t_p = time.time() - t0
+    return t_i, t_p
+
+
+def cpu_baseline(full_size=True):
+    """The CPU oracle (a port of the reference's PyTorch CPU path, pinned bit-exact to it on the golden fixtures) timed on
+    this box's host cores, BASELINE.md section 3: (i) all cores the process may use, 1 I + 1 P frame at the FULL
+    EL 1152x1920 / BL 576x960 size, no scaling; GOP time = I + 31 P (a whole GOP would take ~half an hour);
+    (ii) torch.set_num_threads(1), which is what the reference pins per worker (test.py:642), on a 1/22.5-size sample
+    (EL 256x384) scaled by pixel count -- one full-size frame takes ~15 min on one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    cores = max(1, usable)
+    H, W = (1152, 1920) if full_size else (384, 640)
+    t_i, t_p = _oracle_frames(H, W, cores)
     scale = (H * W) / (1152.0 * 1920.0)
     fps = GOP / (t_i + (GOP - 1) * t_p) * scale
+    h1, w1 = 256, 384                     # smallest sample whose BL (128x192) is still a multiple of 64
+    s_i, s_p = _oracle_frames(h1, w1, 1)
+    fps1 = GOP / (s_i + (GOP - 1) * s_p) * (h1 * w1) / (1152.0 * 1920.0)
+    torch.set_num_threads(cores)
+    size = "the full EL 1152x1920 / BL 576x960 size, no scaling" if full_size else "EL 384x640 / BL 192x320 (1/9 of the pixels), scaled by 1/9"
     return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "1 I-frame (%.2f s) + 1 P-frame (%.2f s) at EL 384x640 / BL 192x320 (1/9 of the pixels), "
-                      "GOP-32 mix (1 I + 31 P), scaled by 1/9; torch %s CPU fp32" % (t_i, t_p, torch.__version__)}
+            "sample": "1 I-frame (%.2f s) + 1 P-frame (%.2f s) at %s, GOP-32 mix (1 I + 31 P); %d threads "
+                      "(os.cpu_count() = %s, usable = %d); torch %s CPU fp32" % (t_i, t_p, size, cores, os.cpu_count(), usable,
+                                                                                torch.__version__),
+            "single_thread": {"value": round(fps1, 6), "unit": "frames/s", "cores": 1,
+                              "sample": "torch.set_num_threads(1) (test.py:642): 1 I (%.2f s) + 1 P (%.2f s) at EL %dx%d, scaled by "
+                                        "pixel count (1/22.5)" % (s_i, s_p, h1, w1)}}
 
 
 def main():
@@ -194,6 +235,8 @@ def main():
     ap.add_argument("--frames", type=int, default=GOP, help="frames per GOP (default 32 = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events in the last timed step")
+    ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop (per-frame H2D + pre-processing included)")
+    ap.add_argument("--cpu-baseline-small", action="store_true", help="CPU baseline on the 384x640 sample instead of the full size")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
                     help="conv arithmetic (default: lssvc_amd's default, see hip_ops.CONV_PRECISION)")
     args = ap.parse_args()
@@ -220,7 +263,7 @@ def main():
 
     hip_ops.reserve_device_memory(device)          # one hipMalloc up front instead of pool growth during the first GOPs
     t0 = time.time()
-    x_bls, x_els, pad = build_inputs(device, seed=rank, frames=args.frames)   # each rank codes its own GOP
+    x_bls, x_els, pad, clip_u8 = build_inputs(device, seed=rank, frames=args.frames)   # each rank codes its own GOP
     shape_hr = pad["HR_padded_size"]
     torch.cuda.synchronize()
     if rank == 0:
@@ -250,10 +293,23 @@ def main():
             bits, _ = encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log)
         sync_all()
         dt = time.time() - t_start
+        # the same GOP with per-frame H2D + pre-processing inside the clock (reported beside `value`, never as it)
+        dt_incl, incl_steps = None, 0
+        if not args.no_h2d_pass:
+            incl_steps = max(1, min(args.steps, 5))
+            host = HostFrames(clip_u8, device)
+            encode_gop(inet, pnet, None, None, shape_hr, host_frames=host)          # untimed: allocator warm-up of this path
+            sync_all()
+            t1 = time.time()
+            for k in range(incl_steps):
+                bits_incl, _ = encode_gop(inet, pnet, None, None, shape_hr, host_frames=host)
+            sync_all()
+            dt_incl = time.time() - t1
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt, dt_incl if dt_incl is not None else 0.0], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt = t[0].item()
+        dt_incl = t[1].item() if dt_incl is not None else None
 
     if rank == 0:
         frames = world * args.frames * args.steps
@@ -263,10 +319,19 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE[hip_ops.CONV_PRECISION], "data": "synthetic",
             "config": {"workload": "configs[1]: LSSVC two-layer x2, EL 1152x1920 (1080p padded) / BL 576x960, "
-                                   "%d-frame GOP per GPU per step, write_stream=0" % args.frames,
+                                   "%d-frame GOP per GPU per step, write_stream=0; inputs resident in HBM for `value`, "
+                                   "per-frame H2D + pre-processing included in `h2d_inclusive`" % args.frames,
                        "frames_per_step_per_gpu": args.frames, "weights": "seeded synthetic (lssvc_amd.synth, gain %.2f)" % GAIN,
                        "parallelism": "gop-shard x%d (no data-path collective)" % world},
         }
+        if dt_incl is not None:
+            out["h2d_inclusive"] = {
+                "value": round(world * args.frames * incl_steps / dt_incl, 4), "unit": "frames/s", "steps": incl_steps,
+                "ms_per_step": round(1e3 * dt_incl / incl_steps, 2),
+                "what": "same GOP; per frame inside the clock: H2D of the 8-bit 1080x1920 RGB frame from pinned host memory "
+                        "(6.2 MB), u8 -> fp32, zero padding to 1152x1920, MATLAB-bicubic BL 576x960 (lssvc_amd.preprocess), "
+                        "encode, D2H of the bit counts (BASELINE.md section 3 'GPU side')",
+                "bits_equal_resident_run": bool(bits_incl == bits)}
         pel = HEIGHT * WIDTH
         out["bpp_check"] = {"i_frame_bpp_el": round(bits[0][1] / pel, 5),
                             "p_frame_bpp_el_mean": round(sum(b[1] for b in bits[1:]) / max(1, len(bits) - 1) / pel, 5)}
@@ -278,7 +343,7 @@ def main():
             out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(full_size=not args.cpu_baseline_small)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
