@@ -83,8 +83,11 @@ def encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log=None, host_frames=None
     bits = []
     dpb = None
     n = len(host_frames) if host_frames is not None else len(x_els)
+    graph = pnet.graph_mode
     for t in range(n):
-        hip_ops.OP_LOG = op_log if (op_log is not None and 1 <= t <= EVENT_FRAMES) else None
+        logging = op_log is not None and 1 <= t <= EVENT_FRAMES
+        hip_ops.OP_LOG = op_log if logging else None
+        pnet.graph_mode = graph and not logging        # per-launch events need the eager path for these frames
         inet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
         pnet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
         x_bl, x_el = host_frames.layers(t) if host_frames is not None else (x_bls[t], x_els[t])
@@ -99,6 +102,7 @@ def encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log=None, host_frames=None
         dpb["ref_frame_el"].clamp_(0, 1)
         bits.append((r["bit_bl"], r["bit_el"]))
     hip_ops.OP_LOG = None
+    pnet.graph_mode = graph
     return bits, dpb
 
 
@@ -197,12 +201,14 @@ def _oracle_frames(H, W, threads):
     return t_i, t_p
 
 
-def cpu_baseline(full_size=True):
+def cpu_baseline(full_size=False):
     """The CPU oracle (a port of the reference's PyTorch CPU path, pinned bit-exact to it on the golden fixtures) timed on
-    this box's host cores, BASELINE.md section 3: (i) all cores the process may use, 1 I + 1 P frame at the FULL
-    EL 1152x1920 / BL 576x960 size, no scaling; GOP time = I + 31 P (a whole GOP would take ~half an hour);
-    (ii) torch.set_num_threads(1), which is what the reference pins per worker (test.py:642), on a 1/22.5-size sample
-    (EL 256x384) scaled by pixel count -- one full-size frame takes ~15 min on one thread."""
+    this box's host cores on a BOUNDED sample: (i) all cores the process may use, 1 I + 1 P frame
+    at EL 384x640 / BL 192x320 = 1/9 of the 1152x1920 workload's pixels, frames/s scaled by 1/9 (conv work is linear in
+    pixels), GOP time = I + 31 P; (ii) torch.set_num_threads(1), which is what the reference pins per worker
+    (test.py:642), on a 1/22.5-size sample (EL 256x384). `--cpu-baseline-full` times (i) at the full size instead: on the
+    GPU box's 16-core host share that takes more than 7 minutes for the two frames (measured in round 2: the run was
+    cut off by the pool's silence limit), which is why it is not the default."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
         usable = len(os.sched_getaffinity(0))
@@ -210,14 +216,17 @@ def cpu_baseline(full_size=True):
         usable = os.cpu_count()
     cores = max(1, usable)
     H, W = (1152, 1920) if full_size else (384, 640)
+    log("  cpu baseline: %d threads (os.cpu_count() = %s), 1 I + 1 P at EL %dx%d ..." % (cores, os.cpu_count(), H, W))
     t_i, t_p = _oracle_frames(H, W, cores)
     scale = (H * W) / (1152.0 * 1920.0)
     fps = GOP / (t_i + (GOP - 1) * t_p) * scale
     h1, w1 = 256, 384                     # smallest sample whose BL (128x192) is still a multiple of 64
+    log("  cpu baseline: I %.2f s, P %.2f s; now 1 thread at EL %dx%d ..." % (t_i, t_p, h1, w1))
     s_i, s_p = _oracle_frames(h1, w1, 1)
     fps1 = GOP / (s_i + (GOP - 1) * s_p) * (h1 * w1) / (1152.0 * 1920.0)
     torch.set_num_threads(cores)
-    size = "the full EL 1152x1920 / BL 576x960 size, no scaling" if full_size else "EL 384x640 / BL 192x320 (1/9 of the pixels), scaled by 1/9"
+    size = "the full EL 1152x1920 / BL 576x960 size, no scaling" if full_size else \
+        "EL 384x640 / BL 192x320 (1/9 of the pixels), scaled by 1/9"
     return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "1 I-frame (%.2f s) + 1 P-frame (%.2f s) at %s, GOP-32 mix (1 I + 31 P); %d threads "
                       "(os.cpu_count() = %s, usable = %d); torch %s CPU fp32" % (t_i, t_p, size, cores, os.cpu_count(), usable,
@@ -235,8 +244,9 @@ def main():
     ap.add_argument("--frames", type=int, default=GOP, help="frames per GOP (default 32 = BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events in the last timed step")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying hipGraph frame plans")
     ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop (per-frame H2D + pre-processing included)")
-    ap.add_argument("--cpu-baseline-small", action="store_true", help="CPU baseline on the 384x640 sample instead of the full size")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline at the full 1152x1920 size (takes > 7 min on a 16-core host share)")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
                     help="conv arithmetic (default: lssvc_amd's default, see hip_ops.CONV_PRECISION)")
     args = ap.parse_args()
@@ -261,6 +271,9 @@ def main():
     pnet.load_dict(synth_state_dict("lssvc_extend", 0, GAIN))
     pnet.to(device).eval()
 
+    if not args.no_graph:
+        inet.set_graph_mode(True)                  # FramePlan: the per-frame launch sequence replayed as a hipGraph
+        pnet.set_graph_mode(True)
     hip_ops.reserve_device_memory(device)          # one hipMalloc up front instead of pool growth during the first GOPs
     t0 = time.time()
     x_bls, x_els, pad, clip_u8 = build_inputs(device, seed=rank, frames=args.frames)   # each rank codes its own GOP
@@ -322,7 +335,8 @@ def main():
                                    "%d-frame GOP per GPU per step, write_stream=0; inputs resident in HBM for `value`, "
                                    "per-frame H2D + pre-processing included in `h2d_inclusive`" % args.frames,
                        "frames_per_step_per_gpu": args.frames, "weights": "seeded synthetic (lssvc_amd.synth, gain %.2f)" % GAIN,
-                       "parallelism": "gop-shard x%d (no data-path collective)" % world},
+                       "parallelism": "gop-shard x%d (no data-path collective)" % world,
+                       "launch": "eager (ctypes per kernel)" if args.no_graph else "hipGraph frame plans (I / first-P / steady-P)"},
         }
         if dt_incl is not None:
             out["h2d_inclusive"] = {
@@ -343,7 +357,7 @@ def main():
             out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(full_size=not args.cpu_baseline_small)
+            out["cpu_baseline"] = cpu_baseline(full_size=args.cpu_baseline_full)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

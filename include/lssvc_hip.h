@@ -272,6 +272,8 @@ int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, u
 /* Runtime tuning switches (each also reads an environment variable at first use):
  *   "f16x3_persist"            1/0   use the persistent warp-specialised 3x3 kernel (LSSVC_F16X3_PERSIST)
  *   "f16x3_persist_min_tiles"  n     ... for convs with at least n output tiles (LSSVC_F16X3_PERSIST_MIN_TILES, 256)
+ *   "f16x3_pingpong"           1/0   which persistent kernel: ping-pong wave groups (default) or producer/consumer waves
+ *                                    (LSSVC_F16X3_PINGPONG)
  * Results do not depend on them (the kernels they choose between are bit-identical); tests use them to pin that. */
 int lssvc_set_option(const char *name, int32_t value);
 int lssvc_get_option(const char *name, int32_t *value);

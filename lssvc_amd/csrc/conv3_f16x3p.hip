@@ -19,8 +19,9 @@
 //     barrier per phase (phase = one 16-channel chunk, all 9 taps), and the phase sequence runs on across tile
 //     boundaries, so tiles have no head or tail.
 // Arithmetic, operand order inside a K-step, accumulator layout and the fused epilogue are those of
-// conv_f16x3_kernel (lo*hi + hi*lo + hi*hi per K = 32 step = two taps x 16 channels): results are bit-identical to
-// it. The odd ninth tap is paired with a zeroed B fragment.
+// conv_f16x3_kernel (f16x3_step_pair per two taps x 16 channels, f16x3_step_odd for the ninth tap): results are
+// bit-identical to it. Superseded as the default by conv3_f16x3q.hip (ping-pong wave groups); kept selectable
+// (lssvc_set_option("f16x3_pingpong", 0)) as the A/B baseline.
 #include "conv_f16x3_kernel.h"
 
 namespace lssvc {
@@ -213,45 +214,56 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         const _Float16 *wl_ = wh_ + G::W_HALFS;
 #pragma unroll
         for (int u = 0; u < NSTEP; ++u) {
-            const bool pad_step = 2 * u + 1 >= NTAP;                         // the ninth tap has no partner
-            const int tap = pad_step ? 2 * u : 2 * u + tsel;
+            const bool odd = 2 * u + 1 >= NTAP;                              // the ninth tap: f16x3_step_odd
+            const int tap = odd ? 2 * u : 2 * u + tsel;
             const int ky = tap / 3, kx = tap - ky * 3;
-            f16x8 ah[MF], al[MF];
+            const _Float16 *wa1 = (odd && !tsel) ? wl_ : wh_, *wa2 = (odd && !tsel) ? wh_ : wl_;
+            const _Float16 *pb1 = (odd && tsel) ? pl_ : ph_;
+            f16x8 a1[MF], a2[MF];
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
                 const int o = (tap * TM + f * 16 + li) * CK16 + ch8;
-                ah[f] = *reinterpret_cast<const f16x8 *>(wh_ + o);
-                al[f] = *reinterpret_cast<const f16x8 *>(wl_ + o);
+                a1[f] = *reinterpret_cast<const f16x8 *>(wa1 + o);
+                a2[f] = *reinterpret_cast<const f16x8 *>(wa2 + o);
             }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                f16x8 bh[G::HALF], bl[G::HALF];
+                f16x8 b1[G::HALF], b2[G::HALF];
 #pragma unroll
                 for (int r = 0; r < G::HALF; ++r) {
                     const int row = wave * RPW + half * G::HALF + r;
                     const int o = ((row + ky) * PW + li + kx) * CK16 + ch8;
-                    bh[r] = *reinterpret_cast<const f16x8 *>(ph_ + o);
-                    bl[r] = *reinterpret_cast<const f16x8 *>(pl_ + o);
-                    if (pad_step && tsel) {
-                        bh[r] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                        bl[r] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    }
+                    b1[r] = *reinterpret_cast<const f16x8 *>(pb1 + o);
+                    if (!odd) b2[r] = *reinterpret_cast<const f16x8 *>(pl_ + o);
                 }
+                if (odd) {
 #pragma unroll
-                for (int f = 0; f < MF; ++f)
+                    for (int f = 0; f < MF; ++f)
 #pragma unroll
-                    for (int r = 0; r < G::HALF; ++r)
-                        acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][half * G::HALF + r], 0, 0, 0);
+                        for (int r = 0; r < G::HALF; ++r)
+                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b1[r], acc[f][half * G::HALF + r], 0, 0, 0);
 #pragma unroll
-                for (int f = 0; f < MF; ++f)
+                    for (int f = 0; f < MF; ++f)
 #pragma unroll
-                    for (int r = 0; r < G::HALF; ++r)
-                        acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][half * G::HALF + r], 0, 0, 0);
+                        for (int r = 0; r < G::HALF; ++r)
+                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[f], b1[r], acc[f][half * G::HALF + r], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int f = 0; f < MF; ++f)
+                    for (int f = 0; f < MF; ++f)
 #pragma unroll
-                    for (int r = 0; r < G::HALF; ++r)
-                        acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][half * G::HALF + r], 0, 0, 0);
+                        for (int r = 0; r < G::HALF; ++r)
+                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[f], b1[r], acc[f][half * G::HALF + r], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < MF; ++f)
+#pragma unroll
+                        for (int r = 0; r < G::HALF; ++r)
+                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b2[r], acc[f][half * G::HALF + r], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < MF; ++f)
+#pragma unroll
+                        for (int r = 0; r < G::HALF; ++r)
+                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b1[r], acc[f][half * G::HALF + r], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                                   // (B_k)
@@ -312,7 +324,7 @@ static int p3_pick_mf(int frags) {
 // Worth it once every CU gets at least one 32x16 tile (measured on the bench workload: thresholds 256 / 512 / 1024 /
 // 2048 tiles give 14.0 / 13.9 / 13.6 / 13.5 frames/s).
 bool conv3_f16x3p_wanted(const ConvP &p) {
-    const int on = option_get(OPT_P3_ON), min_tiles = option_get(OPT_P3_MIN_TILES);
+    const int on = option_get(OPT_P3_ON), min_tiles = option_get(OPT_P3_MIN_TILES);     // shared by both persistent kernels
     if (!on || !p.fast_epi) return false;
     if (p.in_act == LSSVC_INACT_LRELU && !(p.in_slope >= 0.0f && p.in_slope <= 1.0f)) return false;   // max(x, s*x) form
     const int mf = p3_pick_mf(p.M_pad / 16);

@@ -3,7 +3,8 @@
 //
 // Every operand is split as x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (about 22 significant bits)
 // and the product is accumulated in fp32 as  hi*hi + hi*lo + lo*hi  (the lo*lo term, ~2^-22 relative, is
-// dropped): 3 fp16 MFMAs replace 8 fp32 MFMAs per 32-deep K step, 5.3x fewer matrix-pipe cycles.
+// dropped, except in the odd step below where it is free): 3 fp16 MFMAs replace 8 fp32 MFMAs per 32-deep K step,
+// 5.3x fewer matrix-pipe cycles.
 // Plain fp16 inputs miss the parity bars of BASELINE.json by 100-1000x; this 3-term split holds them with
 // a ~40x margin (measured on the golden cases). Activations stay fp32 in HBM and are
 // split while they are staged into LDS (after the fused input activation); weights are pre-split on the
@@ -12,9 +13,9 @@
 // Layout. K is walked in chunks of 16 input channels. One MFMA K-step (32) = two filter taps x 16
 // channels: lane group g = lane>>4 takes tap 2u + (g>>1), channels 8(g&1)..+7, so the A (weights) and B
 // (pixels) fragments are single ds_read_b128 each. LDS rows are 16 fp16 = 32 B, unpadded: for the b128
-// lane groups of gfx950 the 16-B slots (2i + (g&1) + const) are distinct, i.e. conflict-free. An odd tap
-// count is padded with an all-zero weight slot. Tile = (4*RPW rows x 16 cols) pixels x 16*MF channels,
-// 4 waves, epilogue shared with the fp32 kernel (conv_mfma_kernel.h).
+// lane groups of gfx950 the 16-B slots (2i + (g&1) + const) are distinct, i.e. conflict-free. The last tap
+// of an odd tap count shares its K step between its own hi and lo planes (f16x3_step_odd). Tile = (4*RPW rows x
+// 16 cols) pixels x 16*MF channels, 4 waves, epilogue shared with the fp32 kernel (conv_mfma_kernel.h).
 #pragma once
 #include "conv_mfma_kernel.h"
 
@@ -24,6 +25,43 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK16 = 16;   // input channels per K chunk in this mode
+
+// ---- the two K = 32 MFMA steps every f16x3 conv kernel is built from ------------------------------------------------
+// PAIR step: lane group g = lane >> 4 carries tap (2u + (g >> 1)), channels 8 (g & 1) .. +7, for both operands:
+//     acc += wl * xh  +  wh * xl  +  wh * xh          (small terms first; three MFMAs)
+// ODD step (the last tap of an odd tap count has no partner): instead of pairing it with a zero tap -- half of every
+// MFMA multiplying zeros -- the hi and lo PLANES of the same tap share the K axis. Lane groups with (g >> 1) == 0 load
+// (a1, a2, b) = (wl, wh, xh), the others (wh, wl, xl):
+//     acc += [wl | wh] . [xh | xl]   =  wl * xh + wh * xl
+//     acc += [wh | wl] . [xh | xl]   =  wh * xh + wl * xl      (two MFMAs; the lo*lo term comes along for free)
+// 3x3: 4 pair steps + 1 odd step = 14 MFMAs per 16 channels instead of 15; 7x7 (one kernel row per phase): 11 instead of 12.
+template <int MF, int R>
+__device__ __forceinline__ void f16x3_step_pair(f32x4 (&acc)[MF][R], const f16x8 (&ah)[MF], const f16x8 (&al)[MF], const f16x8 (&bh)[R],
+                                                const f16x8 (&bl)[R]) {
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][r], 0, 0, 0);
+}
+template <int MF, int R>
+__device__ __forceinline__ void f16x3_step_odd(f32x4 (&acc)[MF][R], const f16x8 (&a1)[MF], const f16x8 (&a2)[MF], const f16x8 (&b)[R]) {
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b[r], acc[f][r], 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[f], b[r], acc[f][r], 0, 0, 0);
+}
 
 template <int MF, int RPW, int KS, int S>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
@@ -36,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
     constexpr int PWE = (PW + 1) / 2;
     constexpr int RPP = (KS <= 3) ? KS : 1;                     // kernel rows per phase
     constexpr int NTAP = RPP * KS;                              // taps per phase
-    constexpr int NSTEP = (NTAP + 1) / 2;                       // MFMA K-steps (2 taps each) per phase
-    constexpr int NSLOT = 2 * NSTEP;                            // weight slots incl. the zero pad
+    constexpr int NSTEP = (NTAP + 1) / 2;                       // MFMA K-steps per phase: NTAP / 2 tap pairs (+ the odd tap)
+    constexpr int NSLOT = NTAP;                                 // weight slots
     constexpr int PATCH_ITEMS = PH * PW * 4;                    // float4 (4-channel) items of the patch
     constexpr int W_ITEMS = NTAP * TM * 2;                      // 16-byte (8 x fp16) items per weight plane
     constexpr int NP = (PATCH_ITEMS + 255) / 256;
@@ -179,15 +217,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
         return k;
     };
 
-    // the zero weight slot that pads an odd tap count (never overwritten afterwards)
-    if (NSLOT > NTAP) {
-        for (int i = tid; i < TM * CK16 / 8; i += 256) {
-            const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<f16x8 *>(wts_h + NTAP * TM * CK16 + i * 8) = z;
-            *reinterpret_cast<f16x8 *>(wts_l + NTAP * TM * CK16 + i * 8) = z;
-        }
-    }
-
     KState cur{0, 0, 0, 0};
     load_patch(cur);
     load_w(cur);
@@ -203,43 +232,32 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvP p) {
         }
 #pragma unroll
         for (int u = 0; u < NSTEP; ++u) {
-            // this lane group's tap of the pair (2u, 2u+1); a missing odd tap reads the zero weight slot and any
-            // valid patch address
-            const int tap_w = 2 * u + tsel;                                   // weight slot (NTAP = zero slot)
-            const int tap_b = (2 * u + 1 < NTAP) ? tap_w : 2 * u;             // patch tap (clamped)
-            const int ry = tap_b / KS, kx = tap_b - ry * KS;
+            const bool odd = 2 * u + 1 >= NTAP;                               // the last tap of an odd count: f16x3_step_odd
+            const int tap = odd ? 2 * u : 2 * u + tsel;                       // this lane group's tap
+            const int ry = tap / KS, kx = tap - ry * KS;
             const int ky = cur.ky + ry;
-            f16x8 ah[MF], al[MF], bh[RPW], bl[RPW];
             const int dbg_u = (p.debug & 16) ? 0 : 1;          // ablation: every step re-reads step 0's fragments
+            // pair step: (a1, a2) = (wh, wl), (b1, b2) = (xh, xl) for every lane; odd step: lane groups with tsel = 0 take
+            // (a1, a2, b1) = (wl, wh, xh), the others (wh, wl, xl)
+            const _Float16 *wa1 = (odd && !tsel) ? wts_l : wts_h, *wa2 = (odd && !tsel) ? wts_h : wts_l;
+            const _Float16 *pb1 = (odd && tsel) ? patch_l : patch_h;
+            f16x8 a1[MF], a2[MF], b1[RPW], b2[RPW];
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                const int o = dbg_u * (tap_w * TM + f * 16 + li) * CK16 + ch8;
-                ah[f] = *reinterpret_cast<const f16x8 *>(wts_h + o);
-                al[f] = *reinterpret_cast<const f16x8 *>(wts_l + o);
+                const int o = dbg_u * (tap * TM + f * 16 + li) * CK16 + ch8;
+                a1[f] = *reinterpret_cast<const f16x8 *>(wa1 + o);
+                a2[f] = *reinterpret_cast<const f16x8 *>(wa2 + o);
             }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int row = wave * RPW + r;
                 const int col = (S == 2) ? (kx & 1) * PWE + li + (kx >> 1) : li + kx;
                 const int o = dbg_u * ((row * S + ky) * PW + col) * CK16 + ch8;
-                bh[r] = *reinterpret_cast<const f16x8 *>(patch_h + o);
-                bl[r] = *reinterpret_cast<const f16x8 *>(patch_l + o);
+                b1[r] = *reinterpret_cast<const f16x8 *>(pb1 + o);
+                if (!odd) b2[r] = *reinterpret_cast<const f16x8 *>(patch_l + o);
             }
-#pragma unroll
-            for (int f = 0; f < MF; ++f)
-#pragma unroll
-                for (int r = 0; r < RPW; ++r)
-                    acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[r], acc[f][r], 0, 0, 0);
-#pragma unroll
-            for (int f = 0; f < MF; ++f)
-#pragma unroll
-                for (int r = 0; r < RPW; ++r)
-                    acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[r], acc[f][r], 0, 0, 0);
-#pragma unroll
-            for (int f = 0; f < MF; ++f)
-#pragma unroll
-                for (int r = 0; r < RPW; ++r)
-                    acc[f][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[r], acc[f][r], 0, 0, 0);
+            if (odd) f16x3_step_odd<MF, RPW>(acc, a1, a2, b1);
+            else f16x3_step_pair<MF, RPW>(acc, a1, a2, b1, b2);
         }
         if (!more) break;
         if (!(p.debug & 4)) __syncthreads();
@@ -291,9 +309,11 @@ int dispatch_tile_f16x3_s2(const ConvP &p, int MF, int RPW, hipStream_t st) {
 }
 extern template int dispatch_tile_f16x3_s2<3>(const ConvP &, int, int, hipStream_t);
 
-// persistent double-buffered 3x3 variant for large images (conv3_f16x3p.hip)
+// persistent 3x3 variants for large images: conv3_f16x3q.hip (ping-pong wave groups, the default) and
+// conv3_f16x3p.hip (producer / consumer waves, kept for A/B: option f16x3_pingpong = 0)
 bool conv3_f16x3p_wanted(const ConvP &p);
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
+int dispatch_conv3_f16x3q(const ConvP &p, hipStream_t st, char *kernel_name);
 
 extern template int dispatch_tile_f16x3<3, 1>(const ConvP &, int, int, hipStream_t);
 extern template int dispatch_tile_f16x3<7, 1>(const ConvP &, int, int, hipStream_t);

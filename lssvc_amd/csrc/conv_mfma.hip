@@ -26,9 +26,9 @@ namespace lssvc {
 // ---- runtime tuning switches: environment at first use, lssvc_set_option() afterwards ----------------
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<bool> g_opt_set[OPT_COUNT];
-static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES"};
-static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles"};
-static const int kOptDefault[OPT_COUNT] = {1, 256};
+static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PINGPONG"};
+static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_pingpong"};
+static const int kOptDefault[OPT_COUNT] = {1, 256, 1};
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
         const char *e = getenv(kOptEnv[which]);
@@ -183,7 +183,8 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         p.w16 = d->weight16;
         p.w16_unscale = d->weight16_unscale != 0.0f ? d->weight16_unscale : 1.0f;
         p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
-        if (vec && sd == 1 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3_f16x3p_wanted(p)) return dispatch_conv3_f16x3p(p, st, kname);
+        if (vec && sd == 1 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3_f16x3p_wanted(p))
+            return option_get(OPT_P3_PINGPONG) ? dispatch_conv3_f16x3q(p, st, kname) : dispatch_conv3_f16x3p(p, st, kname);
         static const int s2_on = getenv("LSSVC_F16X3_S2") ? atoi(getenv("LSSVC_F16X3_S2")) : 1;
         if (s2_on && vec && sd == 2 && ks == 3 && RPW <= 2) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, 3, 2>", MF, RPW);

@@ -394,17 +394,26 @@ class LSSVC_extend(_HostModel):
         return feature, recon_el, mv_hat, warp_frame
 
     # ---------------------------------------------------------------------------------------------
+    def _frame_body(self, t):
+        bl = self._bl_codec(t["x_bl"], t["ref_frame_bl"], t["ref_feature_bl"])
+        feature, recon_el, mv_hat, warp_frame = self._el_codec(t["x_el"], bl, t["ref_frame_el"], t["ref_feature_el"])
+        return {"recon_bl": bl["recon"], "feature_bl": bl["feature"], "recon_el": recon_el, "feature_el": feature,
+                "mv_hat": mv_hat, "warp_frame": warp_frame}
+
     def forward_one_frame(self, x_bl, x_el, ref_frame_bl, ref_frame_el, ref_feature_bl, ref_feature_el):
         """LSSVC.forward_one_frame (LSSVC_net.py:445-528): estimate mode."""
         self._require_device()
-        nhwc = lambda t: None if t is None else T.from_nchw(t)
-        xe = nhwc(x_el)
-        assert (xe.H, xe.W) == self.shape_hr, "x_el is %dx%d but shape_hr is %s" % (xe.H, xe.W, self.shape_hr)
-        bl = self._bl_codec(nhwc(x_bl), nhwc(ref_frame_bl), nhwc(ref_feature_bl))
-        feature, recon_el, mv_hat, warp_frame = self._el_codec(xe, bl, nhwc(ref_frame_el), nhwc(ref_feature_el))
-        dpb = {"ref_frame_bl": bl["recon"].to_nchw(remember=True), "ref_feature_bl": bl["feature"].to_nchw(remember=True),
-               "ref_frame_el": recon_el.to_nchw(remember=True), "ref_feature_el": feature.to_nchw(remember=True)}
-        out = {"dpb": dpb, "mv_hat": mv_hat.to_nchw(), "warp_frame": warp_frame.to_nchw(),
+        assert tuple(x_el.shape[2:]) == self.shape_hr, "x_el is %dx%d but shape_hr is %s" % (x_el.shape[2], x_el.shape[3], self.shape_hr)
+        tensors = {"x_bl": x_bl, "x_el": x_el, "ref_frame_bl": ref_frame_bl, "ref_frame_el": ref_frame_el,
+                   "ref_feature_bl": ref_feature_bl, "ref_feature_el": ref_feature_el}
+        if self.graph_mode:
+            key = ("p",) + tuple(None if v is None else tuple(v.shape) for v in tensors.values()) + (ops.CONV_PRECISION,)
+            r = self._run_planned(key, tensors, self._frame_body)
+        else:
+            r = self._frame_body({k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()})
+        dpb = {"ref_frame_bl": r["recon_bl"].to_nchw(remember=True), "ref_feature_bl": r["feature_bl"].to_nchw(remember=True),
+               "ref_frame_el": r["recon_el"].to_nchw(remember=True), "ref_feature_el": r["feature_el"].to_nchw(remember=True)}
+        out = {"dpb": dpb, "mv_hat": r["mv_hat"].to_nchw(), "warp_frame": r["warp_frame"].to_nchw(),
                "encoding_time_EL": 0.0, "decoding_time_EL": 0.0, "encoding_time_BL": 0.0, "decoding_time_BL": 0.0}
         s = self.slots.fetch()
         out["bit_bl"] = s[0] + s[1] + s[2] + s[3]          # y + z + mv_y + mv_z  (dmc_net.py:473)

@@ -1,0 +1,106 @@
+"""FramePlan mode (hipGraph replay of the per-frame launch sequence, lssvc_amd.intra.FramePlan): bit-identical to the
+eager path over whole GOPs -- I-frame plan, first-P plan (feature_adaptor_I path, ref_feature_bl = None) and steady-P
+plan -- including the call that captures and the replays after it, at two sizes and in both conv precisions; and the
+host cost per frame it exists for."""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nets(seed, gain):
+    from lssvc_amd import IntraSS, LSSVC_extend
+    from lssvc_amd.synth import synth_state_dict
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", seed, gain)).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", seed, gain))
+    pnet.to(DEV).eval()
+    return inet, pnet
+
+
+def _code(inet, pnet, x_bl, x_el, H, W, gops, frames):
+    """test.py's loop; returns per frame (bit_bl, bit_el, clones of the four DPB tensors + mv_hat)."""
+    rows = []
+    for _ in range(gops):
+        dpb = None
+        for t in range(frames):
+            inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+            pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+            if t == 0:
+                r = inet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], None, None)
+                dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+                extra = []
+            else:
+                r = pnet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], dpb)
+                dpb = r["dpb"]
+                extra = [r["mv_hat"].clone(), r["warp_frame"].clone()]
+            dpb["ref_frame_bl"].clamp_(0, 1)
+            dpb["ref_frame_el"].clamp_(0, 1)
+            rows.append((r["bit_bl"], r["bit_el"], [None if v is None else v.clone() for v in dpb.values()] + extra))
+    return rows
+
+
+@pytest.mark.parametrize("H,W,precision", [(128, 128, "f16x3"), (128, 256, "f16x3"), (128, 128, "f32")])
+def test_graph_replay_is_bit_identical_to_eager(H, W, precision):
+    from lssvc_amd import hip_ops
+    from lssvc_amd.synth import synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic
+    old = hip_ops.CONV_PRECISION
+    try:
+        hip_ops.set_conv_precision(precision)
+        frames, gops = 5, 3
+        clip = synth_clip(frames, H, W, seed=9).float() / 255.0
+        x_bl, x_el = imresize_bicubic(clip, (H // 2, W // 2)).clamp_(0, 1).to(DEV), clip.to(DEV)
+        inet, pnet = _nets(2, 0.6)
+        eager = _code(inet, pnet, x_bl, x_el, H, W, 1, frames)
+        inet.set_graph_mode(True)
+        pnet.set_graph_mode(True)
+        got = _code(inet, pnet, x_bl, x_el, H, W, gops, frames)      # GOP 0: eager warm-up calls + captures, GOP 1-2: replays
+        assert any(p.graph is not None for p in pnet._plans.values()) and any(p.graph is not None for p in inet._plans.values())
+        assert len(pnet._plans) == 2                                  # first-P and steady-P plans
+        for i, (bb, be, tens) in enumerate(got):
+            wb, we, wt = eager[i % frames]
+            assert (bb, be) == (wb, we), (i, bb, wb, be, we)
+            for a, b in zip(tens, wt):
+                assert (a is None and b is None) or torch.equal(a, b), i
+    finally:
+        hip_ops.set_conv_precision(old)
+
+
+def test_graph_mode_host_time_per_frame():
+    """What the plan is for: host time to issue one 256x256 frame. Eager: Python + ctypes per launch (~250-400 launches);
+    graph: input copies + one hipGraphLaunch. Timed with the GPU idle-waited out (synchronize outside the clock)."""
+    from lssvc_amd.synth import synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic
+    H = W = 256
+    clip = synth_clip(2, H, W, seed=1).float() / 255.0
+    x_bl, x_el = imresize_bicubic(clip, (H // 2, W // 2)).clamp_(0, 1).to(DEV), clip.to(DEV)
+    inet, pnet = _nets(0, 0.55)
+    inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+    pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+
+    def one_p(dpb):
+        return pnet.encode_decode(x_bl[1:2], x_el[1:2], dpb)["dpb"]
+
+    def timed(n):
+        r = inet.encode_decode(x_bl[0:1], x_el[0:1], None, None)
+        dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+        dpb = one_p(dpb)
+        for _ in range(3):
+            dpb = one_p(dpb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            dpb = one_p(dpb)                     # includes the D2H read of the bit counters = one sync per frame
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    eager = timed(20)
+    inet.set_graph_mode(True)
+    pnet.set_graph_mode(True)
+    graph = timed(20)
+    print("256x256 P-frame wall per frame: eager %.2f ms, graph %.2f ms" % (eager * 1e3, graph * 1e3))
+    assert graph < 0.6 * eager, (eager, graph)
