@@ -239,6 +239,32 @@ int lssvc_import_symbols(const int32_t *sym_nchw, const lssvc_view *mean, const 
 int lssvc_build_indexes(const lssvc_view *sigma, float log_min, float log_step, float add, int32_t levels,
                         int32_t *idx_nhwc, void *stream);
 
+/* ---- frame pre/post-processing around the codec (csrc/prepost.hip) ---------------------------------
+ * What the reference's test.py does to every frame on the host before and after encode_decode
+ * (test.py:185-201, 249-311), here on the device so that only 8-bit planes go up and a few scalars come back. */
+
+/* 8-bit planar 4:2:0 (device pointers; y: HxW, u, v: H/2 x W/2) -> RGB fp32 NHWC frame [0,1]: ycbcr420_to_rgb
+ * (src/utils/functional.py:42-58: chroma x2 by linear interpolation at scipy.ndimage.zoom's sample positions, BT.709,
+ * clip). `frame` may be larger than HxW: the rest is the zero inter-layer padding (test.py:191-193).
+ * y_norm / u_norm / v_norm (optional): the planes / 255 that the per-plane PSNRs are taken against. */
+int lssvc_yuv420_to_frame(const uint8_t *y, const uint8_t *u, const uint8_t *v, int32_t H, int32_t W, const lssvc_view *frame,
+                          float *y_norm, float *u_norm, float *v_norm, void *stream);
+/* 8-bit planar RGB (3 x H x W) -> fp32 NHWC frame, x / 255, zero-padded to the frame's size. */
+int lssvc_rgb8_to_frame(const uint8_t *rgb, int32_t H, int32_t W, const lssvc_view *frame, void *stream);
+/* Separable K-tap resampling with host-built tables ([n_out][K] weights and source indexes per axis), vertical pass
+ * then horizontal pass, result clamped to [clamp_lo, clamp_hi]: the MATLAB-style antialiased bicubic `imresize`
+ * (src/utils/core.py:276-432) that makes the base-layer frame (test.py:194-199); tables: lssvc_amd/preprocess.py. */
+int lssvc_resample2d(const lssvc_view *in, const lssvc_view *out, const float *w_v, const int32_t *idx_v, int32_t k_v,
+                     const float *w_h, const int32_t *idx_h, int32_t k_h, float clamp_lo, float clamp_hi, void *stream);
+/* rgb_to_ycbcr420 (functional.py:16-39) of the top-left h x w crop of an RGB frame (optionally clamped to [0,1] first,
+ * test.py:249-250): y (h x w), u, v (h/2 x w/2) fp32 planes. */
+int lssvc_rgb_to_yuv420(const lssvc_view *rgb, int32_t h, int32_t w, int32_t clamp01, float *y, float *u, float *v, void *stream);
+/* out[0] = sum over the top-left h x w crop, all channels, of (clamp01 ? clamp(a,0,1) : a  -  b)^2, accumulated in fp64
+ * in a fixed order (PSNR = 10 log10(1 / (out / n)), test.py:104-118). workspace: lssvc_reduce_workspace_bytes(). */
+int lssvc_sqdiff_sum(const lssvc_view *a, const lssvc_view *b, int32_t h, int32_t w, int32_t clamp01, double *out, void *workspace,
+                     void *stream);
+int lssvc_sqdiff_sum_flat(const float *a, const float *b, int64_t n, double *out, void *workspace, void *stream);
+
 /* ---- host entropy coder (write_stream = 1) ------------------------------------------------------
  * Replaces the reference's pybind11 modules MLCodec_rans (BufferedRansEncoder / RansDecoder,
  * src/cpp/rans/rans_interface.cpp:85-261) and MLCodec_CXX (pmf_to_quantized_cdf, src/cpp/ops/ops.cpp:24-91).
@@ -272,8 +298,8 @@ int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, u
 /* Runtime tuning switches (each also reads an environment variable at first use):
  *   "f16x3_persist"            1/0   use the persistent warp-specialised 3x3 kernel (LSSVC_F16X3_PERSIST)
  *   "f16x3_persist_min_tiles"  n     ... for convs with at least n output tiles (LSSVC_F16X3_PERSIST_MIN_TILES, 256)
- *   "f16x3_pingpong"           1/0   which persistent kernel: ping-pong wave groups (default) or producer/consumer waves
- *                                    (LSSVC_F16X3_PINGPONG)
+ *   "f16x3_deferred"           1/0   which persistent kernel: 16x16 tiles with the epilogue deferred into the next tile's
+ *                                    MFMA stream (default), or 24x16 tiles with the epilogue at the tile boundary (LSSVC_F16X3_DEFERRED)
  * Results do not depend on them (the kernels they choose between are bit-identical); tests use them to pin that. */
 int lssvc_set_option(const char *name, int32_t value);
 int lssvc_get_option(const char *name, int32_t *value);

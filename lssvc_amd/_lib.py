@@ -87,6 +87,12 @@ SIGNATURES = {
     "lssvc_export_symbols": (C.c_int, [VP, VP, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_import_symbols": (C.c_int, [C.c_void_p, VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
     "lssvc_build_indexes": (C.c_int, [VP, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lssvc_yuv420_to_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, VP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_rgb8_to_frame": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, VP, C.c_void_p]),
+    "lssvc_resample2d": (C.c_int, [VP, VP, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
+    "lssvc_rgb_to_yuv420": (C.c_int, [VP, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_sqdiff_sum": (C.c_int, [VP, VP, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_sqdiff_sum_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_rans_encoder_new": (C.c_void_p, []),
     "lssvc_rans_encoder_free": (None, [C.c_void_p]),
     "lssvc_rans_encoder_reset": (None, [C.c_void_p]),

@@ -20,8 +20,8 @@
 //     boundaries, so tiles have no head or tail.
 // Arithmetic, operand order inside a K-step, accumulator layout and the fused epilogue are those of
 // conv_f16x3_kernel (f16x3_step_pair per two taps x 16 channels, f16x3_step_odd for the ninth tap): results are
-// bit-identical to it. Superseded as the default by conv3_f16x3q.hip (ping-pong wave groups); kept selectable
-// (lssvc_set_option("f16x3_pingpong", 0)) as the A/B baseline.
+// bit-identical to it. Superseded as the default by conv3_f16x3d.hip (deferred epilogue); kept selectable
+// (lssvc_set_option("f16x3_deferred", 0)) as the A/B baseline.
 #include "conv_f16x3_kernel.h"
 
 namespace lssvc {
@@ -45,7 +45,7 @@ struct P3Geom {
     static constexpr int W_INSTR = 2 * W_ITEMS / 64;              // wave-level DMA instructions for both planes (= 9 MF)
     static constexpr int NPROD = kP3ProducerThreads / 64;
     static constexpr int NDMA = (W_INSTR + NPROD - 1) / NPROD;
-    static constexpr int LDS_BYTES = 2 * (2 * PATCH_HALFS + 2 * W_HALFS) * 2;
+    static constexpr int LDS_BYTES = 2 * (2 * PATCH_HALFS + 2 * W_HALFS) * 2;      // + the bias vector (launch_p3)
 };
 
 struct P3Phase {
@@ -53,13 +53,17 @@ struct P3Phase {
     KState k;      // segment / channel offset / global chunk index of the phase
 };
 
-template <int MF>
+// STAMP: diagnostic build only (LSSVC_CONV_DEBUG & 256; never dispatched otherwise): consumer wave 0..3 of every workgroup
+// accumulates s_memtime deltas of its compute / barrier-wait / epilogue sections and writes them, with the s_memrealtime
+// span of the loop, to the buffer passed in p.gdn_x.p (unused on this path): 8 x int64 per wave.
+template <int MF, bool INACT, bool STAMP = false>
 __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP p) {
     using G = P3Geom<MF>;
     constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP, NP = G::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *const patch0 = reinterpret_cast<_Float16 *>(smem);                    // [buf][plane][PH*PW][16]
     _Float16 *const wts0 = patch0 + 4 * G::PATCH_HALFS;                             // [buf][plane][tap][m][16]
+    float *const bias_s = reinterpret_cast<float *>(wts0 + 4 * G::W_HALFS);         // [m_tiles * TM], zero past M_pad
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     const int n_it = kb < t_cnt ? (t_cnt - kb + nb_x - 1) / nb_x : 0;
     if (n_it == 0) return;
     const int phases_per_tile = p.n_chunks16;
+    for (int i = tid; i < p.m_tiles * TM; i += kP3Threads) bias_s[i] = (p.bias && i < p.M_pad) ? p.bias[i] : 0.f;   // visible after barrier (A)
 
     auto tile_origin = [&](int it, int &oy0, int &ox0, int &m0) {
         const int tile = t_begin + kb + it * nb_x;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         const int lt = tid - 64 * kP3Consumers;                   // 0 .. 255
         const int pw = wave - kP3Consumers;
         const int quad4 = (lt & 3) * 4;
-        const float in_slope = p.in_act == LSSVC_INACT_LRELU ? p.in_slope : 1.0f;
+        const float in_slope = p.in_slope;
         const int Hin = p.in[0].H, Win = p.in[0].W;
         const _Float16 *w16 = reinterpret_cast<const _Float16 *>(p.w16);
 
@@ -109,45 +114,86 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             }
             return ph;
         };
-        // everything one phase needs, into LDS buffer `buf`: weights by DMA, patch through registers
-        auto fill = [&](const P3Phase &ph, int buf) {
+        // Per-TILE staging geometry, computed when the tile changes instead of every phase (the producers' vector-issue
+        // slots are what they compete for with the consumers' MFMAs): input pixel of every staged float4 item (-1 = zero
+        // padding / past the patch) and the lane offsets of the weight DMA inside one chunk's [hi | lo] image.
+        int ppix[NP], woff[G::NDMA];
+        int geom_it = -1;
+        auto tile_geometry = [&](int it) {
             int oy0, ox0, m0;
-            tile_origin(ph.it, oy0, ox0, m0);
-            if (!(p.debug & 1)) {
-                unsigned char *dst = reinterpret_cast<unsigned char *>(wts0 + buf * 2 * G::W_HALFS);
-                const size_t chunk_base = (size_t)ph.k.kc * NTAP * p.M_pad * CK16;
-#pragma unroll
-                for (int t = 0; t < G::NDMA; ++t) {
-                    int j = pw + G::NPROD * t;                       // wave-uniform DMA instruction index
-                    if (j >= G::W_INSTR) j = G::W_INSTR - 1;         // surplus slots rewrite the last KiB with the same bytes
-                    const int i = j * 64 + lane;                     // 16-byte item of the [hi plane | lo plane] image
-                    const int plane = i >= G::W_ITEMS ? 1 : 0;
-                    const int r = i - plane * G::W_ITEMS;
-                    const int tap = r / (2 * TM);
-                    const int rr = r - tap * 2 * TM;
-                    int m = m0 + (rr >> 1);
-                    if (m >= p.M_pad) m = p.M_pad - 1;               // rows past M_pad: any finite weights, masked by the epilogue
-                    const _Float16 *src = w16 + (size_t)plane * p.w16_plane + chunk_base + ((size_t)tap * p.M_pad + m) * CK16 + (rr & 1) * 8;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
-                }
-            }
-            if (p.debug & 2) return;
-            const V X = p.in[ph.k.seg];
-            const int cleft = X.C - ph.k.c0;
-            const int cc = quad4 < cleft ? ph.k.c0 + quad4 : 0;
-            float4 preg[NP];
-            unsigned pmask = 0;
+            tile_origin(it, oy0, ox0, m0);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int idx = lt + i * kP3ProducerThreads;
                 const int pix = idx >> 2;
                 const int py = pix / PW, px = pix - py * PW;
                 const int gy = oy0 - p.pad_t + py, gx = ox0 - p.pad_l + px;
-                const bool ok = idx < G::PATCH_ITEMS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win && quad4 < cleft;
-                const size_t off = ok ? (size_t)(gy * Win + gx) * X.ld + cc : 0;
+                const bool ok = idx < G::PATCH_ITEMS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+                ppix[i] = ok ? gy * Win + gx : -1;
+            }
+#pragma unroll
+            for (int t = 0; t < G::NDMA; ++t) {
+                int j = pw + G::NPROD * t;                       // wave-uniform DMA instruction index
+                if (j >= G::W_INSTR) j = G::W_INSTR - 1;         // surplus slots rewrite the last KiB with the same bytes
+                const int i = j * 64 + lane;                     // 16-byte item of the [hi plane | lo plane] image
+                const int plane = i >= G::W_ITEMS ? 1 : 0;
+                const int r = i - plane * G::W_ITEMS;
+                const int tap = r / (2 * TM);
+                const int rr = r - tap * 2 * TM;
+                int m = m0 + (rr >> 1);
+                if (m >= p.M_pad) m = p.M_pad - 1;               // rows past M_pad: any finite weights, masked by the epilogue
+                woff[t] = plane * (int)p.w16_plane + (tap * p.M_pad + m) * CK16 + (rr & 1) * 8;
+            }
+            geom_it = it;
+        };
+        // everything one phase needs, into LDS buffer `buf`: weights by DMA, patch through registers
+        long long s_dma = 0, s_ld = 0, s_wait = 0, s_cvt = 0, s_bar = 0, s_geo = 0;      // STAMP build only
+        auto fill = [&](const P3Phase &ph, int buf) {
+            long long ts = 0;
+            if (STAMP) ts = __builtin_amdgcn_s_memtime();
+            if (ph.it != geom_it) tile_geometry(ph.it);
+            if (STAMP) {
+                const long long t = __builtin_amdgcn_s_memtime();
+                s_geo += t - ts;
+                ts = t;
+            }
+            if (!(p.debug & 1)) {
+                unsigned char *dst = reinterpret_cast<unsigned char *>(wts0 + buf * 2 * G::W_HALFS);
+                const _Float16 *src0 = w16 + (size_t)ph.k.kc * NTAP * p.M_pad * CK16;
+#pragma unroll
+                for (int t = 0; t < G::NDMA; ++t) {
+                    int j = pw + G::NPROD * t;
+                    if (j >= G::W_INSTR) j = G::W_INSTR - 1;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + woff[t]),
+                                                     (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+                }
+            }
+            if (STAMP) {
+                const long long t = __builtin_amdgcn_s_memtime();
+                s_dma += t - ts;
+                ts = t;
+            }
+            if (p.debug & 2) return;
+            const V X = p.in[ph.k.seg];
+            const bool cvalid = quad4 < X.C - ph.k.c0;
+            const int cc = cvalid ? ph.k.c0 + quad4 : 0;
+            float4 preg[NP];
+            unsigned pmask = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const bool ok = ppix[i] >= 0 && cvalid;
+                const size_t off = ok ? (size_t)ppix[i] * X.ld + cc : 0;
                 preg[i] = *reinterpret_cast<const float4 *>(X.p + off);
                 pmask |= ok ? (1u << i) : 0u;
+            }
+            if (STAMP) {
+                long long t = __builtin_amdgcn_s_memtime();
+                s_ld += t - ts;
+                ts = t;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (diagnostic: separates the load latency from the conversion)
+                t = __builtin_amdgcn_s_memtime();
+                s_wait += t - ts;
+                ts = t;
             }
             _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;
             _Float16 *pl_ = ph_ + G::PATCH_HALFS;
@@ -160,7 +206,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = live ? raw[j] : 0.f;
-                    x = fmaxf(x, in_slope * x);                               // LeakyReLU for 0 <= slope <= 1 (1 = none): exact
+                    if (INACT) x = fmaxf(x, in_slope * x);                    // LeakyReLU for 0 <= slope <= 1: exact
                     x = fminf(fmaxf(x, -65504.f), 65504.f);
                     h[j] = (_Float16)x;
                     l[j] = (_Float16)(x - (float)h[j]);
@@ -170,6 +216,10 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                     *reinterpret_cast<f16x4 *>(ph_ + o) = h;
                     *reinterpret_cast<f16x4 *>(pl_ + o) = l;
                 }
+            }
+            if (STAMP) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                s_cvt += __builtin_amdgcn_s_memtime() - ts;
             }
         };
 
@@ -186,7 +236,14 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             // LDS-DMA data is ordered for the consumers' ds_reads only by the issuing wave's vmcnt wait + a barrier;
             // the compiler emits that wait today, this line makes it a property of the source
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            long long tb = 0;
+            if (STAMP) tb = __builtin_amdgcn_s_memtime();
             __syncthreads();                               // (B_k) buffer (k+1)&1 complete, buffer k&1 released
+            if (STAMP) s_bar += __builtin_amdgcn_s_memtime() - tb;
+        }
+        if (STAMP && lane == 0 && p.gdn_x.p) {
+            long long *o = reinterpret_cast<long long *>(p.gdn_x.p) + ((size_t)gridDim.x * kP3Consumers + (size_t)blockIdx.x * 4 + pw) * 8;
+            o[0] = s_dma; o[1] = s_ld; o[2] = s_wait; o[3] = s_cvt; o[4] = s_bar; o[5] = total; o[6] = s_geo; o[7] = 0;
         }
         return;
     }
@@ -206,6 +263,11 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     __syncthreads();                                       // (A)
     int it = 0, kt = 0;                                    // tile index in this workgroup's sequence, phase inside the tile
     const int total = n_it * phases_per_tile;
+    long long t_comp = 0, t_bar = 0, t_epi = 0, t_mark = 0, t_real0 = 0, t_cyc0 = 0;
+    if (STAMP) {
+        t_real0 = __builtin_amdgcn_s_memrealtime();
+        t_cyc0 = t_mark = __builtin_amdgcn_s_memtime();
+    }
     for (int k = 0; k < total; ++k) {
         const int buf = k & 1;
         const _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;
@@ -266,7 +328,17 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 }
             }
         }
+        if (STAMP) {
+            const long long t = __builtin_amdgcn_s_memtime();
+            t_comp += t - t_mark;
+            t_mark = t;
+        }
         __syncthreads();                                   // (B_k)
+        if (STAMP) {
+            const long long t = __builtin_amdgcn_s_memtime();
+            t_bar += t - t_mark;
+            t_mark = t;
+        }
         if (++kt == phases_per_tile) {
             int oy0, ox0, m0;
             tile_origin(it, oy0, ox0, m0);
@@ -285,7 +357,10 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                         const int oy = oy0 + wave * RPW + half * G::HALF + r, ox = ox0 + li;
                         pix[r] = (oy < p.Hout && ox < p.Wout) ? (long long)oy * p.Wout + ox : -1;
                     }
-                    conv_epilogue_fast<MF, G::HALF>(p, part, pix, m0, lg, p.w16_unscale);       // the dispatcher only sends p.fast_epi convs here
+                    // interior: this wave's rows, the tile's 16 columns and its 16*MF channels all lie inside the output
+                const bool interior = oy0 + wave * RPW + half * G::HALF + G::HALF <= p.Hout && ox0 + 16 <= p.Wout && m0 + TM <= p.Cout;
+                conv_epilogue_fast<MF, G::HALF>(p, part, pix, m0, lg, p.w16_unscale, interior,     // the dispatcher only sends p.fast_epi convs here
+                                                (lds_cfloat_ptr)bias_s);
                 }
             }
 #pragma unroll
@@ -294,25 +369,46 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 for (int b = 0; b < RPW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
             kt = 0;
             ++it;
+            if (STAMP) {
+                const long long t = __builtin_amdgcn_s_memtime();
+                t_epi += t - t_mark;
+                t_mark = t;
+            }
         }
+    }
+    if (STAMP && lane == 0 && p.gdn_x.p) {
+        long long *o = reinterpret_cast<long long *>(p.gdn_x.p) + ((size_t)blockIdx.x * kP3Consumers + wave) * 8;
+        o[0] = t_comp; o[1] = t_bar; o[2] = t_epi;
+        o[3] = __builtin_amdgcn_s_memtime() - t_cyc0;
+        o[4] = __builtin_amdgcn_s_memrealtime() - t_real0;
+        o[5] = total; o[6] = n_it; o[7] = 0;
     }
 }
 
-template <int MF>
+template <int MF, bool INACT>
 static int launch_p3(const ConvP &p, hipStream_t st) {
     using G = P3Geom<MF>;
     const int cus = device_cus();
-    static LdsGrant grant;
-    if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF>), G::LDS_BYTES)) return 1;
     ConvP q = p;
     q.tiles_x = (p.Wout + 15) / 16;
     q.tiles_y = (p.Hout + G::TH - 1) / G::TH;
     q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
+    const size_t lds = (size_t)G::LDS_BYTES + (size_t)q.m_tiles * G::TM * sizeof(float);
+    if (lds > 160 * 1024) return fail("conv2d(f16x3p): %zu bytes of LDS", lds);
+    static LdsGrant grant;
+    if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, INACT>), lds)) return 1;
     const long long ntiles = (long long)q.tiles_x * q.tiles_y * q.m_tiles;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return fail("conv2d(f16x3p): bad tile count %lld", ntiles);
+    if (p.w16_plane * 2 > 0x7fffffffLL) return fail("conv2d(f16x3p): weight image too large for 32-bit lane offsets");
     long long blocks = cus;                       // one persistent 8-wave workgroup per CU
     if (blocks > ntiles) blocks = ntiles;
-    hipLaunchKernelGGL((conv3_f16x3p_kernel<MF>), dim3((unsigned)blocks), dim3(kP3Threads), G::LDS_BYTES, st, q);
+    if (MF == 4 && !INACT && (p.debug & 256)) {             // diagnostic: in-kernel stamps (tools/p3_stamps.py)
+        static LdsGrant grant_s;
+        if (grant_s.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<4, false, true>), lds)) return 1;
+        hipLaunchKernelGGL((conv3_f16x3p_kernel<4, false, true>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
+        return launch_status("conv2d(f16x3p, stamps)");
+    }
+    hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, INACT>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
     return launch_status("conv2d(f16x3p)");
 }
 
@@ -334,11 +430,13 @@ bool conv3_f16x3p_wanted(const ConvP &p) {
 
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
     const int mf = p3_pick_mf(p.M_pad / 16);
-    snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d>", mf);
-    if (mf == 4) return launch_p3<4>(p, st);
-    if (mf == 3) return launch_p3<3>(p, st);
-    if (mf == 2) return launch_p3<2>(p, st);
-    return launch_p3<1>(p, st);
+    const bool inact = p.in_act == LSSVC_INACT_LRELU;
+    snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s>", mf, inact ? "true" : "false");
+#define LSSVC_P3_CASE(m) \
+    if (mf == m) return inact ? launch_p3<m, true>(p, st) : launch_p3<m, false>(p, st);
+    LSSVC_P3_CASE(4) LSSVC_P3_CASE(3) LSSVC_P3_CASE(2) LSSVC_P3_CASE(1)
+#undef LSSVC_P3_CASE
+    return fail("conv2d(f16x3p): no kernel for MF=%d", mf);
 }
 
 }  // namespace lssvc

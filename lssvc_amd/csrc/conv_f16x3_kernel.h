@@ -309,11 +309,12 @@ int dispatch_tile_f16x3_s2(const ConvP &p, int MF, int RPW, hipStream_t st) {
 }
 extern template int dispatch_tile_f16x3_s2<3>(const ConvP &, int, int, hipStream_t);
 
-// persistent 3x3 variants for large images: conv3_f16x3q.hip (ping-pong wave groups, the default) and
-// conv3_f16x3p.hip (producer / consumer waves, kept for A/B: option f16x3_pingpong = 0)
+// persistent 3x3 variants for large images (producer / consumer waves): conv3_f16x3d.hip (16x16-pixel tiles, epilogue
+// deferred into the next tile's MFMA stream; the default) and conv3_f16x3p.hip (24x16 tiles, epilogue at the tile
+// boundary; option f16x3_deferred = 0, kept as the A/B baseline)
 bool conv3_f16x3p_wanted(const ConvP &p);
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
-int dispatch_conv3_f16x3q(const ConvP &p, hipStream_t st, char *kernel_name);
+int dispatch_conv3_f16x3d(const ConvP &p, hipStream_t st, char *kernel_name);
 
 extern template int dispatch_tile_f16x3<3, 1>(const ConvP &, int, int, hipStream_t);
 extern template int dispatch_tile_f16x3<7, 1>(const ConvP &, int, int, hipStream_t);

@@ -26,8 +26,8 @@ namespace lssvc {
 // ---- runtime tuning switches: environment at first use, lssvc_set_option() afterwards ----------------
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<bool> g_opt_set[OPT_COUNT];
-static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PINGPONG"};
-static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_pingpong"};
+static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_DEFERRED"};
+static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_deferred"};
 static const int kOptDefault[OPT_COUNT] = {1, 256, 1};
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
@@ -154,7 +154,7 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     }
     {
         static const int fast_on = getenv("LSSVC_FAST_EPI") ? atoi(getenv("LSSVC_FAST_EPI")) : 1;
-        const bool common = fast_on && d->epilogue == LSSVC_EPI_NONE && (d->Cout % 4 == 0) && p.out_vec &&
+        const bool common = fast_on && d->epilogue == LSSVC_EPI_NONE && (d->Cout % 4 == 0) && p.out_vec && d->out_scale == 1.0f &&
                             (d->act != LSSVC_ACT_LRELU || (d->slope >= 0.0f && d->slope <= 1.0f));
         p.fast_epi = 0;
         if (common && !d->pixel_shuffle && (!d->residual.ptr || p.res_vec)) p.fast_epi = 1;
@@ -164,6 +164,7 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     {
         static const int dbg = getenv("LSSVC_CONV_DEBUG") ? atoi(getenv("LSSVC_CONV_DEBUG")) : 0;
         p.debug = dbg;
+        if ((dbg & 256) && d->epilogue == LSSVC_EPI_NONE && d->gdn_x.ptr) p.gdn_x = V{d->gdn_x.ptr, 0, 0, 0, 0};   // stamp buffer (diagnostic)
     }
 
     int MF, RPW;
@@ -184,7 +185,7 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         p.w16_unscale = d->weight16_unscale != 0.0f ? d->weight16_unscale : 1.0f;
         p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
         if (vec && sd == 1 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3_f16x3p_wanted(p))
-            return option_get(OPT_P3_PINGPONG) ? dispatch_conv3_f16x3q(p, st, kname) : dispatch_conv3_f16x3p(p, st, kname);
+            return option_get(OPT_P3_DEFERRED) ? dispatch_conv3_f16x3d(p, st, kname) : dispatch_conv3_f16x3p(p, st, kname);
         static const int s2_on = getenv("LSSVC_F16X3_S2") ? atoi(getenv("LSSVC_F16X3_S2")) : 1;
         if (s2_on && vec && sd == 2 && ks == 3 && RPW <= 2) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, 3, 2>", MF, RPW);

@@ -59,18 +59,32 @@ __device__ __forceinline__ void conv_unscale(const ConvP &p, f32x4 (&acc)[MF][RP
 // prescale (1 for the fp32 kernels); multiplying by a power of two and by 1.0f is exact.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int MF, int RPW, bool PS>
+// INTERIOR (wave-uniform, decided by the caller from the tile's position): every pixel row of this wave lies inside the
+// image and every channel fragment below Cout, so no load or store needs a per-lane guard. With the guards the compiler
+// wraps EACH conditional load / store in its own s_and_saveexec / s_cbranch_execz block -- ~50 branches per epilogue;
+// interior tiles (all but the last tile row / column / M tile) get straight-line code instead. RES likewise lifts the
+// "is there a residual" test out of the per-row code.
+typedef __attribute__((address_space(3))) const float *lds_cfloat_ptr;
+
+template <int MF, int RPW, bool PS, bool RES, bool INTERIOR, bool ACT>
 __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
-                                                        int lg, float unscale) {
+                                                        int lg, float unscale, lds_cfloat_ptr bias_lds) {
     const float s_neg = p.act == LSSVC_ACT_LRELU ? p.slope : (p.act == LSSVC_ACT_RELU ? 0.0f : 1.0f);
-    const bool has_res = p.res.p != nullptr;
-    const f32x2 us = {unscale, unscale}, sn = {s_neg, s_neg}, os = {p.out_scale, p.out_scale};
+    constexpr bool has_res = RES;
+    const f32x2 us = {unscale, unscale}, sn = {s_neg, s_neg};      // (out_scale == 1 here: the host keeps other convs off this path)
     f32x2 bb[MF][2];
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
         const int mb = m0 + f * 16 + 4 * lg;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && mb < p.Cout && !(p.debug & 128)) t = *reinterpret_cast<const float4 *>(p.bias + mb);
+        if (bias_lds) {
+            // the persistent kernels keep the (zero-padded, M_pad long) bias vector in LDS: a dependent GLOBAL load at the
+            // head of every tile's epilogue costs a full L2 round trip with the matrix pipe idle
+            const f32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>(bias_lds + mb);
+            t = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (p.bias && (INTERIOR || mb < p.Cout)) {
+            t = *reinterpret_cast<const float4 *>(p.bias + mb);
+        }
         bb[f][0] = f32x2{t.x, t.y};
         bb[f][1] = f32x2{t.z, t.w};
     }
@@ -92,14 +106,15 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
         for (int f = 0; f < MF; ++f) {
             const int mb = m0 + f * 16 + 4 * lg;
             d[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has_res && pix[r] >= 0 && mb < p.Cout) d[f] = *reinterpret_cast<const float4 *>(p.res.p + (size_t)pix[r] * p.res.ld + mb);
+            if (has_res && (INTERIOR || (pix[r] >= 0 && mb < p.Cout)))
+                d[f] = *reinterpret_cast<const float4 *>(p.res.p + (size_t)pix[r] * p.res.ld + mb);
         }
     };
     load_res(0, rs[0]);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         if (r + 1 < RPW) load_res(r + 1, rs[(r + 1) & 1]);      // issued before row r's stores (see conv_epilogue_flat)
-        const size_t opix = (size_t)(pix[r] >= 0 ? pix[r] : 0);
+        const size_t opix = (size_t)((INTERIOR || pix[r] >= 0) ? pix[r] : 0);
         float *orow = p.out.p + opix * p.out.ld + m0 + 4 * lg;
         float *srow = nullptr;                                   // pixel-shuffle: the 2x2 output block of this conv pixel
         if (PS) {
@@ -111,14 +126,18 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
             const int mb = m0 + f * 16 + 4 * lg;
             f32x2 v0 = f32x2{acc[f][r][0], acc[f][r][1]} * us + bb[f][0];
             f32x2 v1 = f32x2{acc[f][r][2], acc[f][r][3]} * us + bb[f][1];
-            const f32x2 n0 = v0 * sn, n1 = v1 * sn;
-            v0 = f32x2{fmaxf(v0.x, n0.x), fmaxf(v0.y, n0.y)};
-            v1 = f32x2{fmaxf(v1.x, n1.x), fmaxf(v1.y, n1.y)};
-            v0 = (v0 + f32x2{rs[r & 1][f].x, rs[r & 1][f].y}) * os;
-            v1 = (v1 + f32x2{rs[r & 1][f].z, rs[r & 1][f].w}) * os;
+            if (ACT) {                                                        // no activation: max(v, 1 * v) == v, skipped
+                const f32x2 n0 = v0 * sn, n1 = v1 * sn;
+                v0 = f32x2{fmaxf(v0.x, n0.x), fmaxf(v0.y, n0.y)};
+                v1 = f32x2{fmaxf(v1.x, n1.x), fmaxf(v1.y, n1.y)};
+            }
+            if (RES) {
+                v0 = v0 + f32x2{rs[r & 1][f].x, rs[r & 1][f].y};
+                v1 = v1 + f32x2{rs[r & 1][f].z, rs[r & 1][f].w};
+            }
             float *dst = orow + f * 16;
             if (PS) dst = srow + ps_off[f];
-            if (pix[r] >= 0 && mb < p.Cout && (!(p.debug & 64) || v0.x == 1.2345f))   // debug 64: perf ablation, stores off
+            if (INTERIOR || (pix[r] >= 0 && mb < p.Cout))
                 *reinterpret_cast<float4 *>(dst) = make_float4(v0.x, v0.y, v1.x, v1.y);
         }
     }
@@ -126,9 +145,23 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
 
 template <int MF, int RPW>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
-                                                   int lg, float unscale = 1.0f) {
-    if (p.fast_epi == 2) conv_epilogue_fast_impl<MF, RPW, true>(p, acc, pix, m0, lg, unscale);      // pixel-shuffle store
-    else conv_epilogue_fast_impl<MF, RPW, false>(p, acc, pix, m0, lg, unscale);
+                                                   int lg, float unscale = 1.0f, bool interior = false,
+                                                   lds_cfloat_ptr bias_lds = nullptr) {
+    // (every condition is wave-uniform: scalar branches)
+    const bool act = p.act != LSSVC_ACT_NONE;
+#define LSSVC_EPI_CALL(PS_, RES_)                                                                                              \
+    do {                                                                                                                       \
+        if (interior) {                                                                                                        \
+            if (act) conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, true>(p, acc, pix, m0, lg, unscale, bias_lds);          \
+            else conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, false>(p, acc, pix, m0, lg, unscale, bias_lds);             \
+        } else {                                                                                                               \
+            conv_epilogue_fast_impl<MF, RPW, PS_, RES_, false, true>(p, acc, pix, m0, lg, unscale, bias_lds);                  \
+        }                                                                                                                      \
+    } while (0)
+    if (p.fast_epi == 2) LSSVC_EPI_CALL(true, false);                        // pixel-shuffle store (never with a residual)
+    else if (p.res.p != nullptr) LSSVC_EPI_CALL(false, true);
+    else LSSVC_EPI_CALL(false, false);
+#undef LSSVC_EPI_CALL
 }
 
 // Memory-op ordering matters here: on gfx9/CDNA loads and stores share the vmcnt counter, so a wait for a load that
@@ -144,10 +177,11 @@ struct EpiSide {
 
 template <int MF, int RPW, bool GDN = true>
 __device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
-                                                   int lg) {
+                                                   int lg, bool interior = false) {
     // pix[r] = conv-space pixel index oy*Wout + ox of this lane's column of fragment row r, or -1 if outside
+    // interior (wave-uniform): the caller knows that no pix[r] is -1 and m0 + 16 MF <= Cout
     if (p.fast_epi) {
-        conv_epilogue_fast<MF, RPW>(p, acc, pix, m0, lg);
+        conv_epilogue_fast<MF, RPW>(p, acc, pix, m0, lg, 1.0f, interior);
         return;
     }
     const int cps = p.Cout >> 2;  // channels after pixel shuffle
@@ -259,7 +293,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x4 (&acc)[MF][R
         const int oy = oy0 + wave * RPW + r;
         pix[r] = (oy < p.Hout && ox < p.Wout) ? (long long)oy * p.Wout + ox : -1;
     }
-    conv_epilogue_flat<MF, RPW, GDN>(p, acc, pix, m0, lg);
+    const bool interior = oy0 + wave * RPW + RPW <= p.Hout && ox0 + 16 <= p.Wout && m0 + 16 * MF <= p.Cout;
+    conv_epilogue_flat<MF, RPW, GDN>(p, acc, pix, m0, lg, interior);
 }
 
 // One K "phase" = one 8-channel chunk x RPP kernel rows. Small kernels (<=3x3) take all rows in one

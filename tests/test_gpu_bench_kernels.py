@@ -1,6 +1,6 @@
 """Parity of the kernel instantiations the BENCHMARK runs (round-1 verdict, "What's weak" 1).
 
-The dispatcher picks a kernel by tile count: conv3_f16x3q_kernel<MF, INACT> (persistent, ping-pong wave groups) only for 3x3
+The dispatcher picks a kernel by tile count: conv3_f16x3d_kernel<MF, INACT> / conv3_f16x3p_kernel (persistent, warp-specialised) only for 3x3
 stride-1 convs with >= 256 tiles, the RPW = 4 instantiations of the tiled kernels only for grids of >= 512
 workgroups. The small shapes of test_gpu_ops.py never reach those, so every case here is sized to DISPATCH the
 kernel under test (asserted through the op log) and compared with an fp64 reference of the same op:
@@ -110,7 +110,8 @@ def test_persistent_3x3_matches_fp64(hip, cins, cout, H, W, in_act, act, residua
 
     got16, k16 = _run(hip, "f16x3", launch)
     got32, k32 = _run(hip, "f32", launch)
-    assert k16 == "conv3_f16x3q_kernel<%d, %s>" % (mf, "true" if in_act else "false"), k16     # really the persistent kernel
+    want = "conv3_f16x3%s_kernel<%d, %s>" % ("d" if sum(cins) > 16 else "p", mf, "true" if in_act else "false")
+    assert k16 == want, k16                                           # really the persistent kernel (deferred-epilogue variant)
     assert k32.startswith("conv_mfma_kernel"), k32
     assert got16.shape == ref.shape
     e16 = (got16.double() - ref).abs().max().item()
@@ -138,28 +139,28 @@ def test_persistent_3x3_is_bit_identical_to_tiled(hip, cins, cout, H, W, in_act,
         ins = [nhwc(hip, x) for x in xs]
         return back(hip.subpel(Wt, "s", ins, **kw) if shuffle else hip.conv(Wt, "c", ins, **kw))
 
-    old, old_pp = _get("f16x3_persist"), _get("f16x3_pingpong")
+    old, old_pp = _get("f16x3_persist"), _get("f16x3_deferred")
     try:
         _set("f16x3_persist", 1)
-        _set("f16x3_pingpong", 1)
-        a, ka = _run(hip, "f16x3", launch)                    # ping-pong wave groups (conv3_f16x3q.hip, the default)
-        _set("f16x3_pingpong", 0)
-        c, kc = _run(hip, "f16x3", launch)                    # producer / consumer waves (conv3_f16x3p.hip)
+        _set("f16x3_deferred", 1)
+        a, ka = _run(hip, "f16x3", launch)                    # 16x16 tiles, deferred epilogue (conv3_f16x3d.hip, the default)
+        _set("f16x3_deferred", 0)
+        c, kc = _run(hip, "f16x3", launch)                    # 24x16 tiles, epilogue at the tile boundary (conv3_f16x3p.hip)
         _set("f16x3_persist", 0)
         b_, kb = _run(hip, "f16x3", launch)                   # tiled kernel
     finally:
         _set("f16x3_persist", old)
-        _set("f16x3_pingpong", old_pp)
-    assert ka.startswith("conv3_f16x3q_kernel") and kc.startswith("conv3_f16x3p_kernel") and kb.startswith("conv_f16x3_kernel"), (ka, kc, kb)
+        _set("f16x3_deferred", old_pp)
+    assert ka.startswith("conv3_f16x3d_kernel") and kc.startswith("conv3_f16x3p_kernel") and kb.startswith("conv_f16x3_kernel"), (ka, kc, kb)
     assert torch.equal(a, b_) and torch.equal(c, b_)
 
 
 def test_persistent_3x3_small_grids(hip):
     """Grids with fewer than 8 workgroups (tile ranges keyed by blockIdx & 7 left tiles uncomputed): force
     the persistent kernel onto convs with 1..7 tiles and compare with the tiled kernel."""
-    old_min, old_on, old_pp = _get("f16x3_persist_min_tiles"), _get("f16x3_persist"), _get("f16x3_pingpong")
+    old_min, old_on, old_pp = _get("f16x3_persist_min_tiles"), _get("f16x3_persist"), _get("f16x3_deferred")
     try:
-        # 1..7 tiles, odd tile-row counts (the ping-pong kernel's lower tile then lies outside the image), several M tiles
+        # 1..7 tiles (24x16) / a few more 16x16 ones, partial tiles, several M tiles, a lone last tile to flush
         for H, W, cout in ((24, 16, 64), (24, 48, 64), (48, 48, 64), (30, 70, 48), (24, 16, 128), (50, 20, 16), (72, 16, 64),
                            (100, 40, 192)):
             g = torch.Generator().manual_seed(H * W + cout)
@@ -172,15 +173,15 @@ def test_persistent_3x3_small_grids(hip):
             b_, kb = _run(hip, "f16x3", lambda: back(hip.conv(Wt, "c", nhwc(hip, x))))
             assert kb.startswith("conv_f16x3_kernel"), kb
             _set("f16x3_persist", 1)
-            for pp, prefix in ((1, "conv3_f16x3q_kernel"), (0, "conv3_f16x3p_kernel")):
-                _set("f16x3_pingpong", pp)
+            for pp, prefix in ((1, "conv3_f16x3d_kernel"), (0, "conv3_f16x3p_kernel")):
+                _set("f16x3_deferred", pp)
                 a, ka = _run(hip, "f16x3", lambda: back(hip.conv(Wt, "c", nhwc(hip, x))))
                 assert ka.startswith(prefix), ka
                 assert torch.equal(a, b_), (H, W, cout, prefix)
     finally:
         _set("f16x3_persist_min_tiles", old_min)
         _set("f16x3_persist", old_on)
-        _set("f16x3_pingpong", old_pp)
+        _set("f16x3_deferred", old_pp)
 
 
 # ---- RPW = 4 instantiations of the tiled f16x3 kernels (7x7 SpyNet convs; 3x3 with 2-3 output channels) -----------

@@ -1,0 +1,69 @@
+"""In-kernel stamps of the persistent 3x3 kernel's consumer waves (diagnostic build, LSSVC_CONV_DEBUG=256):
+where a consumer's time goes -- MFMA phases, barrier waits, epilogues -- and the shader clock it ran at.
+    LSSVC_CONV_DEBUG=256 python tools/p3_stamps.py"""
+import math
+import os
+import sys
+
+import torch
+
+os.environ.setdefault("LSSVC_CONV_DEBUG", "256")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lssvc_amd import hip_ops as ops  # noqa: E402
+from lssvc_amd import _lib  # noqa: E402
+from lssvc_amd.weights import WeightStore  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    ops.set_conv_precision("f16x3")
+    g = torch.Generator().manual_seed(0)
+    for name, cin, cout, H, W in (("64->64 @1152x1920", 64, 64, 1152, 1920), ("128->64 @576x960", 128, 64, 576, 960)):
+        w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+        b = torch.randn(cout, generator=g)
+        Wt = WeightStore({"c.weight": w, "c.bias": b}, dev)
+        x = ops.T(torch.randn(H * W * cin, device=dev), H, W, cin, cin)
+        stamps = torch.zeros(2 * 256 * 4 * 8, dtype=torch.int64, device=dev)      # consumer records, then producer records
+        out = ops.T.empty(H, W, cout, dev)
+        import ctypes as C
+        w_dev, b_dev, co, m_pad, KH, KW = Wt.conv("c", [cin], False)
+        w16 = Wt.conv_f16x3("c", [cin], False)
+        d = _lib.ConvDesc()
+        d.inp[0] = x.v
+        d.n_in = 1
+        d.weight, d.bias = w_dev.data_ptr(), b_dev.data_ptr()
+        d.KH, d.KW, d.stride, d.pad_t, d.pad_l = 3, 3, 1, 1, 1
+        d.Cout, d.M_pad = co, m_pad
+        d.in_act, d.in_slope, d.epilogue = 0, 0.01, 0
+        d.gdn_x = _lib.View(stamps.data_ptr(), 1, 1, 1, 1)
+        d.act, d.slope, d.out_scale, d.pixel_shuffle = 0, 0.01, 1.0, 0
+        d.residual = _lib.View(None, 0, 0, 0, 0)
+        d.out = out.v
+        d.precision, d.weight16, d.weight16_unscale = _lib.PREC_F16X3, w16[0].data_ptr(), w16[1]
+        for _ in range(30):                       # warm the clock governor with back-to-back launches
+            _lib.check(_lib.lib.lssvc_conv2d(C.byref(d), ops.stream_ptr()))
+        torch.cuda.synchronize()
+        allrec = stamps.view(-1, 8).cpu().double()
+        s = allrec[:1024]
+        s = s[s[:, 5] > 0]
+        pr = allrec[1024:]
+        pr = pr[pr[:, 5] > 0]
+        comp, bar, epi, cyc, real, phases, tiles = (s[:, i].median().item() for i in range(7))
+        clock = cyc / real * 100.0                 # s_memrealtime ticks at 100 MHz
+        print("%s (%s): per consumer wave, median over %d waves: %d phases / %d tiles; total %.0f cycles at %.0f MHz" %
+              (name, _lib.lib.lssvc_conv2d_last_kernel().decode(), s.shape[0], phases, tiles, cyc, clock))
+        print("   compute %5.1f %% (%.0f cyc/phase; 336 MFMAs = 5376 issue cycles)   barrier wait %5.1f %% (%.0f cyc/phase)   "
+              "epilogue %5.1f %% (%.0f cyc/tile)" % (100 * comp / cyc, comp / phases, 100 * bar / cyc, bar / phases,
+                                                    100 * epi / cyc, epi / max(tiles, 1)))
+        if pr.shape[0]:
+            dma, ld, wait, cvt, pbar, pph, geo = (pr[:, i].median().item() for i in range(7))
+            print("   producer wave, cycles per phase: weight-DMA issue %.0f, patch-load issue %.0f, load wait %.0f, convert + LDS stores %.0f, "
+                  "barrier wait %.0f, tile geometry %.0f" % (dma / pph, ld / pph, wait / pph, cvt / pph, pbar / pph, geo / pph))
+
+
+def _unused():
+    pass
+
+
+if __name__ == "__main__":
+    main()
