@@ -20,8 +20,8 @@
 //     boundaries, so tiles have no head or tail.
 // Arithmetic, operand order inside a K-step, accumulator layout and the fused epilogue are those of
 // conv_f16x3_kernel (f16x3_step_pair per two taps x 16 channels, f16x3_step_odd for the ninth tap): results are
-// bit-identical to it. Superseded as the default by conv3_f16x3d.hip (deferred epilogue); kept selectable
-// (lssvc_set_option("f16x3_deferred", 0)) as the A/B baseline.
+// bit-identical to it. conv3_f16x3d.hip is an experimental variant with a deferred epilogue
+// (lssvc_set_option("f16x3_deferred", 1)).
 #include "conv_f16x3_kernel.h"
 
 namespace lssvc {

@@ -309,9 +309,9 @@ int dispatch_tile_f16x3_s2(const ConvP &p, int MF, int RPW, hipStream_t st) {
 }
 extern template int dispatch_tile_f16x3_s2<3>(const ConvP &, int, int, hipStream_t);
 
-// persistent 3x3 variants for large images (producer / consumer waves): conv3_f16x3d.hip (16x16-pixel tiles, epilogue
-// deferred into the next tile's MFMA stream; the default) and conv3_f16x3p.hip (24x16 tiles, epilogue at the tile
-// boundary; option f16x3_deferred = 0, kept as the A/B baseline)
+// persistent 3x3 variants for large images (producer / consumer waves): conv3_f16x3p.hip (24x16-pixel tiles, epilogue at
+// the tile boundary; the default) and conv3_f16x3d.hip (16x16 tiles, epilogue deferred into the next tile's MFMA stream;
+// option f16x3_deferred = 1: an experiment that is bit-identical but only pays for 48-channel tiles with a residual)
 bool conv3_f16x3p_wanted(const ConvP &p);
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
 int dispatch_conv3_f16x3d(const ConvP &p, hipStream_t st, char *kernel_name);

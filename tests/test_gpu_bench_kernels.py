@@ -1,6 +1,6 @@
 """Parity of the kernel instantiations the BENCHMARK runs (round-1 verdict, "What's weak" 1).
 
-The dispatcher picks a kernel by tile count: conv3_f16x3d_kernel<MF, INACT> / conv3_f16x3p_kernel (persistent, warp-specialised) only for 3x3
+The dispatcher picks a kernel by tile count: conv3_f16x3p_kernel<MF, INACT> (persistent, warp-specialised) only for 3x3
 stride-1 convs with >= 256 tiles, the RPW = 4 instantiations of the tiled kernels only for grids of >= 512
 workgroups. The small shapes of test_gpu_ops.py never reach those, so every case here is sized to DISPATCH the
 kernel under test (asserted through the op log) and compared with an fp64 reference of the same op:
@@ -110,8 +110,7 @@ def test_persistent_3x3_matches_fp64(hip, cins, cout, H, W, in_act, act, residua
 
     got16, k16 = _run(hip, "f16x3", launch)
     got32, k32 = _run(hip, "f32", launch)
-    want = "conv3_f16x3%s_kernel<%d, %s>" % ("d" if sum(cins) > 16 else "p", mf, "true" if in_act else "false")
-    assert k16 == want, k16                                           # really the persistent kernel (deferred-epilogue variant)
+    assert k16 == "conv3_f16x3p_kernel<%d, %s>" % (mf, "true" if in_act else "false"), k16     # really the persistent kernel
     assert k32.startswith("conv_mfma_kernel"), k32
     assert got16.shape == ref.shape
     e16 = (got16.double() - ref).abs().max().item()
@@ -143,9 +142,9 @@ def test_persistent_3x3_is_bit_identical_to_tiled(hip, cins, cout, H, W, in_act,
     try:
         _set("f16x3_persist", 1)
         _set("f16x3_deferred", 1)
-        a, ka = _run(hip, "f16x3", launch)                    # 16x16 tiles, deferred epilogue (conv3_f16x3d.hip, the default)
+        a, ka = _run(hip, "f16x3", launch)                    # 16x16 tiles, deferred epilogue (conv3_f16x3d.hip, experimental)
         _set("f16x3_deferred", 0)
-        c, kc = _run(hip, "f16x3", launch)                    # 24x16 tiles, epilogue at the tile boundary (conv3_f16x3p.hip)
+        c, kc = _run(hip, "f16x3", launch)                    # 24x16 tiles, epilogue at the tile boundary (conv3_f16x3p.hip, default)
         _set("f16x3_persist", 0)
         b_, kb = _run(hip, "f16x3", launch)                   # tiled kernel
     finally:
@@ -176,7 +175,7 @@ def test_persistent_3x3_small_grids(hip):
             for pp, prefix in ((1, "conv3_f16x3d_kernel"), (0, "conv3_f16x3p_kernel")):
                 _set("f16x3_deferred", pp)
                 a, ka = _run(hip, "f16x3", lambda: back(hip.conv(Wt, "c", nhwc(hip, x))))
-                assert ka.startswith(prefix), ka
+                assert ka.startswith(prefix) or (pp == 1 and cout < 48 and ka.startswith("conv3_f16x3p_kernel")), ka   # < 48 channels: no deferred variant
                 assert torch.equal(a, b_), (H, W, cout, prefix)
     finally:
         _set("f16x3_persist_min_tiles", old_min)
