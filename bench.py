@@ -42,14 +42,14 @@ def log(*a):
 def build_inputs(device, seed, frames):
     """-> (BL frames, EL frames, padding info, the 8-bit host clip in pinned memory)."""
     from lssvc_amd.synth import synth_clip
-    from lssvc_amd.preprocess import make_layers
+    from lssvc_amd.prepost import FramePrep
     clip = synth_clip(frames, HEIGHT, WIDTH, seed=seed).pin_memory()
+    prep = FramePrep(device)
     x_els, x_bls = [], []
     for t in range(frames):
-        rgb = (clip[t:t + 1].to(device).float() / 255.0)
-        x_bl, x_el, pad = make_layers(rgb, RATIO)
-        x_els.append(x_el.contiguous())
-        x_bls.append(x_bl.contiguous())
+        x_bl, x_el, pad = prep.make_layers_rgb8(clip[t].to(device), RATIO)
+        x_els.append(x_el)
+        x_bls.append(x_bl)
     return x_bls, x_els, pad, clip
 
 
@@ -58,15 +58,15 @@ class HostFrames:
     converted and split into the two layers on the device, every time it is asked for (test.py:185-199)."""
 
     def __init__(self, clip_u8, device):
+        from lssvc_amd.prepost import FramePrep
         self.clip, self.device = clip_u8, device
+        self.prep = FramePrep(device)                    # csrc/prepost.hip: u8 -> fp32 + padding, bicubic base layer
 
     def __len__(self):
         return self.clip.shape[0]
 
     def layers(self, t):
-        from lssvc_amd.preprocess import make_layers
-        rgb = self.clip[t:t + 1].to(self.device, non_blocking=True).float().div_(255.0)
-        x_bl, x_el, _ = make_layers(rgb, RATIO)
+        x_bl, x_el, _ = self.prep.make_layers_rgb8(self.clip[t].to(self.device, non_blocking=True), RATIO)
         return x_bl, x_el
 
 
@@ -343,7 +343,7 @@ def main():
                 "value": round(world * args.frames * incl_steps / dt_incl, 4), "unit": "frames/s", "steps": incl_steps,
                 "ms_per_step": round(1e3 * dt_incl / incl_steps, 2),
                 "what": "same GOP; per frame inside the clock: H2D of the 8-bit 1080x1920 RGB frame from pinned host memory "
-                        "(6.2 MB), u8 -> fp32, zero padding to 1152x1920, MATLAB-bicubic BL 576x960 (lssvc_amd.preprocess), "
+                        "(6.2 MB), u8 -> fp32, zero padding to 1152x1920, MATLAB-bicubic BL 576x960 (HIP kernels, csrc/prepost.hip), "
                         "encode, D2H of the bit counts (BASELINE.md section 3 'GPU side')",
                 "bits_equal_resident_run": bool(bits_incl == bits)}
         pel = HEIGHT * WIDTH

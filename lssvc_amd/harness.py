@@ -6,9 +6,9 @@
 Same command line, dataset config schema (`recommend_test_config.json`), sequencing and result files
 (`{output_path}/{ratio}_{BL,EL,FL}.json`, keys of src/utils/common.py:25-37) as the reference's test.py, so its RD
 scripts keep working. What is different, deliberately:
-  * everything per frame runs on the GPU: 4:2:0 -> RGB (test.py:185-186 does it with scipy on the host), zero padding,
-    the MATLAB-bicubic base layer (`preprocess.imresize_bicubic`), the codec itself, clamping and the PSNRs; only the raw
-    8-bit planes go up and a handful of scalars come back per frame;
+  * everything per frame runs on the GPU, as HIP kernels (csrc/prepost.hip via lssvc_amd.prepost): 4:2:0 -> RGB
+    (test.py:185-186 does it with scipy on the host), zero padding, the MATLAB-bicubic base layer, the codec itself,
+    clamping and the PSNR sums; only the raw 8-bit planes go up and a handful of scalars come back per frame;
   * work is sharded at GOP granularity, not per sequence (a GOP restarts from an I-frame with no carried state,
     test.py:219-227, so results are identical): with --worker 8 a single 96-frame sequence keeps 3 GPUs busy instead of
     1, and `--worker N` processes are pinned `process_idx % gpu_num` exactly like test.py:648-656;
@@ -30,7 +30,18 @@ import torch
 import torch.nn.functional as F
 
 from . import preprocess
+from .hip_ops import T
+from .prepost import FramePrep, psnr_from_sum
 from .shard import split_gops
+
+_PREP = {}
+
+
+def _prep(device):
+    key = str(device)
+    if key not in _PREP:
+        _PREP[key] = FramePrep(device)
+    return _PREP[key]
 
 RATIO_FACTOR = {"x1_5": 1.5, "x2": 2.0, "x3": 3.0, "x4": 4.0}          # test.py:27-33
 RATIO_LIST = ["x2", "x1_5"]                                            # test.py:681
@@ -183,15 +194,19 @@ def code_frames(i_net, p_net, reader, first_frame, n_frames, gop_size, ratio, de
     if bin_folder is not None:
         for tag in ("BL", "EL"):
             os.makedirs(os.path.join(bin_folder, ratio, tag), exist_ok=True)
+    prep = _prep(device)
+    (h_bl, w_bl), (h_el, w_el) = pad["LR_size"], pad["HR_size"]
     for frame_idx in range(first_frame, first_frame + n_frames):
         planes = reader.read()
         if planes is None:
             raise ValueError("sequence ends before frame %d" % frame_idx)
-        rgb_el, y_el, u_el, v_el = yuv420_to_rgb(*planes, device)
-        x_el = F.pad(rgb_el, pad["P_HR"], mode="constant", value=0)
-        x_bl = preprocess.imresize_bicubic(x_el, (h_blp, w_blp)).clamp_(0, 1)
-        rgb_bl = _crop(x_bl, pad["P_LR"])
-        y_bl, u_bl, v_bl = rgb_to_yuv420(rgb_bl)
+        # 8-bit planes up; colour conversion, padding, the bicubic base layer and the BL reference planes on the device
+        # (csrc/prepost.hip): test.py:185-199
+        y8, u8, v8 = (torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True) for a in planes)
+        f_el, (y_el, u_el, v_el) = prep.frame_from_yuv420(y8, u8, v8, (h_elp, w_elp))
+        f_bl = prep.bicubic(f_el, (h_blp, w_blp))
+        y_bl, u_bl, v_bl = prep.rgb_to_yuv420(f_bl, h_bl, w_bl)
+        x_el, x_bl = f_el.to_nchw(), f_bl.to_nchw()
         i_net.set_scale_information(scale, (h_elp, w_elp), (0, 0, 0, 0))
         bins = (None, None)
         if bin_folder is not None:
@@ -212,13 +227,24 @@ def code_frames(i_net, p_net, reader, first_frame, n_frames, gop_size, ratio, de
             rec.update(enc_bl=r.get("encoding_time_BL", 0.0), dec_bl=r.get("decoding_time_BL", 0.0),
                        enc_el=r.get("encoding_time_EL", 0.0), dec_el=r.get("decoding_time_EL", 0.0))
         rec["bits_bl"], rec["bits_el"] = float(r["bit_bl"]), float(r["bit_el"])
-        hat_bl = _crop(dpb["ref_frame_bl"].clamp_(0, 1), pad["P_LR"])
-        hat_el = _crop(dpb["ref_frame_el"].clamp_(0, 1), pad["P_HR"])
-        rec["rgb_psnr_bl"], rec["rgb_psnr_el"] = preprocess.psnr(rgb_bl, hat_bl), preprocess.psnr(rgb_el, hat_el)
-        for tag, ref, hat in (("bl", (y_bl, u_bl, v_bl), hat_bl), ("el", (y_el, u_el, v_el), hat_el)):
-            yr, ur, vr = rgb_to_yuv420(hat)
-            py, pu, pv = _plane_psnr(yr, ref[0]), _plane_psnr(ur, ref[1]), _plane_psnr(vr, ref[2])
-            rec["yuv_" + tag] = (py, pu, pv)
+        # clamp the reconstructions in place (they are the next frame's references, test.py:249-250), then the eight
+        # squared-error sums of the frame -- RGB and Y, U, V of both layers over the unpadded crop -- in one D2H read
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        hat = {"bl": T.from_nchw(dpb["ref_frame_bl"]), "el": T.from_nchw(dpb["ref_frame_el"])}
+        prep.sqdiff_frames(hat["bl"], f_bl, h_bl, w_bl, 0)
+        prep.sqdiff_frames(hat["el"], f_el, h_el, w_el, 1)
+        for i, (tag, ref, (hh, ww)) in enumerate((("bl", (y_bl, u_bl, v_bl), (h_bl, w_bl)), ("el", (y_el, u_el, v_el), (h_el, w_el)))):
+            for j, (got, want) in enumerate(zip(prep.rgb_to_yuv420(hat[tag], hh, ww), ref)):
+                prep.sqdiff_planes(got, want, 2 + 3 * i + j)
+        sq = prep.fetch()
+        rec["rgb_psnr_bl"] = psnr_from_sum(sq[0], 3 * h_bl * w_bl) if sq[0] > 0 else float("inf")
+        rec["rgb_psnr_el"] = psnr_from_sum(sq[1], 3 * h_el * w_el) if sq[1] > 0 else float("inf")
+        for i, (tag, (hh, ww)) in enumerate((("bl", (h_bl, w_bl)), ("el", (h_el, w_el)))):
+            n_y, n_c = hh * ww, (hh // 2) * (ww // 2)
+            rec["yuv_" + tag] = (psnr_from_sum(sq[2 + 3 * i], n_y), psnr_from_sum(sq[3 + 3 * i], n_c), psnr_from_sum(sq[4 + 3 * i], n_c))
+        hat_bl = _crop(dpb["ref_frame_bl"], pad["P_LR"])
+        hat_el = _crop(dpb["ref_frame_el"], pad["P_HR"])
         if png_folder is not None:
             from PIL import Image
             for tag, hat in (("BL", hat_bl), ("EL", hat_el)):
@@ -305,6 +331,14 @@ def build_jobs(args, config):
 
 
 _NETS = {}
+_CKPT = {}          # path -> state dict: filled by the rank-0 broadcast in the torchrun mode, else loaded on demand
+
+
+def _checkpoint(path):
+    if path not in _CKPT:
+        sd = torch.load(path, map_location="cpu")
+        _CKPT[path] = sd.get("state_dict", sd) if isinstance(sd, dict) and "state_dict" in sd else sd
+    return _CKPT[path]
 
 
 def _load_nets(job, device):
@@ -314,14 +348,16 @@ def _load_nets(job, device):
         from . import IntraSS, LSSVC_extend, hip_ops
         if not _NETS:
             hip_ops.reserve_device_memory(torch.device(device))
-        sd = torch.load(job["i_path"], map_location="cpu")
-        i_net = IntraSS.from_state_dict(sd.get("state_dict", sd) if isinstance(sd, dict) else sd).to(device).eval()
+        i_net = IntraSS.from_state_dict(_checkpoint(job["i_path"])).to(device).eval()
         p_net = None
         if not job["force_intra"]:
-            sd = torch.load(job["p_path"], map_location="cpu")
             p_net = LSSVC_extend()
-            p_net.load_dict(sd.get("state_dict", sd) if isinstance(sd, dict) else sd)
+            p_net.load_dict(_checkpoint(job["p_path"]))
             p_net = p_net.to(device).eval()
+        if os.environ.get("LSSVC_GRAPH", "0") == "1" and not job["write_stream"]:
+            i_net.set_graph_mode(True)               # hipGraph frame plans (intra.FramePlan)
+            if p_net is not None:
+                p_net.set_graph_mode(True)
         if job["write_stream"]:
             if p_net is not None:
                 p_net.update(force=True)
@@ -395,7 +431,25 @@ def main(argv=None):
         config = json.load(f)
     jobs = build_jobs(args, config)
     begin = time.time()
-    if args.worker <= 1:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # one process per GPU under `python -m torch.distributed.run --nproc-per-node N test.py ...`: GOP jobs are dealt
+        # round-robin over the ranks, rank 0 alone reads the checkpoints and broadcasts them (RCCL), per-frame records are
+        # gathered at the end, rank 0 writes the result files. No data-path collective.
+        import torch.distributed as dist
+        from .shard import broadcast_state_dicts, run_sharded
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        device = "cuda:%d" % local
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        _CKPT.update(broadcast_state_dicts(list(args.i_frame_model_path) + list(args.model_path), dist, device))
+        results = run_sharded(jobs, lambda j: run_job(j, device=device), dist)
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return None
+    elif args.worker <= 1:
         results = [run_job(j, device="cuda:0") for j in jobs]                   # in-process: no child interpreter
     else:
         ctx = multiprocessing.get_context("spawn")                              # as test.py:676; before any GPU call here

@@ -42,3 +42,70 @@ def max_over_ranks(seconds, dist=None, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
+
+
+def broadcast_state_dicts(paths, dist=None, device="cpu", loader=None):
+    """{path: state_dict} on every rank, with only rank 0 touching the file system: rank 0 loads each checkpoint
+    (`loader(path)`, default torch.load + unwrap of {"state_dict": ...}), packs all tensors of all checkpoints into ONE
+    flat byte blob and broadcasts it (RCCL over xGMI when `device` is a GPU: ~245 MB once per run; gloo on CPUs) together
+    with a small manifest; the other ranks cut their state dicts out of the blob. This is the "RCCL broadcast of the
+    I-frame reference / weights" step of SURVEY 8(e): the only collective besides the end-of-run gather of scalars."""
+    import torch
+
+    def default_loader(path):
+        sd = torch.load(path, map_location="cpu")
+        return sd.get("state_dict", sd) if isinstance(sd, dict) and "state_dict" in sd else sd
+
+    loader = loader or default_loader
+    paths = list(dict.fromkeys(paths))
+    solo = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
+    if solo:
+        return {p: loader(p) for p in paths}
+    rank = dist.get_rank()
+    manifest, blob = None, None
+    if rank == 0:
+        manifest, chunks, off = [], [], 0
+        for p in paths:
+            for name, t in loader(p).items():
+                t = t.detach().contiguous().cpu()
+                raw = t.reshape(-1).view(torch.uint8) if t.numel() else torch.empty(0, dtype=torch.uint8)    # (0-dim scalars too)
+                manifest.append((p, name, str(t.dtype).replace("torch.", ""), tuple(t.shape), off, raw.numel()))
+                chunks.append(raw)
+                off += (raw.numel() + 15) // 16 * 16                      # keep every tensor 16-byte aligned inside the blob
+                pad = off - (manifest[-1][4] + raw.numel())
+                if pad:
+                    chunks.append(torch.zeros(pad, dtype=torch.uint8))
+        blob = torch.cat(chunks) if chunks else torch.empty(0, dtype=torch.uint8)
+    box = [manifest, 0 if blob is None else blob.numel()]
+    dist.broadcast_object_list(box, src=0)
+    manifest, nbytes = box
+    buf = (blob if rank == 0 else torch.empty(nbytes, dtype=torch.uint8)).to(device)
+    if nbytes:
+        dist.broadcast(buf, src=0)
+    buf = buf.cpu()
+    out = {p: {} for p in paths}
+    for p, name, dtype, shape, off, n in manifest:
+        t = buf[off:off + n].clone().view(getattr(torch, dtype)).reshape(shape)
+        out[p][name] = t
+    return out
+
+
+def run_sharded(units, run, dist=None):
+    """Static round-robin of `units` over the ranks, `run(unit)` on each rank's share, results gathered so that EVERY rank
+    returns the full list in unit order (rank 0 writes the result files, test.py:756-789)."""
+    solo = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
+    if solo:
+        return [run(u) for u in units]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = [(i, run(u)) for i, u in enumerate(units) if i % world == rank]
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    merged = {}
+    for part in parts:
+        for i, r in part:
+            if i in merged:
+                raise RuntimeError("unit %d was run by more than one rank" % i)
+            merged[i] = r
+    if len(merged) != len(units):
+        raise RuntimeError("%d of %d units were not run" % (len(units) - len(merged), len(units)))
+    return [merged[i] for i in range(len(units))]

@@ -59,11 +59,21 @@ def test_harness_end_to_end_matches_direct_calls(workdir):
     pnet.load_dict(synth_state_dict("lssvc_extend", SEED, GAIN))
     pnet.to(DEV).eval()
     reader = H.YUV420Reader(str(workdir / "data" / "seq0" / "x1.yuv"), W_EL, H_EL)
-    bits_bl, bits_el, psnr_el = [], [], []
+    from lssvc_amd.prepost import FramePrep, psnr_from_sum
+    from lssvc_amd.hip_ops import T
+    prep = FramePrep(DEV)
+    bits_bl, bits_el, psnr_el, psnr_el_torch = [], [], [], []
     dpb = None
     for t in range(FRAMES):
-        rgb, _, _, _ = H.yuv420_to_rgb(*reader.read(), DEV)
-        x_bl, x_el, pad = preprocess.make_layers(rgb, 2.0)
+        planes = reader.read()
+        y8, u8, v8 = (torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in planes)
+        pad = preprocess.interlayer_padding(H_EL, W_EL, 2.0)
+        f_el, _ = prep.frame_from_yuv420(y8, u8, v8, pad["HR_padded_size"])            # the product's pre-processing kernels
+        f_bl = prep.bicubic(f_el, pad["LR_padded_size"])
+        x_bl, x_el = f_bl.to_nchw(), f_el.to_nchw()
+        rgb, _, _, _ = H.yuv420_to_rgb(*planes, DEV)                                 # torch restatement, for the PSNR cross-check
+        xb_t, xe_t, _ = preprocess.make_layers(rgb, 2.0)
+        assert (x_el - xe_t).abs().max().item() <= 1e-6 and (x_bl - xb_t).abs().max().item() <= 2e-6
         inet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))
         pnet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))
         if t % GOP == 0:
@@ -76,7 +86,10 @@ def test_harness_end_to_end_matches_direct_calls(workdir):
         dpb["ref_frame_el"].clamp_(0, 1)
         bits_bl.append(r["bit_bl"])
         bits_el.append(r["bit_el"])
-        psnr_el.append(preprocess.psnr(rgb, dpb["ref_frame_el"]))
+        prep.sqdiff_frames(T.from_nchw(dpb["ref_frame_el"]), f_el, H_EL, W_EL, 0)
+        psnr_el.append(psnr_from_sum(prep.fetch()[0], 3 * H_EL * W_EL))
+        psnr_el_torch.append(preprocess.psnr(rgb, dpb["ref_frame_el"]))
+    assert psnr_el == pytest.approx(psnr_el_torch, abs=1e-4)                          # fp64 sums vs torch's fp32 mean
     assert el["ave_all_frame_bpp"] == pytest.approx(sum(bits_el) / (FRAMES * H_EL * W_EL), rel=1e-12)
     assert bl["ave_all_frame_bpp"] == pytest.approx(sum(bits_bl) / (FRAMES * 64 * 64), rel=1e-12)
     assert fl["ave_all_frame_bpp"] == pytest.approx((sum(bits_bl) + sum(bits_el)) / (FRAMES * H_EL * W_EL), rel=1e-12)

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lssvc_amd.shard import split_gops, assign, gather_frame_records, max_over_ranks
+from lssvc_amd.shard import split_gops, assign, gather_frame_records, max_over_ranks, broadcast_state_dicts, run_sharded
 
 
 def _fake_code_gop(first, n):
@@ -50,3 +50,88 @@ def test_two_ranks_equal_one():
         assert p.exitcode == 0
     assert merged == gather_frame_records(single) and len(merged) == 70
     assert slow == 2.0
+
+
+# ---- the harness's torchrun mode: checkpoint broadcast from rank 0 + job sharding + end-of-run gather -----------------
+def _ckpt(seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"a.weight": torch.randn(5, 3, 3, 3, generator=g), "a.bias": torch.randn(5, generator=g), "empty": torch.zeros(0),
+            "idx": torch.arange(7, dtype=torch.int32), "half": torch.randn(3, 2, generator=g).half(), "scalar": torch.tensor(2.5)}
+
+
+def _harness_worker(rank, world, port, q, cfg_dir):
+    import json
+    import types
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lssvc_amd import harness as H
+
+    def loader(path):                                   # only rank 0 may touch the "file system"
+        assert dist.get_rank() == 0, "rank %d tried to read %s" % (dist.get_rank(), path)
+        return {"i.pth": _ckpt(1), "p.pth": _ckpt(2)}[os.path.basename(path)]
+
+    sds = broadcast_state_dicts(["i.pth", "p.pth", "i.pth"], dist, "cpu", loader)
+    ok = all(torch.equal(sds[p][k], v) and sds[p][k].dtype == v.dtype for p, want in (("i.pth", _ckpt(1)), ("p.pth", _ckpt(2)))
+             for k, v in want.items())
+    cfg = json.load(open(os.path.join(cfg_dir, "cfg.json")))
+    args = H.parse_args(["--i_frame_model_path", "i.pth", "--model_path", "p.pth", "--test_config", os.path.join(cfg_dir, "cfg.json"),
+                         "--cuda", "1", "--output_path", cfg_dir])
+    jobs = H.build_jobs(args, cfg)
+
+    def fake_run(job):                                  # stand-in for run_job: closed loop inside the GOP only
+        recs, state = [], 0.0
+        for t in range(job["count"]):
+            f = job["first"] + t
+            state = 0.5 * state + f + 1
+            recs.append({"frame": f, "type": 0 if t == 0 else 1, "bits_bl": state, "bits_el": 2 * state, "rgb_psnr_bl": 30.0 + f,
+                         "rgb_psnr_el": 31.0 + f, "yuv_bl": (30.0, 31.0, 32.0), "yuv_el": (33.0, 34.0, 35.0), "enc_bl": 0.0,
+                         "dec_bl": 0.0, "enc_el": 0.0, "dec_el": 0.0, "rank": dist.get_rank()})
+        return {"key": (job["ds_name"], job["ratio"], job["seq"], job["model_idx"]), "records": recs, "seconds": 1.0,
+                "pix_bl": 64 * 64, "pix_el": 128 * 128}
+
+    results = run_sharded(jobs, fake_run, dist)
+    logs = H.collect(args, cfg, results)
+    ranks_used = sorted({r["rank"] for res in results for r in res["records"]})
+    if rank == 0:
+        q.put((ok, json.dumps(logs, sort_keys=True), ranks_used, len(jobs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_harness_jobs_and_checkpoints_across_two_ranks(tmp_path):
+    import json
+    from lssvc_amd import harness as H
+    cfg = {"DS": {"test": 1, "base_path": str(tmp_path), "x1": {"width": 128, "height": 128}, "x2": {"width": 64, "height": 64},
+                  "sequences": {"seqA": {"frames": 7, "gop": 2}, "seqB": {"frames": 3, "gop": 2}}}}
+    with open(tmp_path / "cfg.json", "w") as f:
+        json.dump(cfg, f)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_harness_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, logs2, ranks_used, n_jobs = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and ranks_used == [0, 1] and n_jobs == 6
+    # the two-rank result files equal the single-process ones
+    args = H.parse_args(["--i_frame_model_path", "i.pth", "--model_path", "p.pth", "--test_config", str(tmp_path / "cfg.json"),
+                         "--cuda", "1", "--output_path", str(tmp_path)])
+
+    def fake_run(job):
+        recs, state = [], 0.0
+        for t in range(job["count"]):
+            f = job["first"] + t
+            state = 0.5 * state + f + 1
+            recs.append({"frame": f, "type": 0 if t == 0 else 1, "bits_bl": state, "bits_el": 2 * state, "rgb_psnr_bl": 30.0 + f,
+                         "rgb_psnr_el": 31.0 + f, "yuv_bl": (30.0, 31.0, 32.0), "yuv_el": (33.0, 34.0, 35.0), "enc_bl": 0.0,
+                         "dec_bl": 0.0, "enc_el": 0.0, "dec_el": 0.0, "rank": 0})
+        return {"key": (job["ds_name"], job["ratio"], job["seq"], job["model_idx"]), "records": recs, "seconds": 1.0,
+                "pix_bl": 64 * 64, "pix_el": 128 * 128}
+
+    single = H.collect(args, cfg, run_sharded(H.build_jobs(args, cfg), fake_run))
+    a, b = json.loads(logs2), json.loads(json.dumps(single, sort_keys=True))
+    for ratio in a:                                    # test_time sums wall seconds per job: identical here (1.0 each)
+        assert a[ratio] == b[ratio]
