@@ -207,14 +207,15 @@ def cpu_baseline(full_size=False):
     at EL 384x640 / BL 192x320 = 1/9 of the 1152x1920 workload's pixels, frames/s scaled by 1/9 (conv work is linear in
     pixels), GOP time = I + 31 P; (ii) torch.set_num_threads(1), which is what the reference pins per worker
     (test.py:642), on a 1/22.5-size sample (EL 256x384). `--cpu-baseline-full` times (i) at the full size instead: on the
-    GPU box's 16-core host share that takes more than 7 minutes for the two frames (measured in round 2: the run was
-    cut off by the pool's silence limit), which is why it is not the default."""
+    GPU box's 16-core host share that is several minutes of CPU work for the two frames, which is why it is not the
+    default."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count()
-    cores = max(1, usable)
+    cores = max(1, min(usable, 16))       # a 1-GPU box owns a 16-core share of a 256-thread host: more threads than that
+    #                                        oversubscribe the share and run an order of magnitude slower (measured)
     H, W = (1152, 1920) if full_size else (384, 640)
     log("  cpu baseline: %d threads (os.cpu_count() = %s), 1 I + 1 P at EL %dx%d ..." % (cores, os.cpu_count(), H, W))
     t_i, t_p = _oracle_frames(H, W, cores)
@@ -229,7 +230,7 @@ def cpu_baseline(full_size=False):
         "EL 384x640 / BL 192x320 (1/9 of the pixels), scaled by 1/9"
     return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "1 I-frame (%.2f s) + 1 P-frame (%.2f s) at %s, GOP-32 mix (1 I + 31 P); %d threads "
-                      "(os.cpu_count() = %s, usable = %d); torch %s CPU fp32" % (t_i, t_p, size, cores, os.cpu_count(), usable,
+                      "(os.cpu_count() = %s, affinity = %d, capped at the 16-core share of a 1-GPU box); torch %s CPU fp32" % (t_i, t_p, size, cores, os.cpu_count(), usable,
                                                                                 torch.__version__),
             "single_thread": {"value": round(fps1, 6), "unit": "frames/s", "cores": 1,
                               "sample": "torch.set_num_threads(1) (test.py:642): 1 I (%.2f s) + 1 P (%.2f s) at EL %dx%d, scaled by "

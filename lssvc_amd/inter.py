@@ -406,11 +406,13 @@ class LSSVC_extend(_HostModel):
         assert tuple(x_el.shape[2:]) == self.shape_hr, "x_el is %dx%d but shape_hr is %s" % (x_el.shape[2], x_el.shape[3], self.shape_hr)
         tensors = {"x_bl": x_bl, "x_el": x_el, "ref_frame_bl": ref_frame_bl, "ref_frame_el": ref_frame_el,
                    "ref_feature_bl": ref_feature_bl, "ref_feature_el": ref_feature_el}
+        t_issue = time.perf_counter()
         if self.graph_mode:
             key = ("p",) + tuple(None if v is None else tuple(v.shape) for v in tensors.values()) + (ops.CONV_PRECISION,)
             r = self._run_planned(key, tensors, self._frame_body)
         else:
             r = self._frame_body({k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()})
+        self.last_issue_s = time.perf_counter() - t_issue        # host time to put the frame on the stream (no GPU wait)
         dpb = {"ref_frame_bl": r["recon_bl"].to_nchw(remember=True), "ref_feature_bl": r["feature_bl"].to_nchw(remember=True),
                "ref_frame_el": r["recon_el"].to_nchw(remember=True), "ref_feature_el": r["feature_el"].to_nchw(remember=True)}
         out = {"dpb": dpb, "mv_hat": r["mv_hat"].to_nchw(), "warp_frame": r["warp_frame"].to_nchw(),

@@ -8,6 +8,7 @@ NCHW fp32 torch tensors exactly like the reference's.
 """
 import math
 import os as _os
+import time as _time
 
 import torch
 
@@ -80,6 +81,7 @@ class _HostModel:
         self._medians = {}
         self.graph_mode = _os.environ.get("LSSVC_GRAPH", "0") == "1"
         self._plans = {}
+        self.last_issue_s = 0.0
 
     def set_graph_mode(self, on=True):
         """Estimate-mode frames through captured hipGraphs (FramePlan). Results are bit-identical to the eager path;
@@ -291,10 +293,12 @@ class IntraSS(_HostModel):
         H, Wd = self.shape_hr
         assert tuple(x_el.shape[2:]) == (H, Wd), "x_el is %dx%d but shape_hr is %dx%d" % (x_el.shape[2], x_el.shape[3], H, Wd)
         tensors = {"x_bl": x_bl, "x_el": x_el}
+        t_issue = _time.perf_counter()
         if self.graph_mode:
             r = self._run_planned(("i", tuple(x_bl.shape), tuple(x_el.shape), ops.CONV_PRECISION), tensors, self._frame_body)
         else:
             r = self._frame_body({k: T.from_nchw(v) for k, v in tensors.items()})
+        self.last_issue_s = _time.perf_counter() - t_issue       # host time to put the frame on the stream (no GPU wait)
         x_hat_bl, x_hat, feature = r["x_hat_bl"], r["x_hat_el"], r["feature_el"]
         out = {"x_hat_bl": x_hat_bl.to_nchw(remember=True), "x_hat_el": x_hat.to_nchw(remember=True), "feature_el": feature.to_nchw(remember=True)}
         s = self.slots.fetch()

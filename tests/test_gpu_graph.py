@@ -71,8 +71,10 @@ def test_graph_replay_is_bit_identical_to_eager(H, W, precision):
 
 
 def test_graph_mode_host_time_per_frame():
-    """What the plan is for: host time to issue one 256x256 frame. Eager: Python + ctypes per launch (~250-400 launches);
-    graph: input copies + one hipGraphLaunch. Timed with the GPU idle-waited out (synchronize outside the clock)."""
+    """What the plan is for: HOST time to put one frame on the stream (`last_issue_s`: entry of encode_decode to the
+    point where every launch has been issued, before the D2H read of the bit counters). Eager: Python + ctypes per launch
+    (~400 launches per P-frame); graph: input copies + one hipGraphLaunch. The frame's wall time at 256x256 is GPU-bound
+    (~400 dependent small kernels) and does not change; it is printed for DESIGN.md."""
     from lssvc_amd.synth import synth_clip
     from lssvc_amd.preprocess import imresize_bicubic
     H = W = 256
@@ -82,25 +84,33 @@ def test_graph_mode_host_time_per_frame():
     inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
     pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
 
-    def one_p(dpb):
-        return pnet.encode_decode(x_bl[1:2], x_el[1:2], dpb)["dpb"]
-
     def timed(n):
         r = inet.encode_decode(x_bl[0:1], x_el[0:1], None, None)
         dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
-        dpb = one_p(dpb)
-        for _ in range(3):
-            dpb = one_p(dpb)
+        for _ in range(4):
+            dpb = pnet.encode_decode(x_bl[1:2], x_el[1:2], dpb)["dpb"]
+        i_issue, i_wall = [], []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            inet.encode_decode(x_bl[0:1], x_el[0:1], None, None)
+            i_wall.append(time.perf_counter() - t0)
+            i_issue.append(inet.last_issue_s)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        issue, t0 = [], time.perf_counter()
         for _ in range(n):
-            dpb = one_p(dpb)                     # includes the D2H read of the bit counters = one sync per frame
+            dpb = pnet.encode_decode(x_bl[1:2], x_el[1:2], dpb)["dpb"]        # includes the D2H read of the bit counters
+            issue.append(pnet.last_issue_s)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
+        return sorted(issue)[n // 2], (time.perf_counter() - t0) / n, sorted(i_issue)[2], sorted(i_wall)[2]
 
-    eager = timed(20)
+    e_issue, e_wall, ei_issue, ei_wall = timed(20)
     inet.set_graph_mode(True)
     pnet.set_graph_mode(True)
-    graph = timed(20)
-    print("256x256 P-frame wall per frame: eager %.2f ms, graph %.2f ms" % (eager * 1e3, graph * 1e3))
-    assert graph < 0.6 * eager, (eager, graph)
+    g_issue, g_wall, gi_issue, gi_wall = timed(20)
+    print("256x256 P-frame: host issue eager %.2f ms -> graph %.2f ms; wall per frame eager %.2f ms, graph %.2f ms" %
+          (e_issue * 1e3, g_issue * 1e3, e_wall * 1e3, g_wall * 1e3))
+    print("256x256 I-frame (configs[0]): host issue eager %.2f ms -> graph %.2f ms; latency eager %.2f ms, graph %.2f ms" %
+          (ei_issue * 1e3, gi_issue * 1e3, ei_wall * 1e3, gi_wall * 1e3))
+    assert g_issue < 2e-3 and g_issue < 0.5 * e_issue, (e_issue, g_issue)
+    assert g_wall <= 1.1 * e_wall, (e_wall, g_wall)
