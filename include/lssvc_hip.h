@@ -85,6 +85,10 @@ typedef struct lssvc_conv_desc {
     float weight16_unscale; /* F16X3 only: weight16 holds w * 2^e (a power of two chosen so that the lo parts are
                              * normal fp16 numbers); the accumulators are multiplied by this 2^-e (exact) before the
                              * epilogue. 0 is read as 1. */
+    lssvc_view residual2; /* a second tensor added after `residual` (out = (act(conv) + residual) + residual2): the skip
+                           * sums that follow a ResBlock, e.g. MultiScaleContextFusion's `context1 + res_block1_out(...)`
+                           * (lssvc_modules.py:226-231), folded into the block's last conv. ptr NULL = none; needs
+                           * `residual`, 16-byte addressable views and the plain (no GDN / shuffle / scale) epilogue. */
 } lssvc_conv_desc;
 
 int lssvc_conv2d(const lssvc_conv_desc *d, void *stream);

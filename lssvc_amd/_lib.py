@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("residual", View), ("out_scale", C.c_float),
         ("pixel_shuffle", C.c_int32), ("out", View),
         ("precision", C.c_int32), ("weight16", C.c_void_p), ("weight16_unscale", C.c_float),
+        ("residual2", View),
     ]
 
 

@@ -9,10 +9,19 @@ from . import hip_ops as ops
 from .hip_ops import T
 
 
-def res_block(W, p, x, slope=0.01, start_from_relu=True, end_with_relu=False, out=None):
-    """ResBlock (layers.py:229-255, video_net_component.py:170-188): x + [lrelu]conv2(lrelu(conv1([lrelu]x)))."""
+FOLD_SKIP_ADDS = True      # fold `skip + res_block(x)` into the block's last conv (second residual operand); False: separate add
+
+
+def res_block(W, p, x, slope=0.01, start_from_relu=True, end_with_relu=False, out=None, skip=None):
+    """ResBlock (layers.py:229-255, video_net_component.py:170-188): x + [lrelu]conv2(lrelu(conv1([lrelu]x))).
+    skip: an outer sum `skip + block(x)` that follows the block (lssvc_modules.py:226-231), computed in the same launch as
+    (conv2 + x) + skip -- the reference's rounding order, fp32 addition being commutative."""
     t = ops.conv(W, p + ".conv1", x, in_act="lrelu" if start_from_relu else None, in_slope=slope, act="lrelu", slope=slope)
-    return ops.conv(W, p + ".conv2", t, act="lrelu" if end_with_relu else None, slope=slope, residual=x, out=out)
+    if skip is None:
+        return ops.conv(W, p + ".conv2", t, act="lrelu" if end_with_relu else None, slope=slope, residual=x, out=out)
+    if FOLD_SKIP_ADDS and x.C % 4 == 0 and x.ld % 4 == 0 and skip.ld % 4 == 0 and (out is None or out.ld % 4 == 0):
+        return ops.conv(W, p + ".conv2", t, act="lrelu" if end_with_relu else None, slope=slope, residual=x, residual2=skip, out=out)
+    return ops.add(skip, ops.conv(W, p + ".conv2", t, act="lrelu" if end_with_relu else None, slope=slope, residual=x), out=out)
 
 
 def residual_block(W, p, x):
@@ -75,11 +84,11 @@ def context_fusion(W, p, t1, t2, t3, outs=(None, None, None)):
     """MultiScaleTextureFusion / MultiScaleContextFusion (layers.py:311-339, dmc_net.py:34-62,
     lssvc_modules.py:203-232). `outs` lets the caller place the three results (e.g. into concat slices)."""
     c3_up = res_block(W, p + ".res_block3_up", ops.subpel(W, p + ".conv3_up", t3))
-    c3_out = res_block(W, p + ".res_block3_out", ops.conv(W, p + ".conv3_out", t3))
+    o3 = res_block(W, p + ".res_block3_out", ops.conv(W, p + ".conv3_out", t3), skip=t3, out=outs[2])        # context3 + ...
     c2_up = res_block(W, p + ".res_block2_up", ops.subpel(W, p + ".conv2_up", [c3_up, t2]))
-    c2_out = res_block(W, p + ".res_block2_out", ops.conv(W, p + ".conv2_out", [c3_up, t2]))
-    c1_out = res_block(W, p + ".res_block1_out", ops.conv(W, p + ".conv1_out", [c2_up, t1]))
-    return ops.add(t1, c1_out, out=outs[0]), ops.add(t2, c2_out, out=outs[1]), ops.add(t3, c3_out, out=outs[2])
+    o2 = res_block(W, p + ".res_block2_out", ops.conv(W, p + ".conv2_out", [c3_up, t2]), skip=t2, out=outs[1])
+    o1 = res_block(W, p + ".res_block1_out", ops.conv(W, p + ".conv1_out", [c2_up, t1]), skip=t1, out=outs[0])
+    return o1, o2, o3
 
 
 def res_encoder_gdn(W, p, x, c1, c2, c3, flavour):

@@ -486,7 +486,7 @@ int dispatch_conv3_f16x3d(const ConvP &p, hipStream_t st, char *kernel_name) {
     const int mf = (frags > 4 && frags % 4 != 0 && frags % 3 == 0) ? 3 : (frags >= 4 ? 4 : frags);
     // one phase per tile (Cin <= 16): nothing to defer into; fewer than 48 output channels: too little MFMA work per
     // staged patch for the smaller tile -- both stay on the 24x16 kernel
-    if (p.n_chunks16 < 2 || mf < 3) return dispatch_conv3_f16x3p(p, st, kernel_name);
+    if (p.n_chunks16 < 2 || mf < 3 || p.res2.p != nullptr) return dispatch_conv3_f16x3p(p, st, kernel_name);
     const bool inact = p.in_act == LSSVC_INACT_LRELU, res = p.res.p != nullptr;
     snprintf(kernel_name, 96, "conv3_f16x3d_kernel<%d, %s, %s>", mf, inact ? "true" : "false", res ? "true" : "false");
 #define LSSVC_D_CASE(m)                                                                   \

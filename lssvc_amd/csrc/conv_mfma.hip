@@ -145,6 +145,13 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     } else {
         p.res = mk_null();
     }
+    p.res2 = mk_null();
+    if (d->residual2.ptr) {
+        LSSVC_CHECK(d->residual.ptr != nullptr, "conv2d: residual2 without residual");
+        LSSVC_CHECK(view_ok(&d->residual2) && same_shape(&d->residual2, &d->out) && vec4_ok(&d->residual2),
+                    "conv2d: residual2 must match `out` and be 16-byte addressable");
+        p.res2 = mk(&d->residual2);
+    }
     if (d->epilogue != LSSVC_EPI_NONE) {
         LSSVC_CHECK(view_ok(&d->gdn_x) && same_shape(&d->gdn_x, &d->out), "conv2d: gdn_x shape mismatch");
         p.gdn_x = mk(&d->gdn_x);
@@ -160,6 +167,7 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         if (common && !d->pixel_shuffle && (!d->residual.ptr || p.res_vec)) p.fast_epi = 1;
         if (common && d->pixel_shuffle && !d->residual.ptr && (d->Cout % 16 == 0)) p.fast_epi = 2;   // cps % 4 == 0
     }
+    LSSVC_CHECK(!d->residual2.ptr || p.fast_epi == 1, "conv2d: residual2 needs the plain fused epilogue (no GDN / shuffle / scale, Cout %% 4 == 0)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     {
         static const int dbg = getenv("LSSVC_CONV_DEBUG") ? atoi(getenv("LSSVC_CONV_DEBUG")) : 0;

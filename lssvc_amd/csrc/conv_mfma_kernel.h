@@ -22,6 +22,7 @@ struct ConvP {
     int act;
     float slope;
     V res;
+    V res2;          // second residual (fast epilogue only)
     float out_scale;
     int pixel_shuffle;
     V out;
@@ -66,11 +67,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // "is there a residual" test out of the per-row code.
 typedef __attribute__((address_space(3))) const float *lds_cfloat_ptr;
 
-template <int MF, int RPW, bool PS, bool RES, bool INTERIOR, bool ACT>
+template <int MF, int RPW, bool PS, int RES, bool INTERIOR, bool ACT>      // RES: number of residual operands (0, 1, 2)
 __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
                                                         int lg, float unscale, lds_cfloat_ptr bias_lds) {
     const float s_neg = p.act == LSSVC_ACT_LRELU ? p.slope : (p.act == LSSVC_ACT_RELU ? 0.0f : 1.0f);
-    constexpr bool has_res = RES;
+    constexpr bool has_res = RES > 0;
     const f32x2 us = {unscale, unscale}, sn = {s_neg, s_neg};      // (out_scale == 1 here: the host keeps other convs off this path)
     f32x2 bb[MF][2];
 #pragma unroll
@@ -100,20 +101,23 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
             ps_off[f] = ((q >> 1) * p.out.W + (q & 1)) * p.out.ld + c;      // < 2 * W * ld: fits int
         }
     }
-    float4 rs[2][MF];
-    auto load_res = [&](int r, float4 (&d)[MF]) {
+    float4 rs[2][MF], rs2[2][RES > 1 ? MF : 1];
+    auto load_res = [&](int r, float4 (&d)[MF], float4 (&d2)[RES > 1 ? MF : 1]) {
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const int mb = m0 + f * 16 + 4 * lg;
             d[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has_res && (INTERIOR || (pix[r] >= 0 && mb < p.Cout)))
+            if (RES > 1) d2[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_res && (INTERIOR || (pix[r] >= 0 && mb < p.Cout))) {
                 d[f] = *reinterpret_cast<const float4 *>(p.res.p + (size_t)pix[r] * p.res.ld + mb);
+                if (RES > 1) d2[f] = *reinterpret_cast<const float4 *>(p.res2.p + (size_t)pix[r] * p.res2.ld + mb);
+            }
         }
     };
-    load_res(0, rs[0]);
+    load_res(0, rs[0], rs2[0]);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        if (r + 1 < RPW) load_res(r + 1, rs[(r + 1) & 1]);      // issued before row r's stores (see conv_epilogue_flat)
+        if (r + 1 < RPW) load_res(r + 1, rs[(r + 1) & 1], rs2[(r + 1) & 1]);      // issued before row r's stores (see conv_epilogue_flat)
         const size_t opix = (size_t)((INTERIOR || pix[r] >= 0) ? pix[r] : 0);
         float *orow = p.out.p + opix * p.out.ld + m0 + 4 * lg;
         float *srow = nullptr;                                   // pixel-shuffle: the 2x2 output block of this conv pixel
@@ -131,9 +135,13 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
                 v0 = f32x2{fmaxf(v0.x, n0.x), fmaxf(v0.y, n0.y)};
                 v1 = f32x2{fmaxf(v1.x, n1.x), fmaxf(v1.y, n1.y)};
             }
-            if (RES) {
+            if (RES > 0) {
                 v0 = v0 + f32x2{rs[r & 1][f].x, rs[r & 1][f].y};
                 v1 = v1 + f32x2{rs[r & 1][f].z, rs[r & 1][f].w};
+            }
+            if (RES > 1) {
+                v0 = v0 + f32x2{rs2[r & 1][f].x, rs2[r & 1][f].y};
+                v1 = v1 + f32x2{rs2[r & 1][f].z, rs2[r & 1][f].w};
             }
             float *dst = orow + f * 16;
             if (PS) dst = srow + ps_off[f];
@@ -158,9 +166,10 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
             conv_epilogue_fast_impl<MF, RPW, PS_, RES_, false, true>(p, acc, pix, m0, lg, unscale, bias_lds);                  \
         }                                                                                                                      \
     } while (0)
-    if (p.fast_epi == 2) LSSVC_EPI_CALL(true, false);                        // pixel-shuffle store (never with a residual)
-    else if (p.res.p != nullptr) LSSVC_EPI_CALL(false, true);
-    else LSSVC_EPI_CALL(false, false);
+    if (p.fast_epi == 2) LSSVC_EPI_CALL(true, 0);                            // pixel-shuffle store (never with a residual)
+    else if (p.res2.p != nullptr) LSSVC_EPI_CALL(false, 2);
+    else if (p.res.p != nullptr) LSSVC_EPI_CALL(false, 1);
+    else LSSVC_EPI_CALL(false, 0);
 #undef LSSVC_EPI_CALL
 }
 

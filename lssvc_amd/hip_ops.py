@@ -130,7 +130,8 @@ _INACT = {None: _lib.INACT_NONE, "lrelu": _lib.INACT_LRELU, "square": _lib.INACT
 
 
 def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=None, in_slope=0.01, epilogue=0,
-                 gdn_x=None, act=None, slope=0.01, residual=None, out_scale=1.0, pixel_shuffle=False, name="", w16=None):
+                 gdn_x=None, act=None, slope=0.01, residual=None, out_scale=1.0, pixel_shuffle=False, name="", w16=None,
+                 residual2=None):
     w_dev, b_dev, cout, m_pad = prepared
     d = ConvDesc()
     for i, t in enumerate(inputs):
@@ -145,6 +146,7 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
     d.gdn_x = gdn_x.v if gdn_x is not None else _NULL_VIEW
     d.act, d.slope = _ACT[act], slope
     d.residual = residual.v if residual is not None else _NULL_VIEW
+    d.residual2 = residual2.v if residual2 is not None else _NULL_VIEW
     d.out_scale = out_scale
     d.pixel_shuffle = 1 if pixel_shuffle else 0
     d.out = out.v
@@ -183,7 +185,8 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
                    "vec": all(t.C % 4 == 0 and t.ld % 4 == 0 and t.v.ptr % 16 == 0 for t in inputs),
                    "f16x3": w16 is not None, "kernel": lib.lssvc_conv2d_last_kernel().decode(),
                    "bytes": 4 * (hout * wout * cin * (stride * stride) + out.H * out.W * out.C
-                                 + (out.H * out.W * out.C if residual is not None else 0)),
+                                 + (out.H * out.W * out.C if residual is not None else 0)
+                                 + (out.H * out.W * out.C if residual2 is not None else 0)),
                    "events": (e0, e1)})
     return out
 
@@ -199,7 +202,7 @@ def pad4(t):
 
 
 def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slope=0.01, residual=None,
-         pixel_shuffle=False, out_scale=1.0, out=None, pad=None):
+         pixel_shuffle=False, out_scale=1.0, out=None, pad=None, residual2=None):
     """nn.Conv2d (+ optional fused pieces). `inputs`: a T or a list of up to 3 T's read as torch.cat(dim=1)."""
     if isinstance(inputs, T):
         inputs = [inputs]
@@ -223,7 +226,7 @@ def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slo
         w16 = W.conv_f16x3(name, splits, pixel_shuffle)
     return _conv_launch(inputs, (w_dev, b_dev, cout, m_pad), KH, KW, stride, pad, pad, out, in_act=in_act,
                         in_slope=in_slope, act=act, slope=slope, residual=residual, out_scale=out_scale,
-                        pixel_shuffle=pixel_shuffle, name=name, w16=w16)
+                        pixel_shuffle=pixel_shuffle, name=name, w16=w16, residual2=residual2)
 
 
 def subpel(W, name, inputs, **kw):

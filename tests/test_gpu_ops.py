@@ -582,3 +582,26 @@ def test_ffn_fused_outer_skip(hip, c, hidden, H, W):
     finally:
         hip.set_conv_precision("f32")
     assert torch.equal(got, want) and torch.equal(inplace, want)
+
+
+@pytest.mark.parametrize("cin,cout,k,H,W", [(64, 64, 3, 40, 56), (48, 48, 3, 300, 340), (96, 96, 3, 19, 23), (64, 64, 1, 17, 33)])
+def test_second_residual_equals_separate_add(hip, cin, cout, k, H, W):
+    """lssvc_conv_desc.residual2 (the `skip + res_block(x)` sums of the context-fusion nets folded into the block's last conv):
+    (act(conv) + residual) + residual2 in one launch is bit-identical to the conv followed by lssvc_add, in both precisions
+    and on the tiled as well as the persistent kernels."""
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(1, cin, H, W, generator=g)
+    r1, r2 = torch.randn(1, cout, H, W, generator=g), torch.randn(1, cout, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    Wt = FakeW({"c.weight": w, "c.bias": b})
+    for mode in ("f16x3", "f32"):
+        try:
+            hip.set_conv_precision(mode)
+            two = back(hip.add(nhwc(hip, r2), hip.conv(Wt, "c", nhwc(hip, x), act="lrelu", slope=0.1, residual=nhwc(hip, r1))))
+            one = back(hip.conv(Wt, "c", nhwc(hip, x), act="lrelu", slope=0.1, residual=nhwc(hip, r1), residual2=nhwc(hip, r2)))
+        finally:
+            hip.set_conv_precision("f32")
+        assert torch.equal(one, two), mode
+    want = F.leaky_relu(F.conv2d(x, w, b, padding=k // 2), 0.1) + r1 + r2
+    close(one, want)
