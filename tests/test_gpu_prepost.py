@@ -47,13 +47,14 @@ def test_yuv420_to_frame(prep, H, W, Hp, Wp):
     from lssvc_amd import harness as Hn
     g = np.random.default_rng(H)
     y, u, v = (g.integers(0, 256, s, dtype=np.uint8) for s in ((H, W), (H // 2, W // 2), (H // 2, W // 2)))
-    want, wy, wu, wv = Hn.yuv420_to_rgb(y, u, v, DEV)
+    want, wy, wu, wv = Hn.yuv420_to_rgb(y, u, v, "cpu")      # the torch restatement on the CPU, like the reference (x / 255 is a
+    #                                                          true division there; torch's CUDA kernel multiplies by 1/255)
     f, (py, pu, pv) = prep.frame_from_yuv420(*(torch.from_numpy(a).to(DEV) for a in (y, u, v)), (Hp, Wp))
-    got = f.to_nchw()
+    got = f.to_nchw().cpu()
     assert (got[:, :, :H, :W] - want).abs().max().item() <= 1e-6
     assert got[:, :, H:, :].abs().max().item() == 0 if Hp > H else True
     assert got[:, :, :, W:].abs().max().item() == 0 if Wp > W else True
-    assert torch.equal(py, wy) and torch.equal(pu, wu) and torch.equal(pv, wv)
+    assert torch.equal(py.cpu(), wy) and torch.equal(pu.cpu(), wu) and torch.equal(pv.cpu(), wv)
 
 
 def test_rgb_to_yuv420_and_sqdiff(prep):
