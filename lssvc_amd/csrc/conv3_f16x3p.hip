@@ -22,12 +22,18 @@
 // conv_f16x3_kernel (f16x3_step_pair per two taps x 16 channels, f16x3_step_odd for the ninth tap): results are
 // bit-identical to it. conv3_f16x3d.hip is an experimental variant with a deferred epilogue
 // (lssvc_set_option("f16x3_deferred", 1)).
+#include <type_traits>
+#include <utility>
+
 #include "conv_f16x3_kernel.h"
 
 namespace lssvc {
 
 #ifndef LSSVC_P3_RPW
 #define LSSVC_P3_RPW 6      // rows per consumer wave (Makefile P3_RPW); even
+#endif
+#ifndef LSSVC_P3_MFMA_PER_READ
+#define LSSVC_P3_MFMA_PER_READ 2   // consumer issue pattern: this many MFMAs, then one LDS fragment read
 #endif
 constexpr int kP3Threads = 512;
 constexpr int kP3Consumers = 4;          // waves 0..3
@@ -274,60 +280,115 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         const _Float16 *pl_ = ph_ + G::PATCH_HALFS;
         const _Float16 *wh_ = wts0 + buf * 2 * G::W_HALFS;
         const _Float16 *wl_ = wh_ + G::W_HALFS;
-#pragma unroll
-        for (int u = 0; u < NSTEP; ++u) {
+        // The phase as NSTEP x NG units (K step u, row group g of GR rows), software-pipelined and INTERLEAVED by hand.
+        // In-kernel stamps: the straightforward loop takes 6.6 k cycles per phase for 336 MFMAs = 5.4 k issue cycles, with
+        // the producers idle or not and with the fragment reads prefetched or not -- it is neither LDS latency nor
+        // producer interference but ISSUE ORDER: a wave issues in order, an MFMA holds the issue port for 8 of its 16
+        // cycles, so two 4-cycle instructions fit in every MFMA gap for free and a third delays the next MFMA. The
+        // compiler emits the ~95 ds_reads and ~60 address instructions of a phase in clumps. Here the fragment reads of
+        // unit t+1 (two register sets, every index a compile-time constant) are written before the MFMAs of unit t and
+        // sched_group_barrier lays the unit out as (2 MFMA, 1 ds_read) x reads, then the remaining MFMAs.
+        constexpr int GR = 2, NG = RPW / GR, NUNIT = NG * NSTEP;
+        static_assert(RPW % GR == 0, "row groups");
+        f16x8 fa1[2][MF], fa2[2][MF], fb1[2][GR], fb2[2][GR];
+        // Addresses: everything that depends on the lane is folded into ONE byte offset per operand and K step (the tap of
+        // a lane group is 2u + tsel, so the tap part is a per-lane select between two constants); fragment f / row r are
+        // compile-time byte offsets that the ds_read carries as its immediate. Base pointers as LDS byte addresses.
+        const unsigned a_lane = (unsigned)(li * CK16 + ch8) * 2u;                                  // bytes
+        const unsigned b_lane = (unsigned)(((wave * RPW) * PW + li) * CK16 + ch8) * 2u;
+        const unsigned wh_b = (unsigned)(size_t)(lds_cfloat_ptr)(const float *)(const void *)wh_;   // LDS byte address of the hi plane
+        const unsigned wl_b = wh_b + (unsigned)G::W_HALFS * 2u;
+        const unsigned ph_b = (unsigned)(size_t)(lds_cfloat_ptr)(const float *)(const void *)ph_;
+        const unsigned pl_b = ph_b + (unsigned)G::PATCH_HALFS * 2u;
+        auto lds_read = [](unsigned addr) {
+            return *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>((size_t)addr);
+        };
+        auto load_a = [&](int u, f16x8 (&a1)[MF], f16x8 (&a2)[MF]) {
             const bool odd = 2 * u + 1 >= NTAP;                              // the ninth tap: f16x3_step_odd
-            const int tap = odd ? 2 * u : 2 * u + tsel;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const _Float16 *wa1 = (odd && !tsel) ? wl_ : wh_, *wa2 = (odd && !tsel) ? wh_ : wl_;
-            const _Float16 *pb1 = (odd && tsel) ? pl_ : ph_;
-            f16x8 a1[MF], a2[MF];
+            const unsigned t0 = (unsigned)(2 * u) * TM * CK16 * 2u, t1 = odd ? t0 : (unsigned)(2 * u + 1) * TM * CK16 * 2u;
+            const unsigned tap_b = a_lane + (tsel ? t1 : t0);
+            const unsigned p1 = ((odd && !tsel) ? wl_b : wh_b) + tap_b, p2 = ((odd && !tsel) ? wh_b : wl_b) + tap_b;
 #pragma unroll
             for (int f = 0; f < MF; ++f) {
-                const int o = (tap * TM + f * 16 + li) * CK16 + ch8;
-                a1[f] = *reinterpret_cast<const f16x8 *>(wa1 + o);
-                a2[f] = *reinterpret_cast<const f16x8 *>(wa2 + o);
+                a1[f] = lds_read(p1 + (unsigned)(f * 16 * CK16) * 2u);
+                a2[f] = lds_read(p2 + (unsigned)(f * 16 * CK16) * 2u);
             }
+        };
+        auto load_b = [&](int u, int g, f16x8 (&b1)[GR], f16x8 (&b2)[GR]) {
+            const bool odd = 2 * u + 1 >= NTAP;
+            const int tap0 = 2 * u, tap1 = odd ? tap0 : 2 * u + 1;
+            const unsigned o0 = (unsigned)(((tap0 / 3) * PW + tap0 % 3) * CK16) * 2u, o1 = (unsigned)(((tap1 / 3) * PW + tap1 % 3) * CK16) * 2u;
+            const unsigned tap_b = b_lane + (tsel ? o1 : o0);
+            const unsigned p1 = ((odd && tsel) ? pl_b : ph_b) + tap_b, p2 = pl_b + tap_b;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                f16x8 b1[G::HALF], b2[G::HALF];
-#pragma unroll
-                for (int r = 0; r < G::HALF; ++r) {
-                    const int row = wave * RPW + half * G::HALF + r;
-                    const int o = ((row + ky) * PW + li + kx) * CK16 + ch8;
-                    b1[r] = *reinterpret_cast<const f16x8 *>(pb1 + o);
-                    if (!odd) b2[r] = *reinterpret_cast<const f16x8 *>(pl_ + o);
-                }
-                if (odd) {
-#pragma unroll
-                    for (int f = 0; f < MF; ++f)
-#pragma unroll
-                        for (int r = 0; r < G::HALF; ++r)
-                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b1[r], acc[f][half * G::HALF + r], 0, 0, 0);
-#pragma unroll
-                    for (int f = 0; f < MF; ++f)
-#pragma unroll
-                        for (int r = 0; r < G::HALF; ++r)
-                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[f], b1[r], acc[f][half * G::HALF + r], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < MF; ++f)
-#pragma unroll
-                        for (int r = 0; r < G::HALF; ++r)
-                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[f], b1[r], acc[f][half * G::HALF + r], 0, 0, 0);
-#pragma unroll
-                    for (int f = 0; f < MF; ++f)
-#pragma unroll
-                        for (int r = 0; r < G::HALF; ++r)
-                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b2[r], acc[f][half * G::HALF + r], 0, 0, 0);
-#pragma unroll
-                    for (int f = 0; f < MF; ++f)
-#pragma unroll
-                        for (int r = 0; r < G::HALF; ++r)
-                            acc[f][half * G::HALF + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b1[r], acc[f][half * G::HALF + r], 0, 0, 0);
-                }
+            for (int r = 0; r < GR; ++r) {
+                const unsigned ro = (unsigned)((g * GR + r) * PW * CK16) * 2u;
+                b1[r] = lds_read(p1 + ro);
+                if (!odd) b2[r] = lds_read(p2 + ro);
             }
-        }
+        };
+        auto unit = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int u = t / NG, g = t % NG;
+            constexpr bool odd = 2 * u + 1 >= NTAP;
+            constexpr bool more = t + 1 < NUNIT;
+            constexpr int nu = (t + 1) / NG, ng = (t + 1) % NG;
+            constexpr bool nodd = 2 * nu + 1 >= NTAP;
+            // B fragments are prefetched one unit ahead, the A fragments of K step u+1 during row group NG-2 of step u: a
+            // unit that ends in a burst of reads would make the NEXT unit's first MFMA wait for them
+            constexpr bool pre_a = (NG >= 2 ? g == NG - 2 : true) && u + 1 < NSTEP;
+            constexpr int NR = (pre_a ? 2 * MF : 0) + (more ? (nodd ? GR : 2 * GR) : 0);      // ds_reads issued in this unit
+            constexpr int NM = (odd ? 2 : 3) * MF * GR;                                       // MFMAs of this unit
+            if (pre_a) load_a(u + 1, fa1[(u + 1) & 1], fa2[(u + 1) & 1]);
+            if (more) load_b(nu, ng, fb1[(t + 1) & 1], fb2[(t + 1) & 1]);
+            const f16x8(&a1)[MF] = fa1[u & 1];
+            const f16x8(&a2)[MF] = fa2[u & 1];
+            const f16x8(&b1)[GR] = fb1[t & 1];
+            const f16x8(&b2)[GR] = fb2[t & 1];
+            if (odd) {
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < GR; ++r)
+                        acc[f][g * GR + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b1[r], acc[f][g * GR + r], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < GR; ++r)
+                        acc[f][g * GR + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[f], b1[r], acc[f][g * GR + r], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < GR; ++r)
+                        acc[f][g * GR + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[f], b1[r], acc[f][g * GR + r], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < GR; ++r)
+                        acc[f][g * GR + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b2[r], acc[f][g * GR + r], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int r = 0; r < GR; ++r)
+                        acc[f][g * GR + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[f], b1[r], acc[f][g * GR + r], 0, 0, 0);
+            }
+            // issue order of this unit: (2 MFMA, 1 ds_read) per prefetched read, then the rest of the MFMAs
+            constexpr int MPR = LSSVC_P3_MFMA_PER_READ;
+            constexpr int NI = (MPR * NR <= NM) ? NR : NM / MPR;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (NR > NI) __builtin_amdgcn_sched_group_barrier(0x100, NR - NI, 0);
+            if (NM > MPR * NI) __builtin_amdgcn_sched_group_barrier(0x008, NM - MPR * NI, 0);
+            __builtin_amdgcn_sched_barrier(0);                                                 // units do not mix
+        };
+        load_a(0, fa1[0], fa2[0]);
+        load_b(0, 0, fb1[0], fb2[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, NUNIT>{});
         if (STAMP) {
             const long long t = __builtin_amdgcn_s_memtime();
             t_comp += t - t_mark;
