@@ -144,7 +144,7 @@ def roofline_from_log(op_log):
     dom = table[0]
     common = {"kernel": dom["kernel"], "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
               "gflop_per_launch": dom["gflop_per_launch"], "mbytes_per_launch": dom["mbytes_per_launch"],
-              "traffic": pmc_traffic(dom["kernel"]),
+              "traffic": pmc_traffic(dom["kernel"]), "mfma_busy": pmc_mfma_busy(dom["kernel"]),
               "sampled_frames": EVENT_FRAMES,
               "conv_time_ms_sampled": round(sum(r["total_ms"] for r in table), 2),
               "conv_tflop_sampled": round(sum(r["gflop_per_launch"] * r["launches"] for r in table) * 1e-3, 3)}
@@ -163,17 +163,46 @@ def roofline_from_log(op_log):
     return roof, table
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round present (the PMC passes cannot run inside bench.py: rocprofv3 wraps it)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    legacy = os.path.join(ROOT, "profiles", suffix)
+    return hits[-1] if hits else (legacy if os.path.exists(legacy) else None)
+
+
+def _strip_tmpl(name):
+    return name.replace("lssvc::", "").replace(" ", "")
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     separate runs, gfx950 FETCH correction applied) -- bench.py cannot run the profiler on itself."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = _latest_profile("pmc_traffic.json")
     try:
         with open(path) as f:
             for rec in json.load(f):
-                if rec["kernel"].replace("lssvc::", "") == kernel:
-                    return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch_corrected"], "source": "profiles/pmc_traffic.json",
-                            "collected_on": rec.get("command")}
-    except (OSError, ValueError, KeyError):
+                if _strip_tmpl(rec["kernel"]).startswith(_strip_tmpl(kernel).rstrip(">")):
+                    return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch_corrected"], "kernel_in_profile": rec["kernel"],
+                            "source": os.path.relpath(path, ROOT), "collected_on": rec.get("command")}
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return None
+
+
+def pmc_mfma_busy(kernel):
+    """Matrix-pipe busy fraction and implied shader clock of `kernel` from the committed SQ counter pass."""
+    path = _latest_profile("mfma_busy.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        for rec in doc["kernels"]:
+            if _strip_tmpl(rec["kernel"]).startswith(_strip_tmpl(kernel).rstrip(">")):
+                out = {k: rec[k] for k in ("mfma_busy_frac_of_wall", "clock_ghz_from_grbm", "mfma_busy_frac_of_sq_busy",
+                                           "clock_ghz_from_sq_busy") if k in rec}
+                out.update(kernel_in_profile=rec["kernel"], source=os.path.relpath(path, ROOT), collected_on=doc.get("command"))
+                return out
+    except (OSError, ValueError, KeyError, TypeError):
         pass
     return None
 
