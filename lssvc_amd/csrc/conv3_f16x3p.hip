@@ -276,10 +276,8 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     }
     for (int k = 0; k < total; ++k) {
         const int buf = k & 1;
-        const _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;
-        const _Float16 *pl_ = ph_ + G::PATCH_HALFS;
+        const _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;            // hi plane; the lo plane follows it
         const _Float16 *wh_ = wts0 + buf * 2 * G::W_HALFS;
-        const _Float16 *wl_ = wh_ + G::W_HALFS;
         // The phase as NSTEP x NG units (K step u, row group g of GR rows), software-pipelined and INTERLEAVED by hand.
         // In-kernel stamps: the straightforward loop takes 6.6 k cycles per phase for 336 MFMAs = 5.4 k issue cycles, with
         // the producers idle or not and with the fragment reads prefetched or not -- it is neither LDS latency nor
