@@ -306,6 +306,7 @@ int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, u
  *                                    with the epilogue deferred into the next tile's MFMA stream wherever that kernel exists;
  *                                    2 (default) = the deferred kernel only where it measured faster (48-channel tiles with at
  *                                    most three 16-channel phases) (LSSVC_F16X3_DEFERRED)
+ *   "f16x3_persist7"           1/0   the persistent warp-specialised kernel for 7x7 convs too (LSSVC_F16X3_PERSIST7)
  * Results do not depend on them (the kernels they choose between are bit-identical); tests use them to pin that. */
 int lssvc_set_option(const char *name, int32_t value);
 int lssvc_get_option(const char *name, int32_t *value);

@@ -315,6 +315,9 @@ extern template int dispatch_tile_f16x3_s2<3>(const ConvP &, int, int, hipStream
 bool conv3_f16x3p_wanted(const ConvP &p);
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
 int dispatch_conv3_f16x3d(const ConvP &p, hipStream_t st, char *kernel_name);
+// ... and the 7x7 counterpart (conv7_f16x3p.hip)
+bool conv7_f16x3p_wanted(const ConvP &p);
+int dispatch_conv7_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
 
 extern template int dispatch_tile_f16x3<3, 1>(const ConvP &, int, int, hipStream_t);
 extern template int dispatch_tile_f16x3<7, 1>(const ConvP &, int, int, hipStream_t);

@@ -26,9 +26,9 @@ namespace lssvc {
 // ---- runtime tuning switches: environment at first use, lssvc_set_option() afterwards ----------------
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<bool> g_opt_set[OPT_COUNT];
-static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_DEFERRED"};
-static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_deferred"};
-static const int kOptDefault[OPT_COUNT] = {1, 256, 2};
+static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_DEFERRED", "LSSVC_F16X3_PERSIST7"};
+static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_deferred", "f16x3_persist7"};
+static const int kOptDefault[OPT_COUNT] = {1, 256, 2, 1};
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
         const char *e = getenv(kOptEnv[which]);
@@ -208,6 +208,8 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, 3, 2>", MF, RPW);
             return dispatch_tile_f16x3_s2<3>(p, MF, RPW, st);
         }
+        if (vec && sd == 1 && ks == 7 && d->in_act != LSSVC_INACT_SQUARE && option_get(OPT_P7_ON) && conv7_f16x3p_wanted(p))
+            return dispatch_conv7_f16x3p(p, st, kname);
         if (vec && sd == 1 && (ks == 3 || ks == 7)) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, %d, 1>", MF, RPW, ks);
             return ks == 3 ? dispatch_tile_f16x3<3, 1>(p, MF, RPW, st) : dispatch_tile_f16x3<7, 1>(p, MF, RPW, st);

@@ -201,8 +201,11 @@ TILED_CASES = [
 ]
 
 
+@pytest.mark.parametrize("persist7", [1, 0])
 @pytest.mark.parametrize("cins,cout,k,H,W,act,residual,kernel", TILED_CASES)
-def test_tiled_rpw4_matches_fp64(hip, cins, cout, k, H, W, act, residual, kernel):
+def test_tiled_rpw4_matches_fp64(hip, cins, cout, k, H, W, act, residual, kernel, persist7):
+    """persist7 = 1 (default): the 7x7 convs with a fused-epilogue-friendly output (Cout % 4 == 0) run on the persistent
+    warp-specialised 7x7 kernel (conv7_f16x3p.hip; Cout >= 32); persist7 = 0 and the narrow-output convs: the RPW = 4 tiled kernels."""
     g = torch.Generator().manual_seed(hash((tuple(cins), cout, k, H)) & 0xFFFF)
     xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
     cin = sum(cins)
@@ -219,10 +222,57 @@ def test_tiled_rpw4_matches_fp64(hip, cins, cout, k, H, W, act, residual, kernel
     def launch():
         return back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], act=act, residual=nhwc(hip, r) if residual else None))
 
-    got16, k16 = _run(hip, "f16x3", launch)
+    old = _get("f16x3_persist7")
+    try:
+        _set("f16x3_persist7", persist7)
+        got16, k16 = _run(hip, "f16x3", launch)
+        if persist7 and k == 7 and cout % 4 == 0 and cout >= 32:                      # bit-identical to the tiled kernel
+            _set("f16x3_persist7", 0)
+            tiled, kt = _run(hip, "f16x3", launch)
+            assert kt == kernel and torch.equal(got16, tiled), (k16, kt)
+    finally:
+        _set("f16x3_persist7", old)
     got32, _ = _run(hip, "f32", launch)
-    assert k16 == kernel, k16
+    if persist7 and k == 7 and cout % 4 == 0 and cout >= 32:
+        assert k16 == "conv7_f16x3p_kernel<%d, false>" % min(4, (cout + 15) // 16), k16
+    else:
+        assert k16 == kernel, k16
     e16 = (got16.double() - ref).abs().max().item()
     e32 = (got32.double() - ref).abs().max().item()
     assert e16 <= 8 * e32 + 1e-6, (e16, e32)
     assert e16 <= 2e-5 * max(1.0, ref.abs().max().item()), e16
+
+
+P7_EXTRA = [
+    # cins, cout, H, W: several chunks per tile, two-input concat, partial tiles in both directions, few tiles (forced)
+    ([64], 32, 301, 333), ([32, 32], 64, 290, 350), ([48], 48, 300, 340), ([128], 32, 262, 270), ([16], 64, 50, 40),
+]
+
+
+@pytest.mark.parametrize("cins,cout,H,W", P7_EXTRA)
+def test_persistent_7x7_is_bit_identical_to_tiled(hip, cins, cout, H, W):
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, H)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 7, 7, generator=g) / math.sqrt(cin * 49)
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(1, cout, H, W, generator=g)
+    Wt = _W({"c.weight": w, "c.bias": b})
+
+    def launch():
+        return back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], in_act="lrelu", in_slope=0.2, act="lrelu", slope=0.1, residual=nhwc(hip, r)))
+
+    old, old_min = _get("f16x3_persist7"), _get("f16x3_persist_min_tiles")
+    try:
+        _set("f16x3_persist_min_tiles", 1)
+        _set("f16x3_persist7", 1)
+        a, ka = _run(hip, "f16x3", launch)
+        _set("f16x3_persist7", 0)
+        b_, kb = _run(hip, "f16x3", launch)
+    finally:
+        _set("f16x3_persist7", old)
+        _set("f16x3_persist_min_tiles", old_min)
+    assert ka.startswith("conv7_f16x3p_kernel") and kb.startswith("conv_f16x3_kernel"), (ka, kb)
+    assert torch.equal(a, b_)
+    ref = F.leaky_relu(F.conv2d(F.leaky_relu(torch.cat(xs, 1).double(), 0.2), w.double(), b.double(), padding=3), 0.1) + r.double()
+    assert (a.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
