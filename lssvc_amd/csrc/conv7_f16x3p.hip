@@ -343,23 +343,12 @@ __global__ __launch_bounds__(kP7Threads, 1) void conv7_f16x3p_kernel(const ConvP
                 int oy0, ox0, m0;
                 tile_origin(it, oy0, ox0, m0);
                 if (!(p.debug & 32)) {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        constexpr int HALF = RPW / 2;
-                        f32x4 part[MF][HALF];
-#pragma unroll
-                        for (int f = 0; f < MF; ++f)
-#pragma unroll
-                            for (int r = 0; r < HALF; ++r) part[f][r] = acc[f][half * HALF + r];
-                        long long pix[HALF];
-#pragma unroll
-                        for (int r = 0; r < HALF; ++r) {
-                            const int oy = oy0 + wave * RPW + half * HALF + r, ox = ox0 + li;
-                            pix[r] = (oy < p.Hout && ox < p.Wout) ? (long long)oy * p.Wout + ox : -1;
-                        }
-                        const bool interior = oy0 + wave * RPW + half * HALF + HALF <= p.Hout && ox0 + 16 <= p.Wout && m0 + TM <= p.Cout;
-                        conv_epilogue_fast<MF, HALF>(p, part, pix, m0, lg, p.w16_unscale, interior, (lds_cfloat_ptr)bias_s);
-                    }
+                    const int oy_w = oy0 + wave * RPW;
+                    auto pix = [&](int r, int col) {
+                        return (ox0 + col < p.Wout && oy_w + r < p.Hout) ? (long long)(oy_w + r) * p.Wout + ox0 + col : -1LL;
+                    };
+                    const bool interior = oy0 + wave * RPW + RPW <= p.Hout && ox0 + 16 <= p.Wout && m0 + TM <= p.Cout;
+                    conv_epilogue_fast_f<MF, RPW, true>(p, acc, pix, m0, lg, p.w16_unscale, interior, (lds_cfloat_ptr)bias_s);
                 }
 #pragma unroll
                 for (int a = 0; a < MF; ++a)

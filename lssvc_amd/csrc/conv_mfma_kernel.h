@@ -67,18 +67,33 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // "is there a residual" test out of the per-row code.
 typedef __attribute__((address_space(3))) const float *lds_cfloat_ptr;
 
-template <int MF, int RPW, bool PS, int RES, bool INTERIOR, bool ACT>      // RES: number of residual operands (0, 1, 2)
-__device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
+// BIAS_LDS: the bias vector comes from LDS (persistent kernels) -- a COMPILE-TIME choice: with a run-time one the compiler joins a
+// path holding a global load in front of the first store and waits vmcnt(0) there, i.e. for every store still in flight.
+// PIXF: (r, col) -> conv-space pixel index of column col (0..15) of fragment row r, or -1 if outside the image.
+//
+// LANE TRANSPOSITION. An MFMA 16x16 result has lane (lg, li) = 16 lg + li holding channels 4 lg .. 4 lg + 3 of pixel li: 16
+// CONSECUTIVE lanes touch 16 different pixels, 16 bytes each. The memory pipeline coalesces a wave's accesses over runs of
+// consecutive lanes: measured (tools/probes/store_probe.hip) this native pattern sustains 16.6 B/clk per CU, any pattern
+// whose 4 consecutive lanes cover 64 contiguous bytes 59 B/clk -- and the 96 KB tile of a 64-channel 3x3 conv spent
+// 6.5 k of its 33 k cycles issuing stores. Each result dword is therefore moved with ds_bpermute (the LDS crossbar, no LDS
+// memory) to lane 4 li + lg, so that 4 consecutive lanes hold the 16 channels of one pixel of a fragment; bias and
+// activation are applied before the move (native lane = native channel), residuals are loaded and added and the
+// result stored in the transposed layout. Same arithmetic per element, same results.
+template <int MF, int RPW, bool PS, int RES, bool INTERIOR, bool ACT, bool BIAS_LDS, typename PIXF>      // RES: number of residual operands (0, 1, 2)
+__device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&acc)[MF][RPW], const PIXF &pixf, int m0,
                                                         int lg, float unscale, lds_cfloat_ptr bias_lds) {
     const float s_neg = p.act == LSSVC_ACT_LRELU ? p.slope : (p.act == LSSVC_ACT_RELU ? 0.0f : 1.0f);
     constexpr bool has_res = RES > 0;
     const f32x2 us = {unscale, unscale}, sn = {s_neg, s_neg};      // (out_scale == 1 here: the host keeps other convs off this path)
+    const int lane = threadIdx.x & 63;
+    const int tcol = lane >> 2, tq = lane & 3;                    // transposed layout: pixel column, channel quad of the fragment
+    const int bp_addr = ((lane & 3) * 16 + (lane >> 2)) * 4;      // ds_bpermute source lane (byte address): native lane (lg = tq, li = tcol)
     f32x2 bb[MF][2];
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
         const int mb = m0 + f * 16 + 4 * lg;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias_lds) {
+        if (BIAS_LDS) {
             // the persistent kernels keep the (zero-padded, M_pad long) bias vector in LDS: a dependent GLOBAL load at the
             // head of every tile's epilogue costs a full L2 round trip with the matrix pipe idle
             const f32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>(bias_lds + mb);
@@ -96,21 +111,22 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
         const int cps = p.Cout >> 2;
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            const int mb = m0 + f * 16 + 4 * lg;
-            const int q = mb / cps, c = mb - q * cps;
+            const int mt = m0 + f * 16 + 4 * tq;
+            const int q = mt / cps, c = mt - q * cps;
             ps_off[f] = ((q >> 1) * p.out.W + (q & 1)) * p.out.ld + c;      // < 2 * W * ld: fits int
         }
     }
     float4 rs[2][MF], rs2[2][RES > 1 ? MF : 1];
     auto load_res = [&](int r, float4 (&d)[MF], float4 (&d2)[RES > 1 ? MF : 1]) {
+        const long long px = pixf(r, tcol);
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            const int mb = m0 + f * 16 + 4 * lg;
+            const int mt = m0 + f * 16 + 4 * tq;
             d[f] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (RES > 1) d2[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has_res && (INTERIOR || (pix[r] >= 0 && mb < p.Cout))) {
-                d[f] = *reinterpret_cast<const float4 *>(p.res.p + (size_t)pix[r] * p.res.ld + mb);
-                if (RES > 1) d2[f] = *reinterpret_cast<const float4 *>(p.res2.p + (size_t)pix[r] * p.res2.ld + mb);
+            if (has_res && (INTERIOR || (px >= 0 && mt < p.Cout))) {
+                d[f] = *reinterpret_cast<const float4 *>(p.res.p + (size_t)px * p.res.ld + mt);
+                if (RES > 1) d2[f] = *reinterpret_cast<const float4 *>(p.res2.p + (size_t)px * p.res2.ld + mt);
             }
         }
     };
@@ -118,16 +134,17 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         if (r + 1 < RPW) load_res(r + 1, rs[(r + 1) & 1], rs2[(r + 1) & 1]);      // issued before row r's stores (see conv_epilogue_flat)
-        const size_t opix = (size_t)((INTERIOR || pix[r] >= 0) ? pix[r] : 0);
-        float *orow = p.out.p + opix * p.out.ld + m0 + 4 * lg;
+        const long long px = pixf(r, tcol);
+        const size_t opix = (size_t)((INTERIOR || px >= 0) ? px : 0);
+        float *orow = p.out.p + opix * p.out.ld + m0 + 4 * tq;
         float *srow = nullptr;                                   // pixel-shuffle: the 2x2 output block of this conv pixel
         if (PS) {
             const int oy = (int)(opix / p.Wout), ox = (int)(opix - (size_t)oy * p.Wout);
             srow = p.out.p + ((size_t)(2 * oy) * p.out.W + 2 * ox) * p.out.ld;
         }
+        f32x2 t0[MF], t1[MF];
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
-            const int mb = m0 + f * 16 + 4 * lg;
             f32x2 v0 = f32x2{acc[f][r][0], acc[f][r][1]} * us + bb[f][0];
             f32x2 v1 = f32x2{acc[f][r][2], acc[f][r][3]} * us + bb[f][1];
             if (ACT) {                                                        // no activation: max(v, 1 * v) == v, skipped
@@ -135,6 +152,15 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
                 v0 = f32x2{fmaxf(v0.x, n0.x), fmaxf(v0.y, n0.y)};
                 v1 = f32x2{fmaxf(v1.x, n1.x), fmaxf(v1.y, n1.y)};
             }
+            t0[f] = f32x2{__int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v0.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v0.y)))};
+            t1[f] = f32x2{__int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v1.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v1.y)))};
+        }
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int mt = m0 + f * 16 + 4 * tq;
+            f32x2 v0 = t0[f], v1 = t1[f];
             if (RES > 0) {
                 v0 = v0 + f32x2{rs[r & 1][f].x, rs[r & 1][f].y};
                 v1 = v1 + f32x2{rs[r & 1][f].z, rs[r & 1][f].w};
@@ -145,25 +171,25 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
             }
             float *dst = orow + f * 16;
             if (PS) dst = srow + ps_off[f];
-            if (INTERIOR || (pix[r] >= 0 && mb < p.Cout))
+            if (INTERIOR || (px >= 0 && mt < p.Cout))
                 *reinterpret_cast<float4 *>(dst) = make_float4(v0.x, v0.y, v1.x, v1.y);
         }
     }
 }
 
-template <int MF, int RPW>
-__device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
-                                                   int lg, float unscale = 1.0f, bool interior = false,
-                                                   lds_cfloat_ptr bias_lds = nullptr) {
+template <int MF, int RPW, bool BIAS_LDS = false, typename PIXF>
+__device__ __forceinline__ void conv_epilogue_fast_f(const ConvP &p, f32x4 (&acc)[MF][RPW], const PIXF &pix, int m0,
+                                                     int lg, float unscale = 1.0f, bool interior = false,
+                                                     lds_cfloat_ptr bias_lds = nullptr) {
     // (every condition is wave-uniform: scalar branches)
     const bool act = p.act != LSSVC_ACT_NONE;
 #define LSSVC_EPI_CALL(PS_, RES_)                                                                                              \
     do {                                                                                                                       \
         if (interior) {                                                                                                        \
-            if (act) conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, true>(p, acc, pix, m0, lg, unscale, bias_lds);          \
-            else conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, false>(p, acc, pix, m0, lg, unscale, bias_lds);             \
+            if (act) conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, true, BIAS_LDS>(p, acc, pix, m0, lg, unscale, bias_lds);          \
+            else conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, false, BIAS_LDS>(p, acc, pix, m0, lg, unscale, bias_lds);             \
         } else {                                                                                                               \
-            conv_epilogue_fast_impl<MF, RPW, PS_, RES_, false, true>(p, acc, pix, m0, lg, unscale, bias_lds);                  \
+            conv_epilogue_fast_impl<MF, RPW, PS_, RES_, false, true, BIAS_LDS>(p, acc, pix, m0, lg, unscale, bias_lds);                  \
         }                                                                                                                      \
     } while (0)
     if (p.fast_epi == 2) LSSVC_EPI_CALL(true, 0);                            // pixel-shuffle store (never with a residual)
@@ -172,6 +198,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP &p, f32x4 (&acc)[
     else LSSVC_EPI_CALL(false, 0);
 #undef LSSVC_EPI_CALL
 }
+
 
 // Memory-op ordering matters here: on gfx9/CDNA loads and stores share the vmcnt counter, so a wait for a load that
 // was issued AFTER a store also waits for that store's acknowledgement. The bias is therefore loaded once up front,
@@ -184,13 +211,14 @@ struct EpiSide {
     float4 rs[MF];    // residual
 };
 
-template <int MF, int RPW, bool GDN = true>
-__device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0,
-                                                   int lg, bool interior = false) {
-    // pix[r] = conv-space pixel index oy*Wout + ox of this lane's column of fragment row r, or -1 if outside
-    // interior (wave-uniform): the caller knows that no pix[r] is -1 and m0 + 16 MF <= Cout
+template <int MF, int RPW, bool GDN = true, typename PIXF>
+__device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], const PIXF &pixf,
+                                                   int m0, int lg, bool interior = false) {
+    // pix[r] = conv-space pixel index oy*Wout + ox of this lane's column of fragment row r, or -1 if outside; pixf(r, col) the
+    // same for any column of the tile (conv_epilogue_fast_impl); interior (wave-uniform): the caller knows that no pixel of
+    // the wave's rows is outside and m0 + 16 MF <= Cout
     if (p.fast_epi) {
-        conv_epilogue_fast<MF, RPW>(p, acc, pix, m0, lg, 1.0f, interior);
+        conv_epilogue_fast_f<MF, RPW, false>(p, acc, pixf, m0, lg, 1.0f, interior);
         return;
     }
     const int cps = p.Cout >> 2;  // channels after pixel shuffle
@@ -303,7 +331,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP &p, f32x4 (&acc)[MF][R
         pix[r] = (oy < p.Hout && ox < p.Wout) ? (long long)oy * p.Wout + ox : -1;
     }
     const bool interior = oy0 + wave * RPW + RPW <= p.Hout && ox0 + 16 <= p.Wout && m0 + 16 * MF <= p.Cout;
-    conv_epilogue_flat<MF, RPW, GDN>(p, acc, pix, m0, lg, interior);
+    const int oy_w = oy0 + wave * RPW;
+    auto pixf = [&](int r, int col) {
+        return (oy_w + r < p.Hout && ox0 + col < p.Wout) ? (long long)(oy_w + r) * p.Wout + ox0 + col : -1LL;
+    };
+    conv_epilogue_flat<MF, RPW, GDN>(p, acc, pix, pixf, m0, lg, interior);
 }
 
 // One K "phase" = one 8-channel chunk x RPP kernel rows. Small kernels (<=3x3) take all rows in one

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, RPW == 1 ? 4 : 2) void conv_pw_f16x3_kernel(co
             }
         }
         conv_unscale<MF, RPW>(p, acc);
-        conv_epilogue_flat<MF, RPW, GDN>(p, acc, pix, m0, lg);
+        conv_epilogue_flat<MF, RPW, GDN>(p, acc, pix, [&](int r, int col) { const long long q = (grp * RPW + r) * 16 + col; return q < npix ? q : -1LL; }, m0, lg);
     }
 }
 
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_f16x3_kernel(const ConvP p) {
             }
         }
         conv_unscale<MF, RPW>(p, acc);
-        conv_epilogue_flat<MF, RPW, false>(p, acc, pix, m0, lg);
+        conv_epilogue_flat<MF, RPW, false>(p, acc, pix, [&](int r, int col) { const long long q = (grp * RPW + r) * 16 + col; return q < npix ? q : -1LL; }, m0, lg);
     }
 }
 
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwks_f16x3_kernel(const ConvP p) 
         }
     }
     conv_unscale<MF, RPW>(p, acc);
-    conv_epilogue_flat<MF, RPW, false>(p, acc, pix, m0, lg);
+    conv_epilogue_flat<MF, RPW, false>(p, acc, pix, [&](int r, int col) { const long long q = (grp * RPW + r) * 16 + col; return q < npix ? q : -1LL; }, m0, lg);
 }
 
 template <int MF>
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_allm_f16x3_kernel(const ConvP 
                 }
             }
             conv_unscale<MF, RPW>(p, acc);
-            conv_epilogue_flat<MF, RPW, false>(p, acc, pix, mt * TM, lg);
+            conv_epilogue_flat<MF, RPW, false>(p, acc, pix, [&](int r, int col) { const long long q = (grp * RPW + r) * 16 + col; return q < npix ? q : -1LL; }, mt * TM, lg);
         }
     }
 }

@@ -46,15 +46,16 @@ def main():
         allrec = stamps.view(-1, 8).cpu().double()
         s = allrec[:1024]
         s = s[s[:, 5] > 0]
-        pr = allrec[1024:]
+        pr = allrec[1024:2048]
         pr = pr[pr[:, 5] > 0]
         comp, bar, epi, cyc, real, phases, tiles = (s[:, i].median().item() for i in range(7))
+        zero = s[:, 7].median().item()
         clock = cyc / real * 100.0                 # s_memrealtime ticks at 100 MHz
         print("%s (%s): per consumer wave, median over %d waves: %d phases / %d tiles; total %.0f cycles at %.0f MHz" %
               (name, _lib.lib.lssvc_conv2d_last_kernel().decode(), s.shape[0], phases, tiles, cyc, clock))
         print("   compute %5.1f %% (%.0f cyc/phase; 336 MFMAs = 5376 issue cycles)   barrier wait %5.1f %% (%.0f cyc/phase)   "
-              "epilogue %5.1f %% (%.0f cyc/tile)" % (100 * comp / cyc, comp / phases, 100 * bar / cyc, bar / phases,
-                                                    100 * epi / cyc, epi / max(tiles, 1)))
+              "epilogue %5.1f %% (%.0f cyc/tile, of which zeroing the accumulators %.0f)" % (100 * comp / cyc, comp / phases, 100 * bar / cyc, bar / phases,
+                                                    100 * epi / cyc, epi / max(tiles, 1), zero / max(tiles, 1)))
         if pr.shape[0]:
             dma, ld, wait, cvt, pbar, pph, geo = (pr[:, i].median().item() for i in range(7))
             print("   producer wave, cycles per phase: weight-DMA issue %.0f, patch-load issue %.0f, load wait %.0f, convert + LDS stores %.0f, "
