@@ -70,6 +70,14 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     _Float16 *const patch0 = reinterpret_cast<_Float16 *>(smem);                    // [buf][plane][PH*PW][16]
     _Float16 *const wts0 = patch0 + 4 * G::PATCH_HALFS;                             // [buf][plane][tap][m][16]
     float *const bias_s = reinterpret_cast<float *>(wts0 + 4 * G::W_HALFS);         // [m_tiles * TM], zero past M_pad
+    // Hand-off slots: fills finished by each producer wave / phases finished by each consumer wave.
+    // One s_barrier per phase makes every consumer wait for the SLOWEST consumer of that phase (stamps: ~600 of 6600
+    // cycles); with the counters a consumer only waits for the data of its next phase, which the producers finish a
+    // couple of thousand cycles ahead, and only the producers -- which have the slack -- wait for the last consumer.
+    // One slot per wave (a shared counter could be satisfied by a fast wave signalling twice while a slow one has not signalled
+    // at all): slot = number of fills / phases that wave has completed.
+    int *const sync_s = reinterpret_cast<int *>(bias_s + p.m_tiles * TM);             // [0..3] producer waves: fills done; [4..7] consumer waves: phases done
+    _Float16 *const trash_s = reinterpret_cast<_Float16 *>(sync_s + 8);               // one 8-byte slot per producer lane and plane: staged items past the patch land here
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -88,6 +96,19 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     if (n_it == 0) return;
     const int phases_per_tile = p.n_chunks16;
     for (int i = tid; i < p.m_tiles * TM; i += kP3Threads) bias_s[i] = (p.bias && i < p.M_pad) ? p.bias[i] : 0.f;   // visible after barrier (A)
+    if (tid < 8) sync_s[tid] = 0;
+    // spin until all four slots of a group are >= target (monotonic: every target is reached, and the grid drains, because a
+    // fill never waits for a phase that needs it and a phase never waits for a fill that needs it)
+    auto wait_for = [&](int *slots, int target) {
+        while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(slots + (lane & 3), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) != 0)
+            __builtin_amdgcn_s_sleep(1);
+    };
+    // (the caller has waited, with explicit s_waitcnt, for exactly the LDS / DMA traffic the slot stands for; a RELEASE store
+    // would make the compiler wait for vmcnt(0), i.e. also for the producers' prefetched loads of the phase after next)
+    auto signal = [&](int *slot, int value) {
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
     auto tile_origin = [&](int it, int &oy0, int &ox0, int &m0) {
         const int tile = t_begin + kb + it * nb_x;
@@ -122,10 +143,11 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         };
         // Per-TILE staging geometry, computed when the tile changes instead of every phase (the producers' vector-issue
         // slots are what they compete for with the consumers' MFMAs): input pixel of every staged float4 item (-1 = zero
-        // padding / past the patch) and the lane offsets of the weight DMA inside one chunk's [hi | lo] image.
+        // padding / past the patch) and the lane offsets of the weight DMA inside one chunk's [hi | lo] image. The patch of
+        // phase k+2 is loaded while the weights of phase k+1 are staged, so the two halves are cached per tile separately.
         int ppix[NP], woff[G::NDMA];
-        int geom_it = -1;
-        auto tile_geometry = [&](int it) {
+        int pgeom_it = -1, wgeom_it = -1;
+        auto patch_geometry = [&](int it) {
             int oy0, ox0, m0;
             tile_origin(it, oy0, ox0, m0);
 #pragma unroll
@@ -137,6 +159,11 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 const bool ok = idx < G::PATCH_ITEMS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
                 ppix[i] = ok ? gy * Win + gx : -1;
             }
+            pgeom_it = it;
+        };
+        auto weight_geometry = [&](int it) {
+            int oy0, ox0, m0;
+            tile_origin(it, oy0, ox0, m0);
 #pragma unroll
             for (int t = 0; t < G::NDMA; ++t) {
                 int j = pw + G::NPROD * t;                       // wave-uniform DMA instruction index
@@ -150,20 +177,15 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 if (m >= p.M_pad) m = p.M_pad - 1;               // rows past M_pad: any finite weights, masked by the epilogue
                 woff[t] = plane * (int)p.w16_plane + (tap * p.M_pad + m) * CK16 + (rr & 1) * 8;
             }
-            geom_it = it;
+            wgeom_it = it;
         };
-        // everything one phase needs, into LDS buffer `buf`: weights by DMA, patch through registers
         long long s_dma = 0, s_ld = 0, s_wait = 0, s_cvt = 0, s_bar = 0, s_geo = 0;      // STAMP build only
-        auto fill = [&](const P3Phase &ph, int buf) {
+        // weights of phase `ph` -> LDS buffer `buf`, by DMA
+        auto stage_weights = [&](const P3Phase &ph, int buf) {
             long long ts = 0;
             if (STAMP) ts = __builtin_amdgcn_s_memtime();
-            if (ph.it != geom_it) tile_geometry(ph.it);
-            if (STAMP) {
-                const long long t = __builtin_amdgcn_s_memtime();
-                s_geo += t - ts;
-                ts = t;
-            }
-            if (!(p.debug & 1)) {
+            if (ph.it != wgeom_it) weight_geometry(ph.it);
+            {
                 unsigned char *dst = reinterpret_cast<unsigned char *>(wts0 + buf * 2 * G::W_HALFS);
                 const _Float16 *src0 = w16 + (size_t)ph.k.kc * NTAP * p.M_pad * CK16;
 #pragma unroll
@@ -174,17 +196,24 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                                                      (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
                 }
             }
+            if (STAMP) s_dma += __builtin_amdgcn_s_memtime() - ts;
+        };
+        // patch of phase `ph` -> registers (fp32, as loaded)
+        float4 preg[NP];
+        unsigned pmask = 0;
+        auto load_patch = [&](const P3Phase &ph) {
+            long long ts = 0;
+            if (STAMP) ts = __builtin_amdgcn_s_memtime();
+            if (ph.it != pgeom_it) patch_geometry(ph.it);
             if (STAMP) {
                 const long long t = __builtin_amdgcn_s_memtime();
-                s_dma += t - ts;
+                s_geo += t - ts;
                 ts = t;
             }
-            if (p.debug & 2) return;
             const V X = p.in[ph.k.seg];
             const bool cvalid = quad4 < X.C - ph.k.c0;
             const int cc = cvalid ? ph.k.c0 + quad4 : 0;
-            float4 preg[NP];
-            unsigned pmask = 0;
+            pmask = 0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const bool ok = ppix[i] >= 0 && cvalid;
@@ -192,15 +221,12 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 preg[i] = *reinterpret_cast<const float4 *>(X.p + off);
                 pmask |= ok ? (1u << i) : 0u;
             }
-            if (STAMP) {
-                long long t = __builtin_amdgcn_s_memtime();
-                s_ld += t - ts;
-                ts = t;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (diagnostic: separates the load latency from the conversion)
-                t = __builtin_amdgcn_s_memtime();
-                s_wait += t - ts;
-                ts = t;
-            }
+            if (STAMP) s_ld += __builtin_amdgcn_s_memtime() - ts;
+        };
+        // registers -> fp16 hi / lo planes of LDS buffer `buf`
+        auto store_patch = [&](int buf) {
+            long long ts = 0;
+            if (STAMP) ts = __builtin_amdgcn_s_memtime();
             _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;
             _Float16 *pl_ = ph_ + G::PATCH_HALFS;
 #pragma unroll
@@ -217,11 +243,13 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                     h[j] = (_Float16)x;
                     l[j] = (_Float16)(x - (float)h[j]);
                 }
+                // items past the patch (last round only) go to the lane's trash slot: a guarded store makes the compiler sink
+                // that round's global load INTO the guarded block, behind every other store, and two of the four producer
+                // waves then sit out a full memory latency at the end of every fill
+                const bool in_patch = i + 1 < NP || idx < G::PATCH_ITEMS;
                 const int o = (idx >> 2) * CK16 + quad4;
-                if (i + 1 < NP || idx < G::PATCH_ITEMS) {
-                    *reinterpret_cast<f16x4 *>(ph_ + o) = h;
-                    *reinterpret_cast<f16x4 *>(pl_ + o) = l;
-                }
+                *reinterpret_cast<f16x4 *>(in_patch ? ph_ + o : trash_s + lt * 4) = h;
+                *reinterpret_cast<f16x4 *>(in_patch ? pl_ + o : trash_s + (kP3ProducerThreads + lt) * 4) = l;
             }
             if (STAMP) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -229,23 +257,28 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             }
         };
 
-        P3Phase ph{0, KState{0, 0, 0, 0}};
-        fill(ph, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of this wave has landed (made explicit, see below)
-        __syncthreads();                                   // (A) phase 0 is in buffer 0
+        // Schedule: fill(k+1) = weights by DMA + patch through registers, while the consumers run phase k. (Requesting the patch
+        // of phase k+2 before the buffer of phase k+1 is released -- only the LDS writes need the buffer -- was tried: the
+        // producers then had 2 k cycles of slack per phase, the consumers waited as long as before and the extra loads in
+        // flight slowed the epilogue's stores; 64->64 @1080p 428 -> 458 us.)
         const int total = n_it * phases_per_tile;
-        for (int k = 0; k < total; ++k) {
-            if (k + 1 < total) {
-                ph = next_phase(ph);
-                fill(ph, (k + 1) & 1);                     // the consumers read buffer k & 1 meanwhile
-            }
-            // LDS-DMA data is ordered for the consumers' ds_reads only by the issuing wave's vmcnt wait + a barrier;
-            // the compiler emits that wait today, this line makes it a property of the source
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P3Phase ph{0, KState{0, 0, 0, 0}};
+        stage_weights(ph, 0);
+        load_patch(ph);
+        store_patch(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of this wave has landed
+        __syncthreads();                                   // (A) phase 0 is in buffer 0
+        for (int k = 0; k + 1 < total; ++k) {              // fill(k+1) while the consumers run phase k
             long long tb = 0;
             if (STAMP) tb = __builtin_amdgcn_s_memtime();
-            __syncthreads();                               // (B_k) buffer (k+1)&1 complete, buffer k&1 released
+            if (k >= 1) wait_for(sync_s + 4, k);           // buffer (k+1)&1 was read in phase k-1: every consumer has left it
             if (STAMP) s_bar += __builtin_amdgcn_s_memtime() - tb;
+            ph = next_phase(ph);
+            stage_weights(ph, (k + 1) & 1);
+            load_patch(ph);
+            store_patch((k + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMA has landed, its LDS stores are done
+            signal(sync_s + pw, k + 1);
         }
         if (STAMP && lane == 0 && p.gdn_x.p) {
             long long *o = reinterpret_cast<long long *>(p.gdn_x.p) + ((size_t)gridDim.x * kP3Consumers + (size_t)blockIdx.x * 4 + pw) * 8;
@@ -275,6 +308,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         t_cyc0 = t_mark = __builtin_amdgcn_s_memtime();
     }
     for (int k = 0; k < total; ++k) {
+        int fill_seen = 0;                                 // producers' slots as read during the last unit of this phase
         const int buf = k & 1;
         const _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;            // hi plane; the lo plane follows it
         const _Float16 *wh_ = wts0 + buf * 2 * G::W_HALFS;
@@ -335,10 +369,13 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             // B fragments are prefetched one unit ahead, the A fragments of K step u+1 during row group NG-2 of step u: a
             // unit that ends in a burst of reads would make the NEXT unit's first MFMA wait for them
             constexpr bool pre_a = (NG >= 2 ? g == NG - 2 : true) && u + 1 < NSTEP;
-            constexpr int NR = (pre_a ? 2 * MF : 0) + (more ? (nodd ? GR : 2 * GR) : 0);      // ds_reads issued in this unit
+            constexpr int NR = (pre_a ? 2 * MF : 0) + (more ? (nodd ? GR : 2 * GR) : 1);      // ds_reads issued in this unit
             constexpr int NM = (odd ? 2 : 3) * MF * GR;                                       // MFMAs of this unit
             if (pre_a) load_a(u + 1, fa1[(u + 1) & 1], fa2[(u + 1) & 1]);
             if (more) load_b(nu, ng, fb1[(t + 1) & 1], fb2[(t + 1) & 1]);
+            // last unit: nothing left to prefetch in this buffer -- look at the producers' slots for the NEXT phase instead, so
+            // that the round trip of that read (several hundred cycles with the LDS queue full) hides behind this unit's MFMAs
+            if (!more) fill_seen = __hip_atomic_load(sync_s + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const f16x8(&a1)[MF] = fa1[u & 1];
             const f16x8(&a2)[MF] = fa2[u & 1];
             const f16x8(&b1)[GR] = fb1[t & 1];
@@ -392,11 +429,16 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             t_comp += t - t_mark;
             t_mark = t;
         }
-        __syncthreads();                                   // (B_k)
-        if (STAMP) {
-            const long long t = __builtin_amdgcn_s_memtime();
-            t_bar += t - t_mark;
-            t_mark = t;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (every fragment read of this phase has returned: the MFMAs consumed them)
+        signal(sync_s + 4 + wave, k + 1);                  // this wave is done with buffer k & 1
+        if (k + 1 < total) {                               // every producer wave has finished fill(k+1)? (normally long ago)
+            if (__builtin_amdgcn_ballot_w64(fill_seen < k + 1) != 0) wait_for(sync_s + 0, k + 1);
+            asm volatile("" ::: "memory");                 // the next phase's fragment reads stay behind this check
+            if (STAMP) {
+                const long long t = __builtin_amdgcn_s_memtime();
+                t_bar += t - t_mark;
+                t_mark = t;
+            }
         }
         if (++kt == phases_per_tile) {
             int oy0, ox0, m0;
@@ -452,7 +494,7 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
     q.tiles_x = (p.Wout + 15) / 16;
     q.tiles_y = (p.Hout + G::TH - 1) / G::TH;
     q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
-    const size_t lds = (size_t)G::LDS_BYTES + (size_t)q.m_tiles * G::TM * sizeof(float);
+    const size_t lds = (size_t)G::LDS_BYTES + (size_t)q.m_tiles * G::TM * sizeof(float) + 32 + 2 * kP3ProducerThreads * 8;      // + bias vector + hand-off slots + trash slots
     if (lds > 160 * 1024) return fail("conv2d(f16x3p): %zu bytes of LDS", lds);
     static LdsGrant grant;
     if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, INACT>), lds)) return 1;

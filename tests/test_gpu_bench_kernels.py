@@ -111,10 +111,7 @@ def test_persistent_3x3_matches_fp64(hip, cins, cout, H, W, in_act, act, residua
     got16, k16 = _run(hip, "f16x3", launch)
     got32, k32 = _run(hip, "f32", launch)
     inact = "true" if in_act else "false"
-    if mf == 3 and 32 <= sum(cins) <= 48:        # default policy: 48-channel tiles with <= 3 phases take the deferred-epilogue kernel
-        want = "conv3_f16x3d_kernel<3, %s, %s>" % (inact, "true" if residual else "false")
-    else:
-        want = "conv3_f16x3p_kernel<%d, %s>" % (mf, inact)
+    want = "conv3_f16x3p_kernel<%d, %s>" % (mf, inact)
     assert k16 == want, k16                                           # really a persistent kernel
     assert k32.startswith("conv_mfma_kernel"), k32
     assert got16.shape == ref.shape
@@ -276,3 +273,39 @@ def test_persistent_7x7_is_bit_identical_to_tiled(hip, cins, cout, H, W):
     assert torch.equal(a, b_)
     ref = F.leaky_relu(F.conv2d(F.leaky_relu(torch.cat(xs, 1).double(), 0.2), w.double(), b.double(), padding=3), 0.1) + r.double()
     assert (a.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 576, 960), (48, 48, 576, 960), (64, 64, 290, 350)])
+def test_persistent_3x3_hand_off_is_race_free(hip, cin, cout, H, W):
+    """The persistent kernel's producer and consumer waves hand LDS buffers over through per-wave slots, not barriers: the
+    consumers run ahead of each other and of the producers by up to a phase. Forty launches with an input activation (the
+    longest staging path; a shared hand-off counter once let a consumer read the last patch rows before they were written,
+    nine launches out of ten) must all equal the tiled kernel bit for bit."""
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(1, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    Wt = _W({"c.weight": w, "c.bias": b})
+    xin = nhwc(hip, x)
+
+    def launch():
+        return hip.conv(Wt, "c", [xin], in_act="lrelu", in_slope=0.1, act="lrelu", slope=0.01)
+
+    from lssvc_amd._lib import lib
+    old_on, old_min = _get("f16x3_persist"), _get("f16x3_persist_min_tiles")
+    try:
+        hip.set_conv_precision("f16x3")
+        _set("f16x3_persist", 0)
+        ref = launch().buf.clone()
+        _set("f16x3_persist", 1)
+        _set("f16x3_persist_min_tiles", 1)
+        bad = 0
+        for _ in range(40):
+            out = launch()
+            assert lib.lssvc_conv2d_last_kernel().decode().startswith("conv3_f16x3p_kernel<%d, true>" % min(4, cout // 16))
+            bad += 0 if torch.equal(out.buf, ref) else 1
+    finally:
+        hip.set_conv_precision("f32")
+        _set("f16x3_persist", old_on)
+        _set("f16x3_persist_min_tiles", old_min)
+    assert bad == 0, "%d of 40 launches differ" % bad

@@ -82,7 +82,7 @@ def main():
             line += "  %s %7.1f us %6.1f TF" % (mname, t[len(t) // 2] * 1e3, flops / t[len(t) // 2] * 1e-9)
         print(line + ("  bit-identical" if same else "  *** MISMATCH ***"), flush=True)
     setopt("f16x3_persist", 1)
-    setopt("f16x3_deferred", 1)
+    setopt("f16x3_deferred", 0)
 
 
 if __name__ == "__main__":
