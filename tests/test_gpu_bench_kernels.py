@@ -309,3 +309,34 @@ def test_persistent_3x3_hand_off_is_race_free(hip, cin, cout, H, W):
         _set("f16x3_persist", old_on)
         _set("f16x3_persist_min_tiles", old_min)
     assert bad == 0, "%d of 40 launches differ" % bad
+
+
+def test_persistent_7x7_hand_off_is_race_free(hip):
+    """Same hand-off scheme in the 7x7 kernel (patch written in seven slices, one per phase): repeated launches = tiled kernel."""
+    from lssvc_amd._lib import lib
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 32, 576, 960, generator=g)
+    w = torch.randn(64, 32, 7, 7, generator=g) / math.sqrt(32 * 49)
+    b = torch.randn(64, generator=g)
+    Wt = _W({"c.weight": w, "c.bias": b})
+    xin = nhwc(hip, x)
+
+    def launch():
+        return hip.conv(Wt, "c", [xin], in_act="lrelu", in_slope=0.1, act="relu")
+
+    old = _get("f16x3_persist7")
+    try:
+        hip.set_conv_precision("f16x3")
+        _set("f16x3_persist7", 0)
+        ref = launch().buf.clone()
+        assert lib.lssvc_conv2d_last_kernel().decode().startswith("conv_f16x3_kernel")
+        _set("f16x3_persist7", 1)
+        bad = 0
+        for _ in range(30):
+            out = launch()
+            assert lib.lssvc_conv2d_last_kernel().decode() == "conv7_f16x3p_kernel<4, true>"
+            bad += 0 if torch.equal(out.buf, ref) else 1
+    finally:
+        hip.set_conv_precision("f32")
+        _set("f16x3_persist7", old)
+    assert bad == 0, "%d of 30 launches differ" % bad
