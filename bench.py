@@ -230,6 +230,37 @@ def _oracle_frames(H, W, threads):
     return t_i, t_p
 
 
+def config0_latency(device, graph=True, reps=30):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): IntraSS, ONE 256x256 frame, x2 (BL 128x128), estimate
+    mode. Launch-bound on a GPU, so what matters is the per-frame latency of the hipGraph frame plan: median wall time of
+    encode_decode() + the D2H of its bit counts over `reps` frames, and the host time to issue one frame."""
+    from lssvc_amd import IntraSS
+    from lssvc_amd.prepost import FramePrep
+    from lssvc_amd.synth import synth_clip, synth_state_dict
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, GAIN)).to(device).eval()
+    inet.set_graph_mode(graph)
+    prep = FramePrep(device)
+    x_bl, x_el, pad = prep.make_layers_rgb8(synth_clip(1, 256, 256, seed=1)[0].to(device), 2.0)
+    inet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))
+    lat, issue = [], []
+    with torch.no_grad():
+        for i in range(reps + 5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = inet.encode_decode(x_bl, x_el, None, None)
+            float(r["bit_bl"]), float(r["bit_el"])
+            torch.cuda.synchronize()
+            if i >= 5:
+                lat.append(time.perf_counter() - t0)
+                issue.append(getattr(inet, "last_issue_s", 0.0) or 0.0)
+    lat.sort()
+    issue.sort()
+    med = lat[len(lat) // 2]
+    return {"workload": "configs[0]: IntraSS, one 256x256 frame, x2 (BL 128x128), estimate mode", "latency_ms": round(1e3 * med, 3),
+            "frames_per_s": round(1.0 / med, 1), "host_issue_ms": round(1e3 * issue[len(issue) // 2], 3),
+            "launch": "hipGraph frame plan" if graph else "eager", "reps": reps}
+
+
 def cpu_baseline(full_size=False):
     """The CPU oracle (a port of the reference's PyTorch CPU path, pinned bit-exact to it on the golden fixtures) timed on
     this box's host cores on a BOUNDED sample: (i) all cores the process may use, 1 I + 1 P frame
@@ -385,6 +416,11 @@ def main():
             out["roofline_by_kernel"] = table[:6]
         else:
             out["roofline"] = None
+        if world == 1:
+            try:
+                out["config0_latency"] = config0_latency(device, graph=not args.no_graph)
+            except Exception as e:                          # a side measurement must not take the headline line down
+                out["config0_latency"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample ...")
             out["cpu_baseline"] = cpu_baseline(full_size=args.cpu_baseline_full)
