@@ -30,6 +30,7 @@ struct FfnP {
     float pre_u, u1, u2, slope;
     int hidden, n_pre, n1, n2;           // halfs per plane
     int sa;                              // K-steps (of 32 channels) of the leading conv
+    int tstore;                          // store through the coalescing lane layout (conv_mfma_kernel.h, LANE TRANSPOSITION); 0: native MFMA layout
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8 &h, f16x8 &l) {
@@ -260,26 +261,37 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
             mfma3<CF, RPW>(oacc, ah, al, hh, hl);
         }
 
-        // ---- out = o1 + lrelu(W2 h + b2)
+        // ---- out = o1 + lrelu(W2 h + b2). p.tstore (option ffn_tstore, default off): store through the coalescing lane layout of
+        // the conv epilogue -- lane 4 li + lg takes over (pixel li, channel quad lg) from lane 16 lg + li, 59 instead of 16.6
+        // B/clk per CU of store throughput. Measured 0-3.5 % SLOWER here (tools/ffn_ab.py): this kernel's
+        // eight free-running waves already hide the store issue behind each other's MFMAs, and the moves are extra work.
+        const int tcol = lane >> 2, tq = lane & 3;
+        const int bp_addr = ((lane & 3) * 16 + (lane >> 2)) * 4;
 #pragma unroll
         for (int f = 0; f < CF; ++f) {
-            if (f * 16 + 4 * lg >= C) continue;
+            const bool ch_ok = f * 16 + 4 * lg < C;
             const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                if (pix[r] < 0) continue;
-                float4 o;
+                const bool ok = ch_ok && pix[r] >= 0;
                 float v[4];
                 float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.skip.p) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)pix[r] * p.skip.ld + f * 16 + 4 * lg);
+                if (p.skip.p && ok) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)pix[r] * p.skip.ld + f * 16 + 4 * lg);
                 const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float a = oacc[f][r][j] * p.u2 + b[j];
                     v[j] = (o1[f][r][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
                 }
-                o = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4 *>(p.out.p + (size_t)pix[r] * p.out.ld + f * 16 + 4 * lg) = o;
+                if (p.tstore) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[j])));
+                    const long long qt = (grp * RPW + r) * 16 + tcol;
+                    if (qt < npix && f * 16 + 4 * tq < C)
+                        *reinterpret_cast<float4 *>(p.out.p + (size_t)qt * p.out.ld + f * 16 + 4 * tq) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (ok) {
+                    *reinterpret_cast<float4 *>(p.out.p + (size_t)pix[r] * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
         }
     }
@@ -466,20 +478,30 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
             __syncthreads();                                 // slice g consumed by everyone; slice g+1 has landed
             ++g;
         }
+        const int tcol = lane >> 2, tq = lane & 3;               // the coalescing store layout of the resident kernel
+        const int bp_addr = ((lane & 3) * 16 + (lane >> 2)) * 4;
 #pragma unroll
         for (int f = 0; f < CF; ++f) {
-            if (f * 16 + 4 * lg >= C || !live) continue;
+            const bool ok = f * 16 + 4 * lg < C && live;
             const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
             float v[4];
             float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.skip.p) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)q * p.skip.ld + f * 16 + 4 * lg);
+            if (p.skip.p && ok) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)q * p.skip.ld + f * 16 + 4 * lg);
             const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = oacc[f][0][j] * p.u2 + b[j];
                 v[j] = (o1[f][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
             }
-            *reinterpret_cast<float4 *>(p.out.p + (size_t)q * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.tstore) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[j])));
+                const long long qt = pass * 128 + wave * 16 + tcol;
+                if (qt < npix && f * 16 + 4 * tq < C)
+                    *reinterpret_cast<float4 *>(p.out.p + (size_t)qt * p.out.ld + f * 16 + 4 * tq) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (ok) {
+                *reinterpret_cast<float4 *>(p.out.p + (size_t)q * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
     }
 }
@@ -564,6 +586,7 @@ extern "C" int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream) {
         p.ident = mk_null();
         p.sa = 0;
     }
+    p.tstore = option_get(OPT_FFN_TSTORE);
     if (d->skip.ptr) {
         LSSVC_CHECK(view_ok(&d->skip) && vec4_ok(&d->skip) && same_shape(&d->skip, &d->out), "ffn_f16x3: bad skip view");
         p.skip = mk(&d->skip);
