@@ -43,17 +43,20 @@ static inline Items items_of(const lssvc_view *v) {
     it.total = (long long)v->H * v->W * it.cg;
     return it;
 }
+// The kernels below decode (pixel, channel group) from a 32-bit thread index: four 64-bit div/mod per thread were ~300
+// instructions, more than the rest of most of these kernels. Every launcher checks its item count with LSSVC_ITEMS_OK.
 static inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
+#define LSSVC_ITEMS_OK(total, what) LSSVC_CHECK((total) > 0 && (total) < (1LL << 31), what ": %lld items do not fit 32-bit indexing", (long long)(total))
 
 // ------------------------------------------------------------------------------------------------
 // depthwise 3x3, stride 1, zero pad 1; weight [9][C]
 __global__ void dwconv3x3_kernel(V in, const float *__restrict__ w, const float *__restrict__ bias, V out, int cg,
                                  long long total) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % cg);
-    const long long pix = idx / cg;
-    const int x = (int)(pix % in.W), y = (int)(pix / in.W);
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)cg;
+    const int g = (int)(idx - pix * (unsigned)cg);
+    const int y = (int)(pix / (unsigned)in.W), x = (int)(pix - (unsigned)y * (unsigned)in.W);
     const int c = g * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -95,11 +98,11 @@ __device__ __forceinline__ void src_index(float scale, int dst, int size, int &i
 
 __global__ void resize_bilinear_kernel(V in, V out, float sy, float sx, float post, int cg, long long total, int vin,
                                        int vout) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % cg);
-    const long long pix = idx / cg;
-    const int x = (int)(pix % out.W), y = (int)(pix / out.W);
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)cg;
+    const int g = (int)(idx - pix * (unsigned)cg);
+    const int y = (int)(pix / (unsigned)out.W), x = (int)(pix - (unsigned)y * (unsigned)out.W);
     const int c = g * 4;
     int y0, y1, x0, x1;
     float hy0, hy1, wx0, wx1;
@@ -155,11 +158,11 @@ __device__ __forceinline__ Bilin warp_coords(int x, int y, float fx, float fy, i
 }
 
 __global__ void flow_warp_kernel(V in, V flow, V out, int cg, long long total, int vin, int vout) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % cg);
-    const long long pix = idx / cg;
-    const int x = (int)(pix % out.W), y = (int)(pix / out.W);
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)cg;
+    const int g = (int)(idx - pix * (unsigned)cg);
+    const int y = (int)(pix / (unsigned)out.W), x = (int)(pix - (unsigned)y * (unsigned)out.W);
     const int c = g * 4;
     const float *f = flow.p + (size_t)pix * flow.ld;
     const Bilin b = warp_coords(x, y, f[0], f[1], in.W, in.H);
@@ -177,11 +180,11 @@ __global__ void flow_warp_kernel(V in, V flow, V out, int cg, long long total, i
 
 // ------------------------------------------------------------------------------------------------
 __global__ void pool2x2_kernel(V in, V out, int is_max, int cg, long long total, int vin, int vout) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % cg);
-    const long long pix = idx / cg;
-    const int x = (int)(pix % out.W), y = (int)(pix / out.W);
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)cg;
+    const int g = (int)(idx - pix * (unsigned)cg);
+    const int y = (int)(pix / (unsigned)out.W), x = (int)(pix - (unsigned)y * (unsigned)out.W);
     const int c = g * 4;
     const size_t p00 = (size_t)(2 * y) * in.W + 2 * x;
     const float4 a = ld4(in, p00, c, vin), b = ld4(in, p00 + 1, c, vin);
@@ -203,10 +206,10 @@ __global__ void pool2x2_kernel(V in, V out, int is_max, int cg, long long total,
 
 // ------------------------------------------------------------------------------------------------
 __global__ void softmax2_blend_kernel(V a, V b, V logits, V out, int cg, long long total, int vec) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % cg);
-    const long long pix = idx / cg;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)cg;
+    const int g = (int)(idx - pix * (unsigned)cg);
     const int c = g * 4;
     const float *l = logits.p + (size_t)pix * logits.ld;
     const float m = fmaxf(l[0], l[1]);
@@ -224,10 +227,10 @@ __global__ void softmax2_blend_kernel(V a, V b, V logits, V out, int cg, long lo
 
 // mode 0: out = a + b ; 1: out = a ; 2: out = lrelu(a)
 __global__ void binary_kernel(V a, V b, V out, int mode, float slope, int cg, long long total, int vec) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % cg);
-    const long long pix = idx / cg;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)cg;
+    const int g = (int)(idx - pix * (unsigned)cg);
     const int c = g * 4;
     float4 r = ld4(a, (size_t)pix, c, vec);
     if (mode == 0) {
@@ -249,22 +252,35 @@ __global__ void binary_kernel(V a, V b, V out, int mode, float slope, int cg, lo
 //   grouped 1x1 conv, group G: inputs 6G..6G+5 -> outputs 3G..3G+2.
 __global__ void offset_diversity_kernel(V x, V om, V flow, const float *__restrict__ fw, const float *__restrict__ fb,
                                         V out, long long total) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int G = (int)(idx & 15);
-    const long long pix = idx >> 4;
-    const int px = (int)(pix % x.W), py = (int)(pix / x.W);
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
+    if (idx >= (unsigned)total) return;
+    const int G = (int)(idx & 15u);
+    const unsigned pix = idx >> 4;
+    const int py = (int)(pix / (unsigned)x.W), px = (int)(pix - (unsigned)py * (unsigned)x.W);
     const float *o = om.p + (size_t)pix * om.ld;
     const float *f = flow.p + (size_t)pix * flow.ld;
     const float f0 = f[0], f1 = f[1];
+    // this thread's two offset pairs o[4G..4G+3] and two mask logits o[64+2G..+1]: one 16-byte and one 8-byte load when aligned
+    float ov[4], mv[2];
+    if (((om.ld & 3) | ((int)(size_t)om.p & 15)) == 0) {
+        const float4 t4 = *reinterpret_cast<const float4 *>(o + 4 * G);
+        const float2 t2 = *reinterpret_cast<const float2 *>(o + 64 + 2 * G);
+        ov[0] = t4.x; ov[1] = t4.y; ov[2] = t4.z; ov[3] = t4.w;
+        mv[0] = t2.x; mv[1] = t2.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = o[4 * G + j];
+        mv[0] = o[64 + 2 * G];
+        mv[1] = o[64 + 2 * G + 1];
+    }
     float v[6];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int n = 2 * G + t;
         // flow.repeat(1, 32, 1, 1): offset channel j gets flow[j % 2]
-        const float dx = 40.f * tanhf(o[2 * n]) + f0;
-        const float dy = 40.f * tanhf(o[2 * n + 1]) + f1;
-        const float mk = 1.f / (1.f + expf(-o[64 + n]));
+        const float dx = 40.f * tanhf(ov[2 * t]) + f0;
+        const float dy = 40.f * tanhf(ov[2 * t + 1]) + f1;
+        const float mk = 1.f / (1.f + expf(-mv[t]));
         const Bilin b = warp_coords(px, py, dx, dy, x.W, x.H);
         const int cb = (n & 15) * 3;
         const float *nw = x.p + ((size_t)b.y0 * x.W + b.x0) * x.ld + cb;
@@ -337,6 +353,7 @@ extern "C" int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const 
     LSSVC_CHECK(same_shape(in, out), "dwconv3x3: in %dx%dx%d vs out %dx%dx%d", in->H, in->W, in->C, out->H, out->W, out->C);
     LSSVC_CHECK(vec4_ok(in) && vec4_ok(out), "dwconv3x3: views must be 4-channel aligned (C=%d ld=%d)", in->C, in->ld);
     const Items it = items_of(out);
+    LSSVC_ITEMS_OK(it.total, "dwconv3x3");
     hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), weight,
                        bias, mk(out), it.cg, it.total);
     return launch_status("dwconv3x3");
@@ -347,6 +364,7 @@ extern "C" int lssvc_resize_bilinear(const lssvc_view *in, const lssvc_view *out
     LSSVC_CHECK(in->C == out->C, "resize_bilinear: C %d vs %d", in->C, out->C);
     const Items it = items_of(out);
     const float sy = (float)in->H / (float)out->H, sx = (float)in->W / (float)out->W;
+    LSSVC_ITEMS_OK(it.total, "resize_bilinear");
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in),
                        mk(out), sy, sx, scale, it.cg, it.total, (int)vec4_ok(in), (int)vec4_ok(out));
     return launch_status("resize_bilinear");
@@ -358,6 +376,7 @@ extern "C" int lssvc_flow_warp(const lssvc_view *in, const lssvc_view *flow, con
                 in->H, in->W, in->C, flow->H, flow->W, flow->C, out->H, out->W, out->C);
     LSSVC_CHECK(in->H > 1 && in->W > 1, "flow_warp: needs H,W > 1");
     const Items it = items_of(out);
+    LSSVC_ITEMS_OK(it.total, "flow_warp");
     hipLaunchKernelGGL(flow_warp_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(flow),
                        mk(out), it.cg, it.total, (int)vec4_ok(in), (int)vec4_ok(out));
     return launch_status("flow_warp");
@@ -368,6 +387,7 @@ extern "C" int lssvc_pool2x2(const lssvc_view *in, const lssvc_view *out, int32_
     LSSVC_CHECK(in->C == out->C && out->H == in->H / 2 && out->W == in->W / 2, "pool2x2: in %dx%dx%d out %dx%dx%d", in->H,
                 in->W, in->C, out->H, out->W, out->C);
     const Items it = items_of(out);
+    LSSVC_ITEMS_OK(it.total, "pool2x2");
     hipLaunchKernelGGL(pool2x2_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(out),
                        (int)is_max, it.cg, it.total, (int)vec4_ok(in), (int)vec4_ok(out));
     return launch_status("pool2x2");
@@ -379,6 +399,7 @@ extern "C" int lssvc_softmax2_blend(const lssvc_view *a, const lssvc_view *b, co
     LSSVC_CHECK(same_shape(a, b) && same_shape(a, out) && same_hw(a, logits) && logits->C == 2, "softmax2_blend: shape mismatch");
     const Items it = items_of(out);
     const int vec = vec4_ok(a) && vec4_ok(b) && vec4_ok(out);
+    LSSVC_ITEMS_OK(it.total, "softmax2_blend");
     hipLaunchKernelGGL(softmax2_blend_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(a), mk(b),
                        mk(logits), mk(out), it.cg, it.total, vec);
     return launch_status("softmax2_blend");
@@ -390,6 +411,7 @@ static int binary(const lssvc_view *a, const lssvc_view *b, const lssvc_view *ou
     LSSVC_CHECK(same_shape(a, out) && (mode != 0 || same_shape(a, b)), "%s: shape mismatch", what);
     const Items it = items_of(out);
     const int vec = vec4_ok(a) && vec4_ok(out) && (mode != 0 || vec4_ok(b));
+    LSSVC_ITEMS_OK(it.total, "binary");
     hipLaunchKernelGGL(binary_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(a),
                        mode == 0 ? mk(b) : mk_null(), mk(out), mode, slope, it.cg, it.total, vec);
     return launch_status(what);
@@ -411,6 +433,7 @@ extern "C" int lssvc_offset_diversity(const lssvc_view *x, const lssvc_view *om,
                 x->C, om->C, flow->C, out->C);
     LSSVC_CHECK(same_hw(x, om) && same_hw(x, flow) && same_hw(x, out) && x->H > 1 && x->W > 1, "offset_diversity: size mismatch");
     const long long total = (long long)x->H * x->W * 16;
+    LSSVC_ITEMS_OK(total, "offset_diversity");
     hipLaunchKernelGGL(offset_diversity_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mk(x), mk(om),
                        mk(flow), fusion_w, fusion_b, mk(out), total);
     return launch_status("offset_diversity");
