@@ -420,8 +420,8 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             if (NM > MPR * NI) __builtin_amdgcn_sched_group_barrier(0x008, NM - MPR * NI, 0);
             __builtin_amdgcn_sched_barrier(0);                                                 // units do not mix
         };
-        load_a(0, fa1[0], fa2[0]);
-        load_b(0, 0, fb1[0], fb2[0]);
+        load_b(0, 0, fb1[0], fb2[0]);                      // B first: the first MFMA needs b1[0] and a2[0], LDS returns in order,
+        load_a(0, fa1[0], fa2[0]);                         // so it can start after 6 of these 12 reads instead of 10
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, NUNIT>{});
         if (STAMP) {

@@ -30,7 +30,6 @@ struct FfnP {
     float pre_u, u1, u2, slope;
     int hidden, n_pre, n1, n2;           // halfs per plane
     int sa;                              // K-steps (of 32 channels) of the leading conv
-    int tstore;                          // store through the coalescing lane layout (conv_mfma_kernel.h, LANE TRANSPOSITION); 0: native MFMA layout
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8 &h, f16x8 &l) {
@@ -109,20 +108,21 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
     const int li = lane & 15;
     const int lg = lane >> 4;
     const int C = p.out.C;
-    const long long npix = (long long)p.out.H * p.out.W;
-    const long long ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
-    const long long wave_id = (long long)blockIdx.x * (kFfnThreads / 64) + wave;
-    const long long wave_stride = (long long)gridDim.x * (kFfnThreads / 64);
+    // 32-bit pixel / group indices (the host refuses images of 2^31 pixels or more): this instantiation sits at the VGPR cap
+    const int npix = p.out.H * p.out.W;
+    const int ngroups = (npix + 16 * RPW - 1) / (16 * RPW);
+    const int wave_id = (int)blockIdx.x * (kFfnThreads / 64) + wave;
+    const int wave_stride = (int)gridDim.x * (kFfnThreads / 64);
     const int T = p.hidden >> 5;
     const int a_off = li * 32 + lg * 8;             // this lane's 8 halfs inside a [16][32] fragment image
 
     // prefetch registers: the next group's inputs in flight while the current one is in the matrix pipe
     float4 nx[CF][RPW];                             // o1 (no leading conv) or ident (leading conv), accumulator layout
     float4 nt[PRE ? SA_MAX : 1][RPW][2];            // leading conv input, B-fragment layout (8 channels per lane)
-    auto load_group = [&](long long grp) {
+    auto load_group = [&](int grp) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            long long q = (grp * RPW + r) * 16 + li;
+            int q = (grp * RPW + r) * 16 + li;
             if (q >= npix) q = 0;
             const V &src = PRE ? p.ident : p.x;
 #pragma unroll
@@ -141,11 +141,11 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
     };
     if (wave_id < ngroups) load_group(wave_id);
 
-    for (long long grp = wave_id; grp < ngroups; grp += wave_stride) {
-        long long pix[RPW];
+    for (int grp = wave_id; grp < ngroups; grp += wave_stride) {
+        int pix[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const long long q = (grp * RPW + r) * 16 + li;
+            const int q = (grp * RPW + r) * 16 + li;
             pix[r] = q < npix ? q : -1;
         }
         // ---- o1 in accumulator layout: o1[f][r][j] = channel 16f + 4g + j of pixel pix[r]
@@ -261,37 +261,26 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
             mfma3<CF, RPW>(oacc, ah, al, hh, hl);
         }
 
-        // ---- out = o1 + lrelu(W2 h + b2). p.tstore (option ffn_tstore, default off): store through the coalescing lane layout of
-        // the conv epilogue -- lane 4 li + lg takes over (pixel li, channel quad lg) from lane 16 lg + li, 59 instead of 16.6
-        // B/clk per CU of store throughput. Measured 0-3.5 % SLOWER here (tools/ffn_ab.py): this kernel's
-        // eight free-running waves already hide the store issue behind each other's MFMAs, and the moves are extra work.
-        const int tcol = lane >> 2, tq = lane & 3;
-        const int bp_addr = ((lane & 3) * 16 + (lane >> 2)) * 4;
+        // ---- out = o1 + lrelu(W2 h + b2)
 #pragma unroll
         for (int f = 0; f < CF; ++f) {
-            const bool ch_ok = f * 16 + 4 * lg < C;
+            if (f * 16 + 4 * lg >= C) continue;
             const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const bool ok = ch_ok && pix[r] >= 0;
+                if (pix[r] < 0) continue;
+                float4 o;
                 float v[4];
                 float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.skip.p && ok) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)pix[r] * p.skip.ld + f * 16 + 4 * lg);
+                if (p.skip.p) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)pix[r] * p.skip.ld + f * 16 + 4 * lg);
                 const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float a = oacc[f][r][j] * p.u2 + b[j];
                     v[j] = (o1[f][r][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
                 }
-                if (p.tstore) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[j])));
-                    const long long qt = (grp * RPW + r) * 16 + tcol;
-                    if (qt < npix && f * 16 + 4 * tq < C)
-                        *reinterpret_cast<float4 *>(p.out.p + (size_t)qt * p.out.ld + f * 16 + 4 * tq) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if (ok) {
-                    *reinterpret_cast<float4 *>(p.out.p + (size_t)pix[r] * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
-                }
+                o = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(p.out.p + (size_t)pix[r] * p.out.ld + f * 16 + 4 * lg) = o;
             }
         }
     }
@@ -478,30 +467,20 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
             __syncthreads();                                 // slice g consumed by everyone; slice g+1 has landed
             ++g;
         }
-        const int tcol = lane >> 2, tq = lane & 3;               // the coalescing store layout of the resident kernel
-        const int bp_addr = ((lane & 3) * 16 + (lane >> 2)) * 4;
 #pragma unroll
         for (int f = 0; f < CF; ++f) {
-            const bool ok = f * 16 + 4 * lg < C && live;
+            if (f * 16 + 4 * lg >= C || !live) continue;
             const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
             float v[4];
             float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.skip.p && ok) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)q * p.skip.ld + f * 16 + 4 * lg);
+            if (p.skip.p) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)q * p.skip.ld + f * 16 + 4 * lg);
             const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = oacc[f][0][j] * p.u2 + b[j];
                 v[j] = (o1[f][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
             }
-            if (p.tstore) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(bp_addr, __float_as_int(v[j])));
-                const long long qt = pass * 128 + wave * 16 + tcol;
-                if (qt < npix && f * 16 + 4 * tq < C)
-                    *reinterpret_cast<float4 *>(p.out.p + (size_t)qt * p.out.ld + f * 16 + 4 * tq) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (ok) {
-                *reinterpret_cast<float4 *>(p.out.p + (size_t)q * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
-            }
+            *reinterpret_cast<float4 *>(p.out.p + (size_t)q * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -567,6 +546,7 @@ extern "C" int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream) {
     LSSVC_CHECK(d->hidden > 0 && d->hidden % 32 == 0, "ffn_f16x3: hidden = %d must be a positive multiple of 32", d->hidden);
     LSSVC_CHECK(d->w1_16 && d->w2_16 && d->b1 && d->b2, "ffn_f16x3: missing FFN weights");
     LSSVC_CHECK(d->slope >= 0.0f && d->slope <= 1.0f, "ffn_f16x3: LeakyReLU slope %g outside [0, 1]", (double)d->slope);
+    LSSVC_CHECK((long long)d->out.H * d->out.W < (1LL << 31) - 64, "ffn_f16x3: %d x %d pixels do not fit 32-bit indexing", d->out.H, d->out.W);
     const bool pre = d->pre_w16 != nullptr;
     FfnP p{};
     p.out = mk(&d->out);
@@ -586,7 +566,6 @@ extern "C" int lssvc_ffn_f16x3(const lssvc_ffn_desc *d, void *stream) {
         p.ident = mk_null();
         p.sa = 0;
     }
-    p.tstore = option_get(OPT_FFN_TSTORE);
     if (d->skip.ptr) {
         LSSVC_CHECK(view_ok(&d->skip) && vec4_ok(&d->skip) && same_shape(&d->skip, &d->out), "ffn_f16x3: bad skip view");
         p.skip = mk(&d->skip);

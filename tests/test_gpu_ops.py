@@ -451,35 +451,6 @@ def test_ffn_fused_matches_fp64(hip, c, hidden, pre_cin, H, W):
     assert e16 <= 8 * e32 + 1e-6, (e16, e32)
 
 
-@pytest.mark.parametrize("c,hidden,pre_cin,H,W", [(64, 256, 64, 21, 35), (48, 192, None, 19, 23), (128, 512, 128, 18, 30), (96, 384, None, 5, 7)])
-def test_ffn_store_layouts_are_bit_identical(hip, c, hidden, pre_cin, H, W):
-    """Option ffn_tstore: the fused tail's results stored through the coalescing lane layout (ds_bpermute) or in the MFMA layout
-    -- same values, ragged sizes included, with a skip operand."""
-    import ctypes as C
-    from lssvc_amd._lib import lib, check
-    g = torch.Generator().manual_seed(c + hidden + H)
-    sd = _ffn_weights(g, c, hidden, pre_cin)
-    Wt = FakeW(sd)
-    ident = nhwc(hip, torch.randn(1, c, H, W, generator=g))
-    skip = nhwc(hip, torch.randn(1, c, H, W, generator=g))
-    t = nhwc(hip, torch.randn(1, pre_cin, H, W, generator=g)) if pre_cin else None
-    old = C.c_int32()
-    check(lib.lssvc_get_option(b"ffn_tstore", C.byref(old)))
-    outs = []
-    try:
-        hip.set_conv_precision("f16x3")
-        for mode in (0, 1):
-            check(lib.lssvc_set_option(b"ffn_tstore", mode))
-            if pre_cin:
-                outs.append(back(hip.ffn_block(Wt, "f", pre_name="p", pre_in=t, ident=ident, skip=skip)))
-            else:
-                outs.append(back(hip.ffn_block(Wt, "f", x=ident, skip=skip)))
-    finally:
-        hip.set_conv_precision("f32")
-        check(lib.lssvc_set_option(b"ffn_tstore", old.value))
-    assert torch.equal(outs[0], outs[1])
-
-
 def test_ffn_fused_on_channel_slices_and_in_place(hip):
     """Views with ld > C (slices of a concat buffer) for every operand, and out aliasing ident."""
     g = torch.Generator().manual_seed(77)
