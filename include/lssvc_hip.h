@@ -307,6 +307,8 @@ int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, u
  *                                    wherever it exists; 2 = that kernel for 48-channel tiles with at most three 16-channel
  *                                    phases only (where it used to win) (LSSVC_F16X3_DEFERRED)
  *   "f16x3_persist7"           1/0   the persistent warp-specialised kernel for 7x7 convs too (LSSVC_F16X3_PERSIST7)
+ *   "pointwise_blocks"         1/0   x2 bilinear resize and depthwise 3x3 compute a 2x2 output block per thread (the input
+ *                                    neighbourhood is loaded once: 9 / 16 loads instead of 16 / 36) (LSSVC_POINTWISE_BLOCKS)
  * Results do not depend on them (the kernels they choose between are bit-identical); tests use them to pin that. */
 int lssvc_set_option(const char *name, int32_t value);
 int lssvc_get_option(const char *name, int32_t *value);

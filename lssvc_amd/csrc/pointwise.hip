@@ -80,6 +80,59 @@ __global__ void dwconv3x3_kernel(V in, const float *__restrict__ w, const float 
     *reinterpret_cast<float4 *>(out.p + (size_t)pix * out.ld + c) = acc;
 }
 
+// The same depthwise conv with a 2x2 output block per thread: the 4x4 input neighbourhood is loaded once (4 loads per output
+// instead of 9 -- the kernel is bound by those L2 reads). Every output accumulates its own nine taps in the generic kernel's
+// order and skips the same out-of-image taps: bit-identical results.
+__global__ void dwconv3x3_b2_kernel(V in, const float *__restrict__ w, const float *__restrict__ bias, V out, int cg, int bw,
+                                    long long total) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)total) return;
+    const unsigned blk = idx / (unsigned)cg;
+    const int g = (int)(idx - blk * (unsigned)cg);
+    const int by = (int)(blk / (unsigned)bw), bx = (int)(blk - (unsigned)by * (unsigned)bw);
+    const int y0 = 2 * by, x0 = 2 * bx, c = g * 4;
+    float4 v[4][4];
+    bool okr[4], okc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        okr[a] = y0 - 1 + a >= 0 && y0 - 1 + a < in.H;
+        okc[a] = x0 - 1 + a >= 0 && x0 - 1 + a < in.W;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const bool ok = okr[a] && okc[b];
+            const size_t off = ok ? ((size_t)(y0 - 1 + a) * in.W + (x0 - 1 + b)) * in.ld + c : (size_t)c;
+            v[a][b] = *reinterpret_cast<const float4 *>(in.p + off);
+        }
+    float4 k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = *reinterpret_cast<const float4 *>(w + t * in.C + c);
+    const float4 bv = *reinterpret_cast<const float4 *>(bias + c);
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox) {
+            if (y0 + oy >= in.H || x0 + ox >= in.W) continue;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    if (!(okr[oy + ky] && okc[ox + kx])) continue;
+                    const float4 &p = v[oy + ky][ox + kx];
+                    const float4 &q = k[ky * 3 + kx];
+                    acc.x = fmaf(p.x, q.x, acc.x);
+                    acc.y = fmaf(p.y, q.y, acc.y);
+                    acc.z = fmaf(p.z, q.z, acc.z);
+                    acc.w = fmaf(p.w, q.w, acc.w);
+                }
+            acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+            *reinterpret_cast<float4 *>(out.p + ((size_t)(y0 + oy) * out.W + x0 + ox) * out.ld + c) = acc;
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bilinear resize, align_corners=False (ATen area_pixel_compute_source_index + guard_index_and_lambda)
 __device__ __forceinline__ void src_index(float scale, int dst, int size, int &i0, int &i1, float &l0, float &l1) {
@@ -125,6 +178,60 @@ __global__ void resize_bilinear_kernel(V in, V out, float sy, float sx, float po
     r.w = lerp2(a.w, b.w, d.w, e.w);
     if (post != 1.0f) { r.x *= post; r.y *= post; r.z *= post; r.w *= post; }
     st4(out, (size_t)pix, c, vout, r);
+}
+
+// Exact x2 upsampling (the inter-layer up-samplers and SpyNet's flow pyramid: 2.1 % of a frame): one thread per INPUT pixel
+// and channel group writes the 2x2 output block. The four outputs read input rows / columns {i-1, i, i+1} (clamped), so 9
+// loads serve what takes the generic kernel 16 -- it is bound by those L2 reads, not by the store. Indices and weights come
+// from the same src_index() calls and the same lerp as the generic kernel: bit-identical results (tests/test_gpu_ops.py).
+__global__ void resize_up2_kernel(V in, V out, float post, int cg, long long total) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)cg;
+    const int g = (int)(idx - pix * (unsigned)cg);
+    const int iy = (int)(pix / (unsigned)in.W), ix = (int)(pix - (unsigned)iy * (unsigned)in.W);
+    const int c = g * 4;
+    const int ry[3] = {iy > 0 ? iy - 1 : 0, iy, iy < in.H - 1 ? iy + 1 : in.H - 1};
+    const int rx[3] = {ix > 0 ? ix - 1 : 0, ix, ix < in.W - 1 ? ix + 1 : in.W - 1};
+    float4 v[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) v[a][b] = *reinterpret_cast<const float4 *>(in.p + ((size_t)ry[a] * in.W + rx[b]) * in.ld + c);
+    // Output row 2 iy + dy reads input rows (y0, y1) = (iy - 1, iy) for dy = 0 and (iy, iy + 1) for dy = 1, i.e. (v[0], v[1]) and
+    // (v[1], v[2]); at the borders src_index() clamps exactly like ry[] does, except at iy = 0, dy = 0 where it returns
+    // (0, 1) with weight 0 on row 1 -- taken from v[2] there so that even the zero-weighted operand is the generic kernel's.
+    // Columns likewise. The horizontal lerps are shared between the two output rows that use the same input row.
+    float hy[2][2], wx[2][2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        int i0, i1;
+        src_index(0.5f, 2 * iy + d, in.H, i0, i1, hy[d][0], hy[d][1]);
+        src_index(0.5f, 2 * ix + d, in.W, i0, i1, wx[d][0], wx[d][1]);
+    }
+    const bool top0 = iy == 0, left0 = ix == 0;
+    float4 h[3][2];                                    // h[row][dx]: horizontal lerp of input row `row` for output column 2 ix + dx
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float4 c1 = left0 ? v[a][2] : v[a][1];   // x1 of dx = 0
+        auto hl = [&](const float4 &p, const float4 &q, float w0, float w1) {
+            return make_float4(fmaf(q.x, w1, p.x * w0), fmaf(q.y, w1, p.y * w0), fmaf(q.z, w1, p.z * w0), fmaf(q.w, w1, p.w * w0));
+        };
+        h[a][0] = hl(v[a][0], c1, wx[0][0], wx[0][1]);
+        h[a][1] = hl(v[a][1], v[a][2], wx[1][0], wx[1][1]);
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const float4 t = dy == 0 ? h[0][dx] : h[1][dx];
+            const float4 bsel = top0 ? h[2][dx] : h[1][dx];
+            const float4 u = dy == 0 ? bsel : h[2][dx];
+            float4 r = make_float4(fmaf(u.x, hy[dy][1], t.x * hy[dy][0]), fmaf(u.y, hy[dy][1], t.y * hy[dy][0]),
+                                   fmaf(u.z, hy[dy][1], t.z * hy[dy][0]), fmaf(u.w, hy[dy][1], t.w * hy[dy][0]));
+            if (post != 1.0f) { r.x *= post; r.y *= post; r.z *= post; r.w *= post; }
+            *reinterpret_cast<float4 *>(out.p + ((size_t)(2 * iy + dy) * out.W + 2 * ix + dx) * out.ld + c) = r;
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,6 +459,14 @@ extern "C" int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const 
     LSSVC_CHECK(view_ok(in) && view_ok(out) && weight && bias, "dwconv3x3: bad arguments");
     LSSVC_CHECK(same_shape(in, out), "dwconv3x3: in %dx%dx%d vs out %dx%dx%d", in->H, in->W, in->C, out->H, out->W, out->C);
     LSSVC_CHECK(vec4_ok(in) && vec4_ok(out), "dwconv3x3: views must be 4-channel aligned (C=%d ld=%d)", in->C, in->ld);
+    if (option_get(OPT_POINTWISE_BLOCKS) && in->H > 1 && in->W > 1) {
+        const int cg = (out->C + 3) / 4, bw = (out->W + 1) / 2;
+        const long long total = (long long)((out->H + 1) / 2) * bw * cg;
+        LSSVC_ITEMS_OK(total, "dwconv3x3");
+        hipLaunchKernelGGL(dwconv3x3_b2_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mk(in), weight, bias, mk(out),
+                           cg, bw, total);
+        return launch_status("dwconv3x3(2x2 blocks)");
+    }
     const Items it = items_of(out);
     LSSVC_ITEMS_OK(it.total, "dwconv3x3");
     hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), weight,
@@ -362,6 +477,13 @@ extern "C" int lssvc_dwconv3x3(const lssvc_view *in, const float *weight, const 
 extern "C" int lssvc_resize_bilinear(const lssvc_view *in, const lssvc_view *out, float scale, void *stream) {
     LSSVC_CHECK(view_ok(in) && view_ok(out), "resize_bilinear: bad views");
     LSSVC_CHECK(in->C == out->C, "resize_bilinear: C %d vs %d", in->C, out->C);
+    if (option_get(OPT_POINTWISE_BLOCKS) && out->H == 2 * in->H && out->W == 2 * in->W && vec4_ok(in) && vec4_ok(out) && in->H > 1 && in->W > 1) {
+        const Items ii = items_of(in);                 // one thread per input pixel and channel group
+        LSSVC_ITEMS_OK(ii.total, "resize_bilinear");
+        hipLaunchKernelGGL(resize_up2_kernel, dim3(blocks_for(ii.total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(out), scale,
+                           ii.cg, ii.total);
+        return launch_status("resize_bilinear(x2)");
+    }
     const Items it = items_of(out);
     const float sy = (float)in->H / (float)out->H, sx = (float)in->W / (float)out->W;
     LSSVC_ITEMS_OK(it.total, "resize_bilinear");

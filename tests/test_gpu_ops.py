@@ -160,6 +160,47 @@ def test_resize(hip, c, hin, win, hout, wout, scale):
     close(got, want, rtol=1e-6, atol=1e-6)
 
 
+def _with_option(name, value, fn):
+    import ctypes as C
+    from lssvc_amd._lib import lib, check
+    old = C.c_int32()
+    check(lib.lssvc_get_option(name.encode(), C.byref(old)))
+    try:
+        check(lib.lssvc_set_option(name.encode(), value))
+        return fn()
+    finally:
+        check(lib.lssvc_set_option(name.encode(), old.value))
+
+
+@pytest.mark.parametrize("c,H,W", [(48, 19, 23), (64, 32, 48), (4, 2, 2), (96, 7, 40), (32, 33, 2)])
+def test_dwconv_block_kernel_is_bit_identical(hip, c, H, W):
+    """Option pointwise_blocks: the depthwise 3x3 with a 2x2 output block per thread (4x4 neighbourhood loaded once) against
+    the one-output-per-thread kernel, odd sizes and borders included; and against ATen."""
+    g = torch.Generator().manual_seed(c + H)
+    x = torch.randn(1, c, H, W, generator=g)
+    w = torch.randn(c, 1, 3, 3, generator=g) / 3
+    b = torch.randn(c, generator=g)
+    Wt = FakeW({"d.weight": w, "d.bias": b})
+    xin = nhwc(hip, x)
+    blocks = _with_option("pointwise_blocks", 1, lambda: back(hip.dwconv3x3(Wt, "d", xin)))
+    single = _with_option("pointwise_blocks", 0, lambda: back(hip.dwconv3x3(Wt, "d", xin)))
+    assert torch.equal(blocks, single)
+    close(blocks, F.conv2d(x, w, b, padding=1, groups=c), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("c,hin,win,scale", [(64, 16, 24, 1.0), (48, 33, 17, 2.0), (8, 2, 2, 1.0), (96, 37, 61, 0.5)])
+def test_resize_x2_kernel_is_bit_identical_to_the_generic_one(hip, c, hin, win, scale):
+    """Exact x2 upsampling of 4-channel-aligned views runs on resize_up2_kernel (9 loads per 2x2 output block); option
+    pointwise_blocks = 0 sends it to the generic kernel: same src_index / lerp arithmetic, equal bits."""
+    x = torch.randn(1, c, hin, win, generator=torch.Generator().manual_seed(c + hin))
+    xin = nhwc(hip, x)
+    fast = _with_option("pointwise_blocks", 1, lambda: back(hip.resize(xin, 2 * hin, 2 * win, scale=scale)))
+    slow = _with_option("pointwise_blocks", 0, lambda: back(hip.resize(xin, 2 * hin, 2 * win, scale=scale)))
+    assert torch.equal(fast, slow)
+    want = F.interpolate(x, size=(2 * hin, 2 * win), mode="bilinear", align_corners=False) * scale
+    close(fast, want, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("c,H,W,mag", [(3, 32, 48, 3.0), (64, 24, 40, 8.0), (48, 64, 64, 50.0), (96, 8, 12, 1.0)])
 def test_flow_warp(hip, c, H, W, mag):
     from lssvc_oracle.blocks import flow_warp
