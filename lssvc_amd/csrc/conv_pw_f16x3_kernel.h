@@ -368,9 +368,9 @@ static int launch_pwk_f16x3(const ConvP &p, hipStream_t st) {
 // slice every 8 steps (two barriers), while each wave owns ONE 64-pixel group whose MF x 4 accumulators live in
 // registers across all slices; the X ring prefetch runs straight through the slice boundaries. One group per wave,
 // no persistence: meant for launches with few pixel groups.
-template <int MF, bool MULTI>
+template <int MF, bool MULTI, int RPW = 4>
 __global__ __launch_bounds__(256, 2) void conv_pwks_f16x3_kernel(const ConvP p) {
-    constexpr int TM = 16 * MF, RPW = 4, D = 2, SLICE_STEPS = 8, SLICE_SLOTS = 2 * SLICE_STEPS;
+    constexpr int TM = 16 * MF, D = 2, SLICE_STEPS = 8, SLICE_SLOTS = 2 * SLICE_STEPS;      // (a ring of 4 for the 32-pixel variant measured slower)
     extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];     // [hi|lo][slot in slice][TM][16]
     constexpr int plane = SLICE_SLOTS * TM * CK16;
     const int tid = threadIdx.x;
@@ -512,11 +512,22 @@ static int launch_pwks_f16x3(const ConvP &p, hipStream_t st) {
     q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
     const size_t lds = (size_t)2 * 16 * 16 * MF * CK16 * sizeof(_Float16);          // 16 KiB per M fragment
     const long long npix = (long long)p.Hout * p.Wout;
-    const long long ngroups = (npix + 63) / 64;
+    // 64-pixel groups (4 accumulator rows per wave) unless that leaves most of the chip without a second workgroup per CU to
+    // hide the X loads and the re-staging barriers behind: then 32-pixel groups, twice the workgroups (the weight slices are
+    // re-read from L2 twice as often; at these sizes they are a few MB)
+    static const int small_on = getenv("LSSVC_PWKS_SMALL") ? atoi(getenv("LSSVC_PWKS_SMALL")) : 1;
+    const long long blocks64 = (((npix + 63) / 64 + 3) / 4) * q.m_tiles;
+    const bool small = small_on && blocks64 < 2LL * device_cus();
+    const long long ngroups = small ? (npix + 31) / 32 : (npix + 63) / 64;
     const long long blocks = ((ngroups + 3) / 4) * q.m_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return fail("conv2d(pwks f16x3): bad grid %lld", blocks);
-    if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true>), dim3((unsigned)blocks), dim3(256), lds, st, q);
-    else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    if (small) {
+        if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true, 2>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+        else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false, 2>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    } else {
+        if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true, 4>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+        else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false, 4>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    }
     return launch_status("conv2d(pwks f16x3)");
 }
 
