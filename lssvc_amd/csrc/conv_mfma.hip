@@ -57,6 +57,11 @@ static void pick_variant(const ConvP &p, int &MF, int &RPW) {
     if (frags % 4 != 0 && frags % 3 == 0) MF = 3;
     RPW = (p.stride == 2) ? 2 : 4;
     while (RPW > 1 && (p.Hout <= 2 * RPW || grid_blocks(p, MF, RPW) < 512)) RPW >>= 1;
+    // still fewer workgroups than CUs (the prior networks' 36x60 / 72x120 maps): these launches are bound by the latency of
+    // staging a K chunk, not by the matrix pipe, so narrower M tiles = more workgroups in flight beat the patch re-staging
+    static const int narrow = getenv("LSSVC_TILED_NARROW") ? atoi(getenv("LSSVC_TILED_NARROW")) : 1;
+    if (narrow && RPW == 1)
+        while (MF > 1 && MF % 2 == 0 && grid_blocks(p, MF, RPW) < 256) MF >>= 1;
 }
 
 }  // namespace lssvc
