@@ -15,9 +15,10 @@
 //     image order) global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write). Their VALU / VMEM issue
 //     slots interleave with the consumer's MFMAs on the same SIMD (an MFMA holds the issue port 8 of its 16 cycles);
 //     their memory latency is hidden by not being on the consumers' path at all.
-//   * both operand images are double-buffered in LDS (2 x (30 KB patch + 37 KB weights) = 134 KB at RPW = 6): ONE workgroup
-//     barrier per phase (phase = one 16-channel chunk, all 9 taps), and the phase sequence runs on across tile
-//     boundaries, so tiles have no head or tail.
+//   * both operand images are double-buffered in LDS (2 x (30 KB patch + 37 KB weights) = 134 KB at RPW = 6); a phase is one
+//     16-channel chunk, all 9 taps, and the phase sequence runs on across tile boundaries, so tiles have no head or tail.
+//     The buffers are handed over through per-wave LDS slots (fills completed / phases completed), not barriers: a consumer
+//     waits only for the fill of its next phase, only the producers wait for the slowest consumer.
 // Arithmetic, operand order inside a K-step, accumulator layout and the fused epilogue are those of
 // conv_f16x3_kernel (f16x3_step_pair per two taps x 16 channels, f16x3_step_odd for the ninth tap): results are
 // bit-identical to it. conv3_f16x3d.hip is an experimental variant with a deferred epilogue
