@@ -83,11 +83,13 @@ def encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log=None, host_frames=None
     bits = []
     dpb = None
     n = len(host_frames) if host_frames is not None else len(x_els)
-    graph = pnet.graph_mode
+    graph, streams = pnet.graph_mode, hip_ops.MULTI_STREAM
     for t in range(n):
         logging = op_log is not None and 1 <= t <= EVENT_FRAMES
         hip_ops.OP_LOG = op_log if logging else None
-        pnet.graph_mode = graph and not logging        # per-launch events need the eager path for these frames
+        pnet.graph_mode = graph and not logging        # per-launch events need the eager path for these frames ...
+        hip_ops.MULTI_STREAM = streams and not logging # ... and one stream: a launch timed beside another stream's kernels
+        #                                                measures the contention, not the kernel
         inet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
         pnet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
         x_bl, x_el = host_frames.layers(t) if host_frames is not None else (x_bls[t], x_els[t])
@@ -103,6 +105,7 @@ def encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log=None, host_frames=None
         bits.append((r["bit_bl"], r["bit_el"]))
     hip_ops.OP_LOG = None
     pnet.graph_mode = graph
+    hip_ops.MULTI_STREAM = streams
     return bits, dpb
 
 
@@ -306,6 +309,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events in the last timed step")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying hipGraph frame plans")
+    ap.add_argument("--no-streams", action="store_true", help="one stream: no parallel branches in the frame plans (same as LSSVC_STREAMS=0)")
     ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop (per-frame H2D + pre-processing included)")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline at the full 1152x1920 size (takes > 7 min on a 16-core host share)")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
@@ -326,6 +330,8 @@ def main():
     from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
     if args.precision:
         hip_ops.set_conv_precision(args.precision)
+    if args.no_streams:
+        hip_ops.MULTI_STREAM = False
     from lssvc_amd.synth import synth_state_dict
     inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, GAIN)).to(device).eval()
     pnet = LSSVC_extend()
@@ -397,7 +403,8 @@ def main():
                                    "per-frame H2D + pre-processing included in `h2d_inclusive`" % args.frames,
                        "frames_per_step_per_gpu": args.frames, "weights": "seeded synthetic (lssvc_amd.synth, gain %.2f)" % GAIN,
                        "parallelism": "gop-shard x%d (no data-path collective)" % world,
-                       "launch": "eager (ctypes per kernel)" if args.no_graph else "hipGraph frame plans (I / first-P / steady-P)"},
+                       "launch": ("eager (ctypes per kernel)" if args.no_graph else "hipGraph frame plans (I / first-P / steady-P)")
+                                 + (", independent chains of a frame as parallel branches (side streams)" if hip_ops.MULTI_STREAM else ", single stream")},
         }
         if dt_incl is not None:
             out["h2d_inclusive"] = {

@@ -302,10 +302,6 @@ int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, u
 /* Runtime tuning switches (each also reads an environment variable at first use):
  *   "f16x3_persist"            1/0   use the persistent warp-specialised 3x3 kernel (LSSVC_F16X3_PERSIST)
  *   "f16x3_persist_min_tiles"  n     ... for convs with at least n output tiles (LSSVC_F16X3_PERSIST_MIN_TILES, 256)
- *   "f16x3_deferred"           0/1/2 which persistent kernel: 0 (default) = 24x16 tiles, epilogue at the tile boundary; 1 = the
- *                                    experimental 16x16-tile kernel with the epilogue deferred into the next tile's MFMA stream
- *                                    wherever it exists; 2 = that kernel for 48-channel tiles with at most three 16-channel
- *                                    phases only (where it used to win) (LSSVC_F16X3_DEFERRED)
  *   "f16x3_persist7"           1/0   the persistent warp-specialised kernel for 7x7 convs too (LSSVC_F16X3_PERSIST7)
  *   "pointwise_blocks"         1/0   x2 bilinear resize and depthwise 3x3 compute a 2x2 output block per thread (the input
  *                                    neighbourhood is loaded once: 9 / 16 loads instead of 16 / 36) (LSSVC_POINTWISE_BLOCKS)

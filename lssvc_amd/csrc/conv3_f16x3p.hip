@@ -21,8 +21,7 @@
 //     waits only for the fill of its next phase, only the producers wait for the slowest consumer.
 // Arithmetic, operand order inside a K-step, accumulator layout and the fused epilogue are those of
 // conv_f16x3_kernel (f16x3_step_pair per two taps x 16 channels, f16x3_step_odd for the ninth tap): results are
-// bit-identical to it. conv3_f16x3d.hip is an experimental variant with a deferred epilogue
-// (lssvc_set_option("f16x3_deferred", 1)).
+// bit-identical to it.
 #include <type_traits>
 #include <utility>
 

@@ -309,12 +309,10 @@ int dispatch_tile_f16x3_s2(const ConvP &p, int MF, int RPW, hipStream_t st) {
 }
 extern template int dispatch_tile_f16x3_s2<3>(const ConvP &, int, int, hipStream_t);
 
-// persistent 3x3 variants for large images (producer / consumer waves): conv3_f16x3p.hip (24x16-pixel tiles, epilogue at
-// the tile boundary; the default) and conv3_f16x3d.hip (16x16 tiles, epilogue deferred into the next tile's MFMA stream;
-// option f16x3_deferred = 1: an experiment that is bit-identical but only pays for 48-channel tiles with a residual)
+// persistent 3x3 kernel for large images (producer / consumer waves): conv3_f16x3p.hip (24x16-pixel tiles, epilogue at
+// the tile boundary)
 bool conv3_f16x3p_wanted(const ConvP &p);
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
-int dispatch_conv3_f16x3d(const ConvP &p, hipStream_t st, char *kernel_name);
 // ... and the 7x7 counterpart (conv7_f16x3p.hip)
 bool conv7_f16x3p_wanted(const ConvP &p);
 int dispatch_conv7_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);

@@ -26,9 +26,9 @@ namespace lssvc {
 // ---- runtime tuning switches: environment at first use, lssvc_set_option() afterwards ----------------
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<bool> g_opt_set[OPT_COUNT];
-static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_DEFERRED", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS"};
-static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_deferred", "f16x3_persist7", "pointwise_blocks"};
-static const int kOptDefault[OPT_COUNT] = {1, 256, 0, 1, 1};
+static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS"};
+static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks"};
+static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1};
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
         const char *e = getenv(kOptEnv[which]);
@@ -198,16 +198,7 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         p.w16_unscale = d->weight16_unscale != 0.0f ? d->weight16_unscale : 1.0f;
         p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
         if (vec && sd == 1 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3_f16x3p_wanted(p))
-        {
-            // f16x3_deferred: 0 = 24x16 tiles always, 1 = the deferred-epilogue kernel wherever it exists, 2 (default) = where it
-            // measured faster: 48-output-channel tiles with at most three 16-channel phases (48 -> 48: +3..10 %; with more
-            // phases per tile or 64 output channels the 24x16 kernel wins, profiles/r02_p3_kernel_ab.txt)
-            const int mode = option_get(OPT_P3_DEFERRED);
-            const int frags = p.M_pad / 16;
-            const bool small48 = frags % 4 != 0 && frags % 3 == 0 && p.n_chunks16 <= 3;
-            if (mode == 1 || (mode == 2 && small48)) return dispatch_conv3_f16x3d(p, st, kname);
             return dispatch_conv3_f16x3p(p, st, kname);
-        }
         static const int s2_on = getenv("LSSVC_F16X3_S2") ? atoi(getenv("LSSVC_F16X3_S2")) : 1;
         if (s2_on && vec && sd == 2 && ks == 3 && RPW <= 2) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, 3, 2>", MF, RPW);

@@ -49,6 +49,74 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- side streams: independent chains of one frame as parallel branches ---------------------------------------------
+# A frame is a fixed DAG of ~400 launches, most of them on maps so small that one launch cannot fill 256 CUs (the prior /
+# hyper / motion-vector codecs). Chains that do not depend on each other (EL SpyNet || the whole BL codec; the BL-texture
+# pyramid || the EL motion-vector codec; ...) are issued on side streams between fork/join events, so that under a
+# captured frame plan they become parallel branches of the hipGraph and in eager mode concurrent HIP streams. The kernels
+# and their per-chain order are unchanged, so results are bit-identical to the single-stream order.
+#
+# Memory: PyTorch's caching allocator recycles a freed block for the next allocation on the block's OWN stream, which is
+# only safe if every other stream that touched the block has been joined since. Every buffer touched by a launch inside
+# a branch is therefore kept alive until the Fork is closed (end of the frame body, after all joins).
+MULTI_STREAM = _os.environ.get("LSSVC_STREAMS", "1") == "1"
+_KEEP = None              # buffers touched while a branch is open (None outside branches)
+_SIDE_STREAMS = {}
+
+
+class _Branch:
+    def __init__(self, fork, i):
+        self.fork, self.i, self.ctx = fork, i, None
+
+    def __enter__(self):
+        global _KEEP
+        f = self.fork
+        if f.enabled:
+            assert _KEEP is None, "branches do not nest"
+            s = f.streams[self.i]
+            s.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(s)
+            self.ctx.__enter__()
+            _KEEP = f.keep
+            f.open.add(self.i)
+        return self
+
+    def __exit__(self, *exc):
+        global _KEEP
+        if self.fork.enabled:
+            _KEEP = None
+            self.ctx.__exit__(*exc)
+        return False
+
+
+class Fork:
+    """Fork/join bookkeeping of one frame body: `with fork.branch(i): ...` issues the enclosed launches on side stream i
+    (which first waits for everything issued so far on the current stream); `fork.join(i)` makes the current stream wait
+    for that branch. A branch index may be reused after its join. Disabled (LSSVC_STREAMS=0 / enabled=False) it is a no-op
+    and everything runs in program order on the current stream."""
+
+    def __init__(self, device, enabled=None, n=3):
+        self.enabled = MULTI_STREAM if enabled is None else bool(enabled)
+        self.keep, self.open = [], set()
+        if self.enabled:
+            key = (device.index, n)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = [torch.cuda.Stream(device) for _ in range(n)]
+            self.streams = _SIDE_STREAMS[key]
+
+    def branch(self, i):
+        return _Branch(self, i)
+
+    def join(self, i):
+        if self.enabled and i in self.open:
+            torch.cuda.current_stream().wait_stream(self.streams[i])
+            self.open.discard(i)
+
+    def close(self):
+        for i in sorted(self.open):
+            self.join(i)
+
+
 class T:
     """An H x W x C fp32 view (batch 1) with pixel pitch `ld` into a flat torch buffer."""
     __slots__ = ("buf", "H", "W", "C", "ld", "off", "_v")
@@ -71,10 +139,14 @@ class T:
 
     @property
     def v(self):
+        if _KEEP is not None:
+            _KEEP.append(self.buf)          # touched by a side-stream launch: alive until the frame's Fork closes
         return self._v
 
     @property
     def ref(self):
+        if _KEEP is not None:
+            _KEEP.append(self.buf)
         return C.byref(self._v)
 
     def slice(self, c0, c1):
@@ -448,14 +520,24 @@ class BitSlots:
 
     def __init__(self, device, n=16):
         self.vals = torch.zeros(n, dtype=torch.float64, device=device)
-        self.ws = torch.empty(int(lib.lssvc_reduce_workspace_bytes()) // 8, dtype=torch.float64, device=device)
+        self.device = device
+        words = int(lib.lssvc_reduce_workspace_bytes()) // 8
+        self._free = [torch.empty(words, dtype=torch.float64, device=device) for _ in range(8)]   # up front: none is ever
+        self._ws = {}                                                                             # allocated inside a capture
 
     def slot(self, i):
         return C.c_void_p(self.vals.data_ptr() + 8 * i)
 
     @property
     def wsp(self):
-        return C.c_void_p(self.ws.data_ptr())
+        """The reduction workspace of the CURRENT stream (reductions on different streams may run concurrently)."""
+        sid = torch.cuda.current_stream().cuda_stream
+        ws = self._ws.get(sid)
+        if ws is None:
+            if not self._free:
+                raise RuntimeError("BitSlots: more than 8 streams issued bit reductions")
+            ws = self._ws[sid] = self._free.pop()
+        return C.c_void_p(ws.data_ptr())
 
     def fetch(self):
         return self.vals.cpu().tolist()     # the per-frame device->host sync (reference: .item(), IntraSS.py:166)

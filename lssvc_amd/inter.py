@@ -65,15 +65,22 @@ class LSSVC_extend(_HostModel):
             out = T.empty(scales.H, scales.W, scales.C, self.device)
         return ops.import_symbols(source.pull(idx, self._tables["laplace"]), out, mean=means, chunk_of_mask=chunk_of_mask)
 
-    def _bl_codec(self, x, ref_frame, ref_feature, sink=None, source=None):
+    def _bl_codec(self, x, ref_frame, ref_feature, sink=None, source=None, fk=None):
         """DMC base layer in one of two roles sharing every decoder-side kernel:
         encoder (x given): get_inter_layer_information (dmc_net.py:421-488) / DMCExtend.compress
         (dmc_net_extend.py:55-107, symbols pushed to `sink` in the order mv_z, mv_y, z, y);
         decoder (source given): DMCExtend.decompress (dmc_net_extend.py:109-146).
-        Estimate-mode bit slots 0..3 = y, z, mv_y, mv_z."""
+        Estimate-mode bit slots 0..3 = y, z, mv_y, mv_z.
+        fk: the frame's ops.Fork -- chains that do not depend on the motion-vector codec (the feature pyramid of the
+        reference, later the temporal prior) are issued as parallel branches (side streams 1 and 2)."""
         W, S, p = self.W, self.slots, "base_layer_model"
         tb = self._tables
         decoding = source is not None
+        fk = fk if fk is not None else ops.Fork(self.device, enabled=False)
+        with fk.branch(1):                      # needs only the DPB: runs beside ME + the whole MV codec
+            f = ops.conv(W, p + ".feature_adaptor_I", ref_frame) if ref_feature is None \
+                else ops.conv(W, p + ".feature_adaptor_P", ref_feature)
+            r1, r2, r3 = B.pyramid_extractor(W, p + ".feature_extractor", f)
         if not decoding:
             est_mv = B.spynet(W, p + ".optic_flow", x, ref_frame)
             # mv_encoder (dmc_net.py:174-188)
@@ -87,6 +94,7 @@ class LSSVC_extend(_HostModel):
             mv_z = self._prior_encoder(p + ".mv_prior_encoder", mv_y)
             mv_z_hat = mv_z.like()
             ops.factorized_quant_bits(mv_z, W.bit_estimator(p + ".bit_estimator_z_mv"), S, 3, z_hat=mv_z_hat)
+            self._tap("bl_mv_z", mv_z_hat)
             if sink:
                 sink.push(*ops.export_symbols(mv_z_hat, None), tb["bl_z_mv"])
         else:
@@ -95,8 +103,9 @@ class LSSVC_extend(_HostModel):
         mv_scales, mv_means = self._prior_decoder_bl(p + ".mv_prior_decoder", mv_z_hat).chunk(2)
         if not decoding:
             mv_y_hat = mv_y.like()
-            mv_y_q = mv_y.like() if sink else None
+            mv_y_q = mv_y.like() if (sink or self.taps is not None) else None
             ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 2, y_q=mv_y_q, y_hat=mv_y_hat)
+            self._tap("bl_mv_y", mv_y_q)
             if sink:
                 sink.push(*ops.export_symbols(mv_y_q, mv_scales, LAPLACE_IDX), tb["laplace"])
         else:
@@ -114,37 +123,39 @@ class LSSVC_extend(_HostModel):
         # motion_compensation (dmc_net.py:352-368)
         mv2 = ops.resize(mv_hat, mv_hat.H // 2, mv_hat.W // 2, scale=0.5)
         mv3 = ops.resize(mv2, mv2.H // 2, mv2.W // 2, scale=0.5)
-        f = ops.conv(W, p + ".feature_adaptor_I", ref_frame) if ref_feature is None \
-            else ops.conv(W, p + ".feature_adaptor_P", ref_feature)
-        r1, r2, r3 = B.pyramid_extractor(W, p + ".feature_extractor", f)
+        fk.join(1)
         c1, c2, c3 = B.context_fusion(W, p + ".context_fusion_net", ops.flow_warp(r1, mv_hat), ops.flow_warp(r2, mv2),
                                       ops.flow_warp(r3, mv3))
 
+        with fk.branch(1):                      # temporal prior (dmc_net.py:121-140): contexts only, beside encoder + hyper codec
+            q = p + ".temporal_prior_encoder"
+            t = ops.gdn(W, q + ".gdn1", ops.conv(W, q + ".conv1", c1, stride=2), "inter")
+            t = ops.gdn(W, q + ".gdn2", ops.conv(W, q + ".conv2", [t, c2], stride=2), "inter")
+            t = ops.gdn(W, q + ".gdn3", ops.conv(W, q + ".conv3", [t, c3], stride=2), "inter")
+            temporal = ops.conv(W, q + ".conv4", t, stride=2)
         if not decoding:
             y = B.res_encoder_gdn(W, p + ".res_encoder", x, c1, c2, c3, "inter")
             z = self._prior_encoder(p + ".res_prior_encoder", y)
             z_hat = z.like()
             ops.factorized_quant_bits(z, W.bit_estimator(p + ".bit_estimator_z"), S, 1, z_hat=z_hat)
+            self._tap("bl_z", z_hat)
             if sink:
                 sink.push(*ops.export_symbols(z_hat, None), tb["bl_z"])
         else:
             z_hat = self._pull_factorized(source, tb["bl_z"], 64, zh, zw)
 
         # params = cat(temporal 192, hierarchical 192) -> res_entropy_parameter (dmc_net.py:440-445)
-        q = p + ".temporal_prior_encoder"
-        t = ops.gdn(W, q + ".gdn1", ops.conv(W, q + ".conv1", c1, stride=2), "inter")
-        t = ops.gdn(W, q + ".gdn2", ops.conv(W, q + ".conv2", [t, c2], stride=2), "inter")
-        t = ops.gdn(W, q + ".gdn3", ops.conv(W, q + ".conv3", [t, c3], stride=2), "inter")
-        temporal = ops.conv(W, q + ".conv4", t, stride=2)
         hier = self._prior_decoder_bl(p + ".res_prior_decoder", z_hat)
+        fk.join(1)
         q = p + ".res_entropy_parameter"
         t = ops.conv(W, q + ".0", [temporal, hier], act="lrelu")
         t = ops.conv(W, q + ".2", t, act="lrelu")
         scales, means = ops.conv(W, q + ".4", t).chunk(2)
         if not decoding:
             y_hat = y.like()
-            y_q = y.like() if sink else None
+            y_q = y.like() if (sink or self.taps is not None) else None
             ops.laplace_quant_bits(y, means, scales, S, 0, y_q=y_q, y_hat=y_hat)
+            self._tap("bl_y", y_q)
             if sink:
                 sink.push(*ops.export_symbols(y_q, scales, LAPLACE_IDX), tb["laplace"])
         else:
@@ -196,30 +207,35 @@ class LSSVC_extend(_HostModel):
         fb = W.vector(p + ".fusion.bias")
         return ops.offset_diversity_tail(x, om, flow, fw, fb)
 
-    def _motion_compensation(self, ref, feature_el, mv):
-        """LSSVC.motion_compensation + multi_scale_feature_extractor (LSSVC_net.py:195-202,229-244)."""
+    def _ref_pyramid(self, ref, feature_el):
+        """multi_scale_feature_extractor (LSSVC_net.py:195-202): feature pyramid of the reference; needs only the DPB."""
         W = self.W
-        warpframe = ops.flow_warp(ref, mv)
-        mv2 = ops.resize(mv, mv.H // 2, mv.W // 2, scale=0.5)
-        mv3 = ops.resize(mv2, mv2.H // 2, mv2.W // 2, scale=0.5)
         if feature_el is None:
             f = ops.conv(W, "feature_adaptor_EL_I", ref)
         elif feature_el.C == 64:
             f = ops.conv(W, "feature_adaptor_EL_first_P", feature_el)
         else:
             f = ops.conv(W, "feature_adaptor_EL", feature_el)
-        r1, r2, r3 = B.pyramid_extractor(W, "feature_extractor", f)
+        return B.pyramid_extractor(W, "feature_extractor", f)
+
+    def _motion_compensation(self, ref, ref_pyr, mv):
+        """LSSVC.motion_compensation (LSSVC_net.py:229-244) on the reference's feature pyramid."""
+        W = self.W
+        warpframe = ops.flow_warp(ref, mv)
+        mv2 = ops.resize(mv, mv.H // 2, mv.W // 2, scale=0.5)
+        mv3 = ops.resize(mv2, mv2.H // 2, mv2.W // 2, scale=0.5)
+        r1, r2, r3 = ref_pyr
         c1_init = ops.flow_warp(r1, mv)
         c1 = self._offset_diversity(r1, [c1_init, warpframe, mv], mv)
         c2, c3 = ops.flow_warp(r2, mv2), ops.flow_warp(r3, mv3)
         return B.context_fusion(W, "context_fusion_net", c1, c2, c3), warpframe
 
-    def _el_context(self, texture_bl, mv, ref, feature_el):
-        """LSSVC.hybrid_temporal_layer_context_fusion (LSSVC_net.py:246-259)."""
+    def _el_context(self, spat, mv, ref, ref_pyr):
+        """LSSVC.hybrid_temporal_layer_context_fusion (LSSVC_net.py:246-259); spat = the texture pyramid of the up-sampled
+        base-layer feature (`texture_extractor(texture_resampler(texture_bl))`), ref_pyr = _ref_pyramid(...)."""
         W = self.W
-        temp, warpframe = self._motion_compensation(ref, feature_el, mv)
-        if texture_bl is not None:
-            spat = B.pyramid_extractor(W, "texture_extractor", self._texture_resampler(texture_bl))
+        temp, warpframe = self._motion_compensation(ref, ref_pyr, mv)
+        if spat is not None:
             ctx = []
             for i, g in enumerate(("generator1", "generator2", "generator3")):   # HybridWeightGenerator :115-154
                 q = "weight_map_generator." + g
@@ -268,15 +284,24 @@ class LSSVC_extend(_HostModel):
                 sink.push(*ops.export_symbols(y_q, s_hat, LAPLACE_IDX, chunk_of_mask=CHUNK_OF_MASK[step]), self._tables["laplace"])
         return y_q, y_hat, s_hat
 
-    def _el_codec(self, xe, bl, ref_el, feat_el, sink=None, source=None):
+    def _el_codec(self, xe, bl, ref_el, feat_el, sink=None, source=None, fk=None, pre=None):
         """LSSVC enhancement layer; `bl` = base-layer outputs {feature, mv_hat, y_hat} (encoder-side in estimate
         mode, DECODED in write mode, LSSVC_net_extend.py:143-147). Encoder: forward_one_frame
         (LSSVC_net.py:458-508) / compress (LSSVC_net_extend.py:24-84, symbols pushed in the order mv_z, mv_y, z,
-        y_w0..3); decoder: decompress (LSSVC_net_extend.py:86-136). EL estimate bit slots 4..7 = y, mv_y, z, mv_z."""
+        y_w0..3); decoder: decompress (LSSVC_net_extend.py:86-136). EL estimate bit slots 4..7 = y, mv_y, z, mv_z.
+        fk / pre: the frame's ops.Fork and what its branch 0 already issued from the inputs and the DPB alone
+        ({"mv": ME_Spynet_DCVC flow, "ref_pyr": _ref_pyramid}); both optional (then everything runs here, in order)."""
         W, S = self.W, self.slots
         tb = self._tables
         H, Wd = self.shape_hr
         decoding = source is not None
+        fk = fk if fk is not None else ops.Fork(self.device, enabled=False)
+        pre = pre or {}
+        fused = T.empty(H // 16, Wd // 16, 384, self.device)       # cat(hyper 128, temporal 128, layer 128), filled in place
+        with fk.branch(1):        # BL texture -> EL pyramid (lssvc_modules.py:368-397,157-177): beside the whole EL MV codec
+            spat = B.pyramid_extractor(W, "texture_extractor", self._texture_resampler(bl["feature"]))
+        with fk.branch(2):        # BL latent -> EL prior (lssvc_modules.py:400-429): small maps, needed only by the prior fusion
+            self._layer_prior_resampler(bl["y_hat"], out=fused.slice(256, 384))
         mv_up = self._mv_resampler(bl["mv_hat"])
         # mv_ctx_prior_encoder (LSSVC_net.py:108-116)
         t, e = mv_up, "mv_ctx_prior_encoder"
@@ -287,7 +312,11 @@ class LSSVC_extend(_HostModel):
 
         zh, zw = bitstream.get_downsampled_shape(H, Wd, 64)
         if not decoding:
-            mv = B.spynet(W, "optic_flow", xe, ref_el)
+            if "mv" in pre:
+                fk.join(0)
+                mv = pre["mv"]
+            else:
+                mv = B.spynet(W, "optic_flow", xe, ref_el)
             # MVResEncoder (lssvc_modules.py:445-469)
             e = "mv_encoder.encoder1"
             t = ops.gdn(W, e + ".1", ops.conv(W, e + ".0", mv, stride=2), "inter")
@@ -301,6 +330,7 @@ class LSSVC_extend(_HostModel):
             mv_z = self._prior_encoder("mv_prior_encoder", mv_y)
             mv_z_hat = mv_z.like()
             ops.factorized_quant_bits(mv_z, W.bit_estimator("bit_estimator_z_mv"), S, 7, z_hat=mv_z_hat)
+            self._tap("el_mv_z", mv_z_hat)
             if sink:
                 sink.push(*ops.export_symbols(mv_z_hat, None), tb["el_z_mv"])
         else:
@@ -315,8 +345,9 @@ class LSSVC_extend(_HostModel):
         mv_scales, mv_means = ops.conv(W, q + ".4", t).chunk(2)
         if not decoding:
             mv_y_hat = mv_y.like()
-            mv_y_q = mv_y.like() if sink else None
+            mv_y_q = mv_y.like() if (sink or self.taps is not None) else None
             ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 5, y_q=mv_y_q, y_hat=mv_y_hat)
+            self._tap("el_mv_y", mv_y_q)
             if sink:
                 sink.push(*ops.export_symbols(mv_y_q, mv_scales, LAPLACE_IDX), tb["laplace"])
         else:
@@ -332,7 +363,18 @@ class LSSVC_extend(_HostModel):
         t = ops.conv(W, d + ".0", [t, mv_ctx], act="lrelu", slope=0.1)
         mv_hat = ops.subpel(W, d + ".2", t)
 
-        c1, c2, c3, warp_frame = self._el_context(bl["feature"], mv_hat, ref_el, feat_el)
+        if "ref_pyr" in pre:
+            fk.join(0)
+            ref_pyr = pre["ref_pyr"]
+        else:
+            ref_pyr = self._ref_pyramid(ref_el, feat_el)
+        fk.join(1)
+        c1, c2, c3, warp_frame = self._el_context(spat, mv_hat, ref_el, ref_pyr)
+
+        with fk.branch(1):        # temporal prior (LSSVC_net.py:75-79): context3 only, beside the encoder and the hyper codec
+            q = "temporal_prior_encoder"
+            t = ops.conv(W, q + ".0", c3, stride=2, act="lrelu", slope=0.1)
+            ops.conv(W, q + ".2", t, stride=2, out=fused.slice(128, 256))
 
         if not decoding:
             # ResEncoder without GDN (lssvc_modules.py:235-254); the concat feeding each ResBlock is built in place
@@ -349,6 +391,7 @@ class LSSVC_extend(_HostModel):
             z = self._prior_encoder("res_prior_encoder", y)
             z_hat = z.like()
             ops.factorized_quant_bits(z, W.bit_estimator("bit_estimator_z"), S, 6, z_hat=z_hat)
+            self._tap("el_z", z_hat)
             if sink:
                 sink.push(*ops.export_symbols(z_hat, None), tb["el_z"])
         else:
@@ -356,22 +399,20 @@ class LSSVC_extend(_HostModel):
             z_hat = self._pull_factorized(source, tb["el_z"], 128, zh, zw)
 
         # prior fusion input cat(hyper 128, temporal 128, layer 128) written in place (lssvc_modules.py:440-442)
-        fused = T.empty(H // 16, Wd // 16, 384, self.device)
         q = "res_prior_decoder"                                     # LSSVC_net.py:63-73
         t = ops.conv(W, q + ".0", z_hat, act="lrelu")
         t = ops.subpel(W, q + ".2", t, act="lrelu")
         t = ops.conv(W, q + ".4", t, act="lrelu")
         t = ops.subpel(W, q + ".6", t, act="lrelu")
         ops.conv(W, q + ".8", t, out=fused.slice(0, 128))
-        q = "temporal_prior_encoder"                                # LSSVC_net.py:75-79
-        t = ops.conv(W, q + ".0", c3, stride=2, act="lrelu", slope=0.1)
-        ops.conv(W, q + ".2", t, stride=2, out=fused.slice(128, 256))
-        self._layer_prior_resampler(bl["y_hat"], out=fused.slice(256, 384))
+        fk.join(1)
+        fk.join(2)
         params = B.depth_conv_block(W, "prior_fusion_net.prior_fusion_conv.1",
                                     B.depth_conv_block(W, "prior_fusion_net.prior_fusion_conv.0", fused))
         y_q, y_hat, scales_hat = self._four_part_prior(y, params, sink=sink, source=source)
         if not decoding:
             ops.laplace_bits(y_q, scales_hat, S, 4)
+            self._tap("el_y", y_q)
 
         # ResDecoder (lssvc_modules.py:257-276)
         p = "res_decoder"
@@ -395,8 +436,15 @@ class LSSVC_extend(_HostModel):
 
     # ---------------------------------------------------------------------------------------------
     def _frame_body(self, t):
-        bl = self._bl_codec(t["x_bl"], t["ref_frame_bl"], t["ref_feature_bl"])
-        feature, recon_el, mv_hat, warp_frame = self._el_codec(t["x_el"], bl, t["ref_frame_el"], t["ref_feature_el"])
+        fk = ops.Fork(self.device)
+        pre = {}
+        if fk.enabled:
+            with fk.branch(0):    # EL motion estimation + reference pyramid: inputs and DPB only, beside the whole BL codec
+                pre["mv"] = B.spynet(self.W, "optic_flow", t["x_el"], t["ref_frame_el"])
+                pre["ref_pyr"] = self._ref_pyramid(t["ref_frame_el"], t["ref_feature_el"])
+        bl = self._bl_codec(t["x_bl"], t["ref_frame_bl"], t["ref_feature_bl"], fk=fk)
+        feature, recon_el, mv_hat, warp_frame = self._el_codec(t["x_el"], bl, t["ref_frame_el"], t["ref_feature_el"], fk=fk, pre=pre)
+        fk.close()
         return {"recon_bl": bl["recon"], "feature_bl": bl["feature"], "recon_el": recon_el, "feature_el": feature,
                 "mv_hat": mv_hat, "warp_frame": warp_frame}
 
@@ -408,7 +456,7 @@ class LSSVC_extend(_HostModel):
                    "ref_feature_bl": ref_feature_bl, "ref_feature_el": ref_feature_el}
         t_issue = time.perf_counter()
         if self.graph_mode:
-            key = ("p",) + tuple(None if v is None else tuple(v.shape) for v in tensors.values()) + (ops.CONV_PRECISION,)
+            key = ("p",) + tuple(None if v is None else tuple(v.shape) for v in tensors.values())
             r = self._run_planned(key, tensors, self._frame_body)
         else:
             r = self._frame_body({k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()})

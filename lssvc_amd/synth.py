@@ -98,3 +98,37 @@ def synth_clip(frames, height, width, seed=0, motion=(0.7, -0.4), noise=0.004):
         fr = fr + noise * torch.randn(fr.shape, generator=g)
         out.append((fr.clamp(0, 1) * 255.0).round().to(torch.uint8))
     return torch.cat(out, 0)
+
+
+def synth_clip_exact(frames, height, width, seed=0, motion_q8=(6, -3)):
+    """Integer-only twin of synth_clip for the full-size golden fixtures: the same kind of picture (three octaves of
+    smooth value noise, a global sub-pixel translation per frame in 1/8-pixel units, +-1 LSB sensor noise), but every
+    step is exact int64 arithmetic on numpy's PCG64 integer stream, so the clip is bit-identical on any host and a
+    fixture only has to store its sha1. Returns uint8 (frames, 3, H, W) as a torch tensor."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    pad = 4 + (abs(motion_q8[0]) * frames + 7) // 8 + (abs(motion_q8[1]) * frames + 7) // 8
+    hh, ww = height + 2 * pad, width + 2 * pad
+    acc = np.zeros((3, hh, ww), dtype=np.int64)                     # texture in units of 1/(256*64) of full scale
+    for octave, amp in ((32, 150), (8, 75), (2, 25)):               # amplitudes sum to 250 < 256
+        gh, gw = hh // octave + 2, ww // octave + 2
+        coarse = rng.integers(0, 256, size=(3, gh, gw), dtype=np.int64)
+        ys, xs = np.arange(hh), np.arange(ww)
+        y0, fy = ys // octave, ys % octave
+        x0, fx = xs // octave, xs % octave
+        top = coarse[:, y0][:, :, x0] * (octave - fx) + coarse[:, y0][:, :, x0 + 1] * fx
+        bot = coarse[:, y0 + 1][:, :, x0] * (octave - fx) + coarse[:, y0 + 1][:, :, x0 + 1] * fx
+        v = top * (octave - fy)[None, :, None] + bot * fy[None, :, None]          # 0 .. 255 * octave^2
+        acc += (v * (amp * 64)) // (octave * octave)                              # 0 .. 255 * amp * 64
+    out = np.empty((frames, 3, height, width), dtype=np.uint8)
+    for t in range(frames):
+        ox, oy = pad * 8 + motion_q8[0] * t, pad * 8 + motion_q8[1] * t          # offsets in 1/8 pixel, >= 0
+        x0, fx, y0, fy = ox // 8, ox % 8, oy // 8, oy % 8
+        a = acc[:, y0:y0 + height + 1, x0:x0 + width + 1]
+        top = a[:, :-1, :-1] * (8 - fx) + a[:, :-1, 1:] * fx
+        bot = a[:, 1:, :-1] * (8 - fx) + a[:, 1:, 1:] * fx
+        v = top * (8 - fy) + bot * fy                                             # 0 .. 255 * 250 * 64 * 64
+        noise = rng.integers(-1, 2, size=v.shape, dtype=np.int64)
+        px = (v + (250 * 64 * 64) // 2) // (250 * 64 * 64) + noise + 3            # small pedestal keeps it off 0
+        out[t] = np.clip(px, 0, 255).astype(np.uint8)
+    return torch.from_numpy(out)

@@ -9,8 +9,23 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False,
+                     help="also run the CPU tests marked slow (full-size oracle-vs-reference fixtures: ~10 min on 8 cores)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of CPU work (the oracle at 1080p / 2160p); run with --runslow or LSSVC_SLOW=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--runslow") or os.environ.get("LSSVC_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow CPU test: pass --runslow (or LSSVC_SLOW=1)")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -41,3 +41,74 @@ def replay(case, i_frame, p_frame, device="cpu"):
         dpb["ref_frame_bl"].clamp_(0, 1)
         dpb["ref_frame_el"].clamp_(0, 1)
         yield t, r, raw, dpb, psnr(x_bl, dpb["ref_frame_bl"]), psnr(x_el, dpb["ref_frame_el"])
+
+
+# ---- full-size cases (tests/golden/make_golden_full.py): inputs are regenerated, not stored -------------------------
+FULL_CASES = ("x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_i")
+FULL_SAMPLE = {"x_hat_bl": (4, 1), "x_hat_el": (8, 1), "feature_el": (32, 4), "feature_bl": (16, 4), "mv_hat": (8, 1),
+               "warp_frame": (8, 1), "x_bl": (8, 1)}
+
+
+def full_sample(name, t):
+    s, c = FULL_SAMPLE[name]
+    return t[:, ::c, ::s, ::s]
+
+
+def load_full_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    frames, ph, pw, H, W, h, w, seed = (int(v) for v in z["meta"])
+    scale, gain = (float(v) for v in z["scale_gain"])
+    return z, dict(frames=frames, ph=ph, pw=pw, H=H, W=W, h=h, w=w, seed=seed, scale=scale, gain=gain)
+
+
+_FULL_INPUTS = {}
+
+
+def full_case_inputs(name):
+    if name not in _FULL_INPUTS:
+        _FULL_INPUTS.clear()                       # one case at a time: a 2160p clip is 100 MB of fp32 per frame
+        _FULL_INPUTS[name] = _full_case_inputs(name)
+    return _FULL_INPUTS[name]
+
+
+def _full_case_inputs(name):
+    """-> list of (x_bl, x_el) CPU tensors, rebuilt exactly as the generator built them: the integer-exact clip (its sha1
+    must match the fixture's), zero padding (test.py:192-197), the pinned bicubic restatement for the base layer
+    (test.py:199). Returns also whether every base-layer frame has the sha1 of what the reference was given; if a host's
+    CPU kernels round differently the frames still have to agree with the stored samples to 1e-6."""
+    import hashlib
+    from lssvc_amd.preprocess import interlayer_padding, imresize_bicubic
+    from lssvc_amd.synth import synth_clip_exact
+    z, m = load_full_case(name)
+    clip = synth_clip_exact(m["frames"], m["ph"], m["pw"], seed=m["seed"])
+    assert hashlib.sha1(clip.numpy().tobytes()).hexdigest() == str(z["clip_sha1"]), "synthetic clip differs from the generator's"
+    pad = interlayer_padding(m["ph"], m["pw"], m["scale"])
+    assert pad["HR_padded_size"] == (m["H"], m["W"]) and pad["LR_padded_size"] == (m["h"], m["w"])
+    out, exact = [], True
+    for t in range(m["frames"]):
+        x_el = torch.nn.functional.pad(clip[t:t + 1].float() / 255.0, pad["P_HR"], mode="constant", value=0)
+        x_bl = imresize_bicubic(x_el, (m["h"], m["w"])).clamp_(0, 1)
+        exact = exact and hashlib.sha1(x_bl.contiguous().numpy().tobytes()).hexdigest() == str(z["f%d_x_bl_sha1" % t])
+        np.testing.assert_allclose(full_sample("x_bl", x_bl).numpy(), z["f%d_x_bl" % t], atol=1e-6, rtol=0)
+        out.append((x_bl, x_el))
+    return out, exact
+
+
+def replay_full(name, i_frame, p_frame, device="cpu"):
+    """test.py's frame loop over a full-size case; yields (t, result, raw frames, dpb after the caller's clamp, psnrs)."""
+    z, m = load_full_case(name)
+    inputs, exact = full_case_inputs(name)
+    dpb = None
+    for t, (x_bl, x_el) in enumerate(inputs):
+        x_bl, x_el = x_bl.to(device), x_el.to(device)
+        if t == 0:
+            r = i_frame(x_bl, x_el, (m["H"], m["W"]))
+            dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None,
+                   "ref_feature_el": r["feature_el"]}
+        else:
+            r = p_frame(x_bl, x_el, dpb, (m["H"], m["W"]), m["scale"])
+            dpb = r["dpb"]
+        raw = {"x_hat_bl": dpb["ref_frame_bl"].clone(), "x_hat_el": dpb["ref_frame_el"].clone()}
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        yield t, r, raw, dpb, psnr(x_bl, dpb["ref_frame_bl"]), psnr(x_el, dpb["ref_frame_el"]), exact

@@ -114,3 +114,36 @@ def test_graph_mode_host_time_per_frame():
           (ei_issue * 1e3, gi_issue * 1e3, ei_wall * 1e3, gi_wall * 1e3))
     assert g_issue < 2e-3 and g_issue < 0.5 * e_issue, (e_issue, g_issue)
     assert g_wall <= 1.1 * e_wall, (e_wall, g_wall)
+
+
+@pytest.mark.parametrize("H,W,graph", [(128, 128, False), (128, 256, True), (384, 640, True)])
+def test_parallel_branches_are_bit_identical_to_single_stream(H, W, graph):
+    """Frame plans issue independent chains of a P-frame (EL SpyNet + reference pyramid || the BL codec; the BL-texture
+    pyramid and the layer prior || the EL motion-vector codec; the temporal priors || the encoders) on side streams
+    (hip_ops.Fork): same kernels, same per-chain order, so every bit count and every tensor must equal the single-stream
+    run -- eager and as captured hipGraph branches, over three GOPs so that buffers recycled across frames and replays of
+    the captured branches are covered. 384x640 is the smallest size that dispatches the persistent kernels."""
+    from lssvc_amd import hip_ops
+    from lssvc_amd.synth import synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic
+    frames, gops = 4, 3
+    clip = synth_clip(frames, H, W, seed=4).float() / 255.0
+    x_bl, x_el = imresize_bicubic(clip, (H // 2, W // 2)).clamp_(0, 1).to(DEV), clip.to(DEV)
+    old = hip_ops.MULTI_STREAM
+    try:
+        hip_ops.MULTI_STREAM = False
+        inet, pnet = _nets(3, 0.55)
+        want = _code(inet, pnet, x_bl, x_el, H, W, 1, frames)
+        hip_ops.MULTI_STREAM = True
+        inet, pnet = _nets(3, 0.55)
+        inet.set_graph_mode(graph)
+        pnet.set_graph_mode(graph)
+        got = _code(inet, pnet, x_bl, x_el, H, W, gops, frames)
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.MULTI_STREAM = old
+    for i, (bb, be, tens) in enumerate(got):
+        wb, we, wt = want[i % frames]
+        assert (bb, be) == (wb, we), (i, bb, wb, be, we)
+        for a, b in zip(tens, wt):
+            assert (a is None and b is None) or torch.equal(a, b), i

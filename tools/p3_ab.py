@@ -1,6 +1,6 @@
-"""A/B of the two persistent 3x3 kernels (deferred epilogue / epilogue at the tile boundary) (and the tiled one) on the benchmark's dominant shapes, interleaved rounds in ONE
+"""A/B of the persistent 3x3 kernel against the tiled one on the benchmark's dominant shapes, interleaved rounds in ONE
 process (cdna_hip_programming.md rule 24), random data:  python tools/p3_ab.py [rounds] [reps]
-Also checks that the three kernels agree bit for bit on every shape."""
+Also checks that the two kernels agree bit for bit on every shape."""
 import ctypes as C
 import math
 import os
@@ -28,7 +28,7 @@ SHAPES = [
     ("96->96 @288x480", [96], 96, 288, 480, None, None, False, False),
     ("192->256 @288x480 subpel", [192], 256, 288, 480, None, None, False, True),
 ]
-MODES = [("deferred", 1, 1), ("prodcons", 1, 0), ("tiled", 0, 0)]
+MODES = [("prodcons", 1), ("tiled", 0)]
 
 
 def setopt(name, v):
@@ -58,16 +58,14 @@ def main():
             return ops.subpel(Wt, "s", xs, out=out, **kw) if subpel else ops.conv(Wt, "c", xs, out=out, **kw)
 
         outs, times = {}, {m[0]: [] for m in MODES}
-        for mname, on, pp in MODES:
+        for mname, on in MODES:
             setopt("f16x3_persist", on)
-            setopt("f16x3_deferred", pp)
             outs[mname] = run()
             torch.cuda.synchronize()
-        same = all(torch.equal(outs["tiled"].buf, outs[m].buf) for m in ("deferred", "prodcons"))
+        same = torch.equal(outs["tiled"].buf, outs["prodcons"].buf)
         for _ in range(rounds):
-            for mname, on, pp in MODES:
+            for mname, on in MODES:
                 setopt("f16x3_persist", on)
-                setopt("f16x3_deferred", pp)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
@@ -77,12 +75,11 @@ def main():
                 times[mname].append(e0.elapsed_time(e1) / reps)
         flops = 2.0 * H * W * cout * 9 * cin
         line = "%-32s" % name
-        for mname, _, _ in MODES:
+        for mname, _ in MODES:
             t = sorted(times[mname])
             line += "  %s %7.1f us %6.1f TF" % (mname, t[len(t) // 2] * 1e3, flops / t[len(t) // 2] * 1e-9)
         print(line + ("  bit-identical" if same else "  *** MISMATCH ***"), flush=True)
     setopt("f16x3_persist", 1)
-    setopt("f16x3_deferred", 0)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,6 @@ def main():
         check(lib.lssvc_set_option(b"f16x3_persist", 0))
         ref = ops.conv(Wt, "c", x, in_act="lrelu", in_slope=0.1, act="lrelu", slope=0.01).buf.clone()
         check(lib.lssvc_set_option(b"f16x3_persist", 1))
-        check(lib.lssvc_set_option(b"f16x3_deferred", 0))
         bad = 0
         for i in range(n):
             out = ops.conv(Wt, "c", x, in_act="lrelu", in_slope=0.1, act="lrelu", slope=0.01)
