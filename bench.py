@@ -160,6 +160,12 @@ def roofline_from_log(op_log):
         peak = PEAK_FP16_MFMA_TFLOPS / 3.0 if "f16x3" in dom["kernel"] else PEAK_FP32_MFMA_TFLOPS
         roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(dom["tflops"] / peak, 4)}
+        if "f16x3" in dom["kernel"]:
+            # the same measurement priced both ways against the RAW dense fp16 peak (2.5 PFLOP/s), so that nobody reads
+            # `frac` as useful work over 2.5 PF: MFMA flops ISSUED (3 per algorithmic flop) and ALGORITHMIC flops
+            roof["peak_note"] = "peak = 2500 / 3: the f16x3 kernels issue 3 fp16-MFMA flops per algorithmic flop"
+            roof["frac_issued_fp16"] = round(3.0 * dom["tflops"] / PEAK_FP16_MFMA_TFLOPS, 4)
+            roof["frac_algorithmic_fp16"] = round(dom["tflops"] / PEAK_FP16_MFMA_TFLOPS, 4)
     roof.update(common)
     for r in table:
         r.pop("ks")
@@ -210,15 +216,16 @@ def pmc_mfma_busy(kernel):
     return None
 
 
-def _oracle_frames(H, W, threads):
-    """Seconds the CPU oracle takes for one I-frame and one (first) P-frame at EL HxW / BL (H/2)x(W/2)."""
+def _oracle_frames(H, W, threads, n_p=1):
+    """Seconds the CPU oracle takes for one I-frame and the first n_p P-frames (the second is a steady-state P-frame: it
+    runs the 48-channel feature adaptors) at EL HxW / BL (H/2)x(W/2): (t_i, t_p of the LAST P-frame timed, [all t_p])."""
     from lssvc_oracle.intra import intra_forward
     from lssvc_oracle.inter import inter_forward
     from lssvc_amd.synth import synth_state_dict, synth_clip
     from lssvc_amd.preprocess import imresize_bicubic
     torch.set_num_threads(threads)
     sd_i, sd_p = synth_state_dict("intra_ss", 0, GAIN), synth_state_dict("lssvc_extend", 0, GAIN)
-    clip = synth_clip(2, H, W, seed=0).float() / 255.0
+    clip = synth_clip(1 + n_p, H, W, seed=0).float() / 255.0
     x_bl = imresize_bicubic(clip, (H // 2, W // 2)).clamp_(0, 1)
     with torch.no_grad():
         t0 = time.time()
@@ -227,10 +234,16 @@ def _oracle_frames(H, W, threads):
         dpb = {"ref_frame_bl": o["x_hat_bl"].clamp_(0, 1), "ref_frame_el": o["x_hat_el"].clamp_(0, 1),
                "ref_feature_bl": None, "ref_feature_el": o["feature_el"]}
         del o
-        t0 = time.time()
-        inter_forward(sd_p, x_bl[1:2], clip[1:2], dpb, (H, W), RATIO)
-        t_p = time.time() - t0
-    return t_i, t_p
+        t_ps = []
+        for t in range(1, 1 + n_p):
+            t0 = time.time()
+            r = inter_forward(sd_p, x_bl[t:t + 1], clip[t:t + 1], dpb, (H, W), RATIO)
+            t_ps.append(time.time() - t0)
+            dpb = r["dpb"]
+            dpb["ref_frame_bl"].clamp_(0, 1)
+            dpb["ref_frame_el"].clamp_(0, 1)
+            del r
+    return t_i, t_ps[-1], t_ps
 
 
 def config0_latency(device, graph=True, reps=30):
@@ -264,6 +277,137 @@ def config0_latency(device, graph=True, reps=30):
             "launch": "hipGraph frame plan" if graph else "eager", "reps": reps}
 
 
+def _cached_cpu_baseline():
+    """The full-size run (1 I + 2 P at 1152x1920, `python bench.py --cpu-baseline-full`, several minutes of CPU work) is made
+    once per round on a GPU box and kept under profiles/ with the host description; the default run quotes it beside its
+    own bounded sample."""
+    path = _latest_profile("cpu_baseline_full.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        d["source"] = os.path.relpath(path, ROOT)
+        return d
+    except (OSError, ValueError, TypeError):
+        return None
+
+
+def config4_stream(device, frames=8):
+    """BASELINE configs[4] at configs[1]'s size: write_stream=1 on 1 I + (frames - 1) P frames at 1152x1920 / 576x960, real
+    rANS strings written to and read back from files, exactly what the reference times as `encoding_time` /
+    `decoding_time` per P-frame (LSSVC_net_extend.py:158-171, dmc_net_extend.py:150-163; its published 1.441 s / 1.348 s,
+    json_results/LSSVC/IP32/x2_FL.json, are on unstated hardware). Pass 1 gives those two numbers undisturbed; pass 2
+    repeats the clip with the profiler on (it drains the device before every copy, so its total is larger) and splits a
+    P-frame into GPU work waited for, D2H / H2D of the int16 planes, host rANS, file I/O."""
+    import shutil
+    import tempfile
+    from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
+    from lssvc_amd.synth import synth_state_dict
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, GAIN)).to(device).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", 0, GAIN))
+    pnet.to(device).eval()
+    t0 = time.time()
+    inet.update(force=True)
+    pnet.update(force=True)
+    t_update = time.time() - t0
+    x_bls, x_els, pad, _ = build_inputs(device, seed=3, frames=frames)
+    shape_hr = pad["HR_padded_size"]
+    tmp = tempfile.mkdtemp(prefix="lssvc_bench_")
+
+    def run():
+        rows, dpb = [], None
+        for t in range(frames):
+            inet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
+            pnet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
+            pb, pe = os.path.join(tmp, "bl_%d.bin" % t), os.path.join(tmp, "el_%d.bin" % t)
+            if t == 0:
+                r = inet.encode_decode(x_bls[t], x_els[t], pb, pe, shape_hr[0] // 2, shape_hr[1] // 2, shape_hr[0], shape_hr[1])
+                dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+            else:
+                r = pnet.encode_decode(x_bls[t], x_els[t], dpb, pb, pe)
+                dpb = r["dpb"]
+                rows.append(r)
+            dpb["ref_frame_bl"].clamp_(0, 1)
+            dpb["ref_frame_el"].clamp_(0, 1)
+        return rows
+
+    try:
+        with torch.no_grad():
+            run()                                       # warm-up: weight layouts, LDS grants, allocator
+            rows = run()
+            n = len(rows)
+            enc = sum(r["encoding_time_BL"] + r["encoding_time_EL"] for r in rows) / n
+            dec = sum(r["decoding_time_BL"] + r["decoding_time_EL"] for r in rows) / n
+            bits = sum(r["bit_bl"] + r["bit_el"] for r in rows) / n
+            est = sum(r["bit_bl_estimate"] + r["bit_el_estimate"] for r in rows) / n
+            prof = hip_ops.STREAM_PROF = {}
+            try:
+                rows2 = run()
+            finally:
+                hip_ops.STREAM_PROF = None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    n_all = frames                                       # the profiled pass includes the I-frame's (smaller) share
+    enc2 = sum(r["encoding_time_BL"] + r["encoding_time_EL"] for r in rows2) / n
+    dec2 = sum(r["decoding_time_BL"] + r["decoding_time_EL"] for r in rows2) / n
+    per = lambda k: round(1e3 * prof.get(k, 0.0) / n_all, 2)
+    return {"workload": "configs[4] at configs[1]'s size: write_stream=1, 1 I + %d P at EL 1152x1920 / BL 576x960, real rANS files" % (frames - 1),
+            "encoding_time_s_per_p_frame": round(enc, 4), "decoding_time_s_per_p_frame": round(dec, 4),
+            "reference_published": {"encoding_time": 1.441, "decoding_time": 1.348, "hardware": "unstated CUDA GPU",
+                                    "source": "json_results/LSSVC/IP32/x2_FL.json (HEVC_B mean)"},
+            "stream_bits_per_p_frame": round(bits, 1), "estimated_bits_per_p_frame": round(est, 1),
+            "profiled_pass_ms_per_frame": {"gpu_work_waited_for": per("gpu_wait_s"), "d2h_int16_planes": per("d2h_s"),
+                                           "h2d_int16_planes": per("h2d_s"), "host_rans_encode": per("rans_enc_s"),
+                                           "host_rans_decode": per("rans_dec_s"), "file_io": per("io_s"),
+                                           "encode_plus_decode_wall_p_frame": round(1e3 * (enc2 + dec2), 2)},
+            "d2h_mb_per_frame": round(1e-6 * prof.get("d2h_bytes", 0) / n_all, 2), "h2d_mb_per_frame": round(1e-6 * prof.get("h2d_bytes", 0) / n_all, 2),
+            "host_rans_msymbols_per_s": {"encode": round(1e-6 * prof.get("enc_symbols", 0) / max(prof.get("rans_enc_s", 0.0), 1e-9), 1),
+                                         "decode": round(1e-6 * prof.get("dec_symbols", 0) / max(prof.get("rans_dec_s", 0.0), 1e-9), 1)},
+            "symbols_per_frame": int(prof.get("enc_symbols", 0) / n_all), "cdf_table_build_s": round(t_update, 2)}
+
+
+def config3_2160p(device, gop=12):
+    """BASELINE configs[3]: EL 2176x3840 (2160p padded) / BL 1088x1920, IP12 (1 I + 11 P), estimate mode, the f16x3 conv path:
+    frames/s of one GOP through hipGraph frame plans (one warm-up GOP captures them) and the dominant kernel's roofline
+    fraction from per-launch HIP events on P-frames 1..4 of an eager pass."""
+    global HEIGHT, WIDTH, EVENT_FRAMES
+    from lssvc_amd import IntraSS, LSSVC_extend
+    from lssvc_amd.synth import synth_state_dict
+    keep = (HEIGHT, WIDTH, EVENT_FRAMES)
+    HEIGHT, WIDTH, EVENT_FRAMES = 2160, 3840, 4
+    try:
+        inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, GAIN)).to(device).eval()
+        pnet = LSSVC_extend()
+        pnet.load_dict(synth_state_dict("lssvc_extend", 0, GAIN))
+        pnet.to(device).eval()
+        inet.set_graph_mode(True)
+        pnet.set_graph_mode(True)
+        x_bls, x_els, pad, _ = build_inputs(device, seed=5, frames=gop)
+        shape_hr = pad["HR_padded_size"]
+        with torch.no_grad():
+            encode_gop(inet, pnet, x_bls, x_els, shape_hr)                  # eager calls + captures
+            torch.cuda.synchronize()
+            t0 = time.time()
+            bits, _ = encode_gop(inet, pnet, x_bls, x_els, shape_hr)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            op_log = []
+            encode_gop(inet, pnet, x_bls[:1 + EVENT_FRAMES], x_els[:1 + EVENT_FRAMES], shape_hr, op_log)
+            torch.cuda.synchronize()
+        roof, _ = roofline_from_log(op_log)
+        for k in ("traffic", "mfma_busy"):
+            roof.pop(k, None)                                                # the committed PMC passes are of the 1080p run
+        inet.set_graph_mode(False)
+        pnet.set_graph_mode(False)
+        return {"workload": "configs[3]: LSSVC two-layer x2, EL %dx%d (2160p padded) / BL %dx%d, IP%d, write_stream=0" % (
+                    shape_hr[0], shape_hr[1], shape_hr[0] // 2, shape_hr[1] // 2, gop),
+                "value": round(gop / dt, 3), "unit": "frames/s", "ms_per_gop": round(1e3 * dt, 1),
+                "p_frame_bpp_el_mean": round(sum(b[1] for b in bits[1:]) / (len(bits) - 1) / (HEIGHT * WIDTH), 5), "roofline": roof}
+    finally:
+        HEIGHT, WIDTH, EVENT_FRAMES = keep
+        torch.cuda.empty_cache()
+
+
 def cpu_baseline(full_size=False):
     """The CPU oracle (a port of the reference's PyTorch CPU path, pinned bit-exact to it on the golden fixtures) timed on
     this box's host cores on a BOUNDED sample: (i) all cores the process may use, 1 I + 1 P frame
@@ -281,18 +425,20 @@ def cpu_baseline(full_size=False):
     #                                        oversubscribe the share and run an order of magnitude slower (measured)
     H, W = (1152, 1920) if full_size else (384, 640)
     log("  cpu baseline: %d threads (os.cpu_count() = %s), 1 I + 1 P at EL %dx%d ..." % (cores, os.cpu_count(), H, W))
-    t_i, t_p = _oracle_frames(H, W, cores)
+    t_i, t_p, t_ps = _oracle_frames(H, W, cores, n_p=2 if full_size else 1)
     scale = (H * W) / (1152.0 * 1920.0)
     fps = GOP / (t_i + (GOP - 1) * t_p) * scale
     h1, w1 = 256, 384                     # smallest sample whose BL (128x192) is still a multiple of 64
     log("  cpu baseline: I %.2f s, P %.2f s; now 1 thread at EL %dx%d ..." % (t_i, t_p, h1, w1))
-    s_i, s_p = _oracle_frames(h1, w1, 1)
+    s_i, s_p, _ = _oracle_frames(h1, w1, 1)
     fps1 = GOP / (s_i + (GOP - 1) * s_p) * (h1 * w1) / (1152.0 * 1920.0)
     torch.set_num_threads(cores)
     size = "the full EL 1152x1920 / BL 576x960 size, no scaling" if full_size else \
         "EL 384x640 / BL 192x320 (1/9 of the pixels), scaled by 1/9"
-    return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "1 I-frame (%.2f s) + 1 P-frame (%.2f s) at %s, GOP-32 mix (1 I + 31 P); %d threads "
+    full = _cached_cpu_baseline()
+    return {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port", "full_size_measured_once": full,
+            "p_frame_seconds": [round(t, 2) for t in t_ps],
+            "sample": "1 I-frame (%.2f s) + 1 P-frame (%.2f s; with --cpu-baseline-full the steady-state second P-frame) at %s, GOP-32 mix (1 I + 31 P); %d threads "
                       "(os.cpu_count() = %s, affinity = %d, capped at the 16-core share of a 1-GPU box); torch %s CPU fp32" % (t_i, t_p, size, cores, os.cpu_count(), usable,
                                                                                 torch.__version__),
             "single_thread": {"value": round(fps1, 6), "unit": "frames/s", "cores": 1,
@@ -311,10 +457,27 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying hipGraph frame plans")
     ap.add_argument("--no-streams", action="store_true", help="one stream: no parallel branches in the frame plans (same as LSSVC_STREAMS=0)")
     ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop (per-frame H2D + pre-processing included)")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline at the full 1152x1920 size (takes > 7 min on a 16-core host share)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline at the full 1152x1920 size, 1 I + 2 P (takes > 7 min on a 16-core host share)")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the configs[3] (2160p IP12) and configs[4] (write_stream=1) side measurements")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
                     help="conv arithmetic (default: lssvc_amd's default, see hip_ops.CONV_PRECISION)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU oracle at full size (1 I + 2 P at 1152x1920) on this host, "
+                    "print its JSON with the host description and exit: the once-per-round run kept as profiles/rNN_cpu_baseline_full.json")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        import platform
+        d = cpu_baseline(full_size=True)
+        d.pop("full_size_measured_once", None)
+        cpu = ""
+        try:
+            with open("/proc/cpuinfo") as f:
+                cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+        except OSError:
+            pass
+        d["host"] = {"cpu": cpu, "os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "platform": platform.platform(),
+                     "torch": torch.__version__}
+        print(json.dumps(d), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -333,10 +496,18 @@ def main():
     if args.no_streams:
         hip_ops.MULTI_STREAM = False
     from lssvc_amd.synth import synth_state_dict
-    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, GAIN)).to(device).eval()
+    from lssvc_amd.shard import broadcast_state_dicts
+    # the deployment path (harness under torchrun): rank 0 alone has the checkpoints and broadcasts them over RCCL, ~245 MB
+    # once; with one rank this is a plain local load
+    t0 = time.time()
+    sds = broadcast_state_dicts(["intra_ss", "lssvc_extend"], dist, device, loader=lambda name: synth_state_dict(name, 0, GAIN))
+    if rank == 0 and world > 1:
+        log("checkpoints broadcast from rank 0 over RCCL in %.2f s" % (time.time() - t0))
+    inet = IntraSS.from_state_dict(sds["intra_ss"]).to(device).eval()
     pnet = LSSVC_extend()
-    pnet.load_dict(synth_state_dict("lssvc_extend", 0, GAIN))
+    pnet.load_dict(sds["lssvc_extend"])
     pnet.to(device).eval()
+    del sds
 
     if not args.no_graph:
         inet.set_graph_mode(True)                  # FramePlan: the per-frame launch sequence replayed as a hipGraph
@@ -402,7 +573,8 @@ def main():
                                    "%d-frame GOP per GPU per step, write_stream=0; inputs resident in HBM for `value`, "
                                    "per-frame H2D + pre-processing included in `h2d_inclusive`" % args.frames,
                        "frames_per_step_per_gpu": args.frames, "weights": "seeded synthetic (lssvc_amd.synth, gain %.2f)" % GAIN,
-                       "parallelism": "gop-shard x%d (no data-path collective)" % world,
+                       "parallelism": "gop-shard x%d (no data-path collective; weights broadcast once from rank 0 over RCCL)" % world if world > 1
+                       else "gop-shard x1",
                        "launch": ("eager (ctypes per kernel)" if args.no_graph else "hipGraph frame plans (I / first-P / steady-P)")
                                  + (", independent chains of a frame as parallel branches (side streams)" if hip_ops.MULTI_STREAM else ", single stream")},
         }
@@ -428,6 +600,17 @@ def main():
                 out["config0_latency"] = config0_latency(device, graph=not args.no_graph)
             except Exception as e:                          # a side measurement must not take the headline line down
                 out["config0_latency"] = {"error": repr(e)}
+        if world == 1 and not args.no_side_configs:
+            del x_bls, x_els
+            inet.set_graph_mode(False)                      # drop the 1080p frame plans and their graph pools first
+            pnet.set_graph_mode(False)
+            torch.cuda.empty_cache()
+            for name, fn in (("config4_stream", config4_stream), ("config3_2160p", config3_2160p)):
+                try:
+                    log("side measurement %s ..." % name)
+                    out[name] = fn(device)
+                except Exception as e:
+                    out[name] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on a bounded sample ...")
             out["cpu_baseline"] = cpu_baseline(full_size=args.cpu_baseline_full)

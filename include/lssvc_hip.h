@@ -167,6 +167,12 @@ int lssvc_add(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, v
 int lssvc_copy(const lssvc_view *in, const lssvc_view *out, void *stream);
 /* out = lrelu(in, slope) (the stand-alone nn.LeakyReLU between blocks, e.g. dmc_net.py:178). */
 int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float slope, void *stream);
+/* Range audit of the f16x3 conv mode: *out_max = max(*out_max, max |x| over the view) as a non-negative float (NaN / Inf
+ * give +Inf); the caller zeroes it. The f16x3 kernels split activations into fp16 hi/lo parts and saturate at +-65504 while
+ * staging (GDN squares first), which the reference's fp32 convs (e.g. src/IntraModules/gdn.py:29-44) do not: the host runs
+ * this on every f16x3 conv input of the first frame of each type and moves layers that come near the limit to the exact
+ * fp32 kernel (lssvc_amd/hip_ops.py RangeAudit). */
+int lssvc_absmax(const lssvc_view *x, float *out_max, void *stream);
 
 /* OffsetDiversity tail (lssvc_modules.py:96-110): from the up-sampled conv_offset output `om`
  * (H x W x 96: o1[32] | o2[32] | mask[32]) and flow (H x W x 2): 32 warps of 3-channel groups of x
@@ -237,6 +243,15 @@ int lssvc_export_symbols(const lssvc_view *q, const lssvc_view *sigma, const int
  * channel chunk of each 2x2 position is written (LSSVC_net_extend.py:208-213). sym_nchw is a device pointer. */
 int lssvc_import_symbols(const int32_t *sym_nchw, const lssvc_view *mean, const float *channel_add,
                          const int32_t *chunk_of_mask, const lssvc_view *out, void *stream);
+/* The same two with 16-bit planes (what replaces the reference's `.tolist()` of ~2.3 M symbols per
+ * P-frame, video_entropy_models.py:234-236,317-319, is an int16 plane in pinned memory): half the PCIe bytes of the
+ * int32 form. A symbol outside [-32768, 32767] sets *overflow (device int32, zeroed by the caller) so that the host can
+ * refuse the plane instead of coding a truncated value. */
+int lssvc_export_symbols_i16(const lssvc_view *q, const lssvc_view *sigma, const int32_t *chunk_of_mask, float log_min,
+                             float log_step, float add, int32_t levels, int16_t *sym_nchw, int16_t *idx_nchw, int32_t *overflow,
+                             void *stream);
+int lssvc_import_symbols_i16(const int16_t *sym_nchw, const lssvc_view *mean, const float *channel_add,
+                             const int32_t *chunk_of_mask, const lssvc_view *out, void *stream);
 
 /* sigma -> CDF-table index planes for the host coder (video_entropy_models.py:309-313,
  * img_entropy_models.py:687-691): idx = clamp((ln max(s,1e-5) - ln smin)/step + add, 0, levels-1). */
@@ -286,6 +301,8 @@ void lssvc_rans_encoder_reset(void *enc);
 /* append n symbols to the pending list (BufferedRansEncoder.encode_with_indexes) */
 int lssvc_rans_encode_with_indexes(void *enc, const int32_t *symbols, const int32_t *indexes, int64_t n,
                                    const lssvc_cdf_table *table);
+int lssvc_rans_encode_with_indexes_i16(void *enc, const int16_t *symbols, const int16_t *indexes, int64_t n,
+                                       const lssvc_cdf_table *table);
 /* entropy-code everything pending; returns the stream length in bytes, lssvc_rans_encoder_bytes() its data */
 int64_t lssvc_rans_encoder_flush(void *enc);
 const uint8_t *lssvc_rans_encoder_bytes(void *enc);
@@ -295,6 +312,8 @@ void lssvc_rans_decoder_free(void *dec);
 int lssvc_rans_decoder_set_stream(void *dec, const uint8_t *bytes, int64_t n);
 /* decode n symbols; the cursor persists across calls (RansDecoder.decode_stream) */
 int lssvc_rans_decode_stream(void *dec, const int32_t *indexes, int64_t n, const lssvc_cdf_table *table, int32_t *out);
+/* 16-bit planes: same streams; a decoded symbol outside [-32768, 32767] is an error */
+int lssvc_rans_decode_stream_i16(void *dec, const int16_t *indexes, int64_t n, const lssvc_cdf_table *table, int16_t *out);
 
 /* cdf_out has n + 1 entries */
 int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, uint32_t *cdf_out);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "lssvc_add": (C.c_int, [VP, VP, VP, C.c_void_p]),
     "lssvc_copy": (C.c_int, [VP, VP, C.c_void_p]),
     "lssvc_lrelu": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
+    "lssvc_absmax": (C.c_int, [VP, C.c_void_p, C.c_void_p]),
     "lssvc_offset_diversity": (C.c_int, [VP, VP, VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
     "lssvc_nchw_to_nhwc": (C.c_int, [C.c_void_p, VP, C.c_void_p]),
     "lssvc_nhwc_to_nchw": (C.c_int, [VP, C.c_void_p, C.c_void_p]),
@@ -87,6 +88,8 @@ SIGNATURES = {
     "lssvc_entropy_bottleneck": (C.c_int, [VP, C.c_void_p, VP, VP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_export_symbols": (C.c_int, [VP, VP, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_import_symbols": (C.c_int, [C.c_void_p, VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
+    "lssvc_export_symbols_i16": (C.c_int, [VP, VP, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_import_symbols_i16": (C.c_int, [C.c_void_p, VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
     "lssvc_build_indexes": (C.c_int, [VP, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "lssvc_yuv420_to_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, VP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_rgb8_to_frame": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, VP, C.c_void_p]),
@@ -98,12 +101,14 @@ SIGNATURES = {
     "lssvc_rans_encoder_free": (None, [C.c_void_p]),
     "lssvc_rans_encoder_reset": (None, [C.c_void_p]),
     "lssvc_rans_encode_with_indexes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, TP]),
+    "lssvc_rans_encode_with_indexes_i16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, TP]),
     "lssvc_rans_encoder_flush": (C.c_int64, [C.c_void_p]),
     "lssvc_rans_encoder_bytes": (C.c_void_p, [C.c_void_p]),
     "lssvc_rans_decoder_new": (C.c_void_p, []),
     "lssvc_rans_decoder_free": (None, [C.c_void_p]),
     "lssvc_rans_decoder_set_stream": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "lssvc_rans_decode_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, TP, C.c_void_p]),
+    "lssvc_rans_decode_stream_i16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, TP, C.c_void_p]),
     "lssvc_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lssvc_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
     "lssvc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),

@@ -105,9 +105,17 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     };
     // (the caller has waited, with explicit s_waitcnt, for exactly the LDS / DMA traffic the slot stands for; a RELEASE store
     // would make the compiler wait for vmcnt(0), i.e. also for the producers' prefetched loads of the phase after next)
+    // Under the HIP memory model the relaxed store is formally a race against the plain LDS writes it publishes; the
+    // ordering is carried by the s_waitcnt in front of every call. `make P3_RELEASE_SIGNAL=1` builds the same kernel with a
+    // RELEASE store instead (slower, ordering by the compiler): if a toolchain change ever breaks the bit-identity tests
+    // (tests/test_gpu_bench_kernels.py: hand_off_is_race_free), that build tells a broken hand-off from anything else.
     auto signal = [&](int *slot, int value) {
         asm volatile("" ::: "memory");
+#ifdef LSSVC_P3_RELEASE_SIGNAL
+        if (lane == 0) __hip_atomic_store(slot, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
         if (lane == 0) __hip_atomic_store(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     };
 
     auto tile_origin = [&](int it, int &oy0, int &ox0, int &m0) {

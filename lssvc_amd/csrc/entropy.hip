@@ -224,8 +224,11 @@ __global__ void build_indexes_kernel(V sigma, float log_min, float log_step, flo
 
 // chunk_of_mask < 0: plain export of a C-channel tensor. Otherwise the 4-step fold (LSSVC_net.py:432-442):
 // out channel j at 2x2 position m takes channel chunk_of_mask[m]*C4 + j of the C-channel inputs.
+// PlaneT = int32_t (the reference's width) or int16_t (half the PCIe bytes; a symbol that does not fit sets *overflow, which
+// the host checks before it codes the plane -- real latents are a few tens at most).
+template <typename PlaneT>
 __global__ void export_symbols_kernel(V q, V sigma, int cm0, int cm1, int cm2, int cm3, float log_min, float log_step, float add,
-                                      int levels, int32_t *sym, int32_t *idx, int C_out, int H, int W, long long total) {
+                                      int levels, PlaneT *sym, PlaneT *idx, int32_t *overflow, int C_out, int H, int W, long long total) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int j = (int)(t % C_out);
@@ -237,13 +240,20 @@ __global__ void export_symbols_kernel(V q, V sigma, int cm0, int cm1, int cm2, i
         c = (m == 0 ? cm0 : (m == 1 ? cm1 : (m == 2 ? cm2 : cm3))) * C_out + j;
     }
     const size_t o = (size_t)j * H * W + pix;
-    if (sym) sym[o] = (int32_t)q.p[(size_t)pix * q.ld + c];
-    if (idx) idx[o] = sigma.p ? sigma_index(sigma.p[(size_t)pix * sigma.ld + c], log_min, log_step, add, levels) : j;
+    if (sym) {
+        const int32_t s = (int32_t)q.p[(size_t)pix * q.ld + c];
+        if constexpr (sizeof(PlaneT) == 2) {
+            if (s < -32768 || s > 32767) atomicOr(overflow, 1);
+        }
+        sym[o] = (PlaneT)s;
+    }
+    if (idx) idx[o] = (PlaneT)(sigma.p ? sigma_index(sigma.p[(size_t)pix * sigma.ld + c], log_min, log_step, add, levels) : j);
 }
 
 // out[pix][c] = sym + mean + add[c]; with chunk_of_mask >= 0 the 4-step unfold (LSSVC_net_extend.py:208-213):
 // only channel chunk_of_mask[m]*C4 + j at position m is written.
-__global__ void import_symbols_kernel(const int32_t *__restrict__ sym, V mean, const float *__restrict__ add, int cm0, int cm1,
+template <typename PlaneT>
+__global__ void import_symbols_kernel(const PlaneT *__restrict__ sym, V mean, const float *__restrict__ add, int cm0, int cm1,
                                       int cm2, int cm3, V out, int C_in, int H, int W, long long total) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -373,8 +383,10 @@ static int chunk_masks_ok(const int32_t *cm) {
     return seen == 15;
 }
 
-extern "C" int lssvc_export_symbols(const lssvc_view *q, const lssvc_view *sigma, const int32_t *chunk_of_mask, float log_min,
-                                    float log_step, float add, int32_t levels, int32_t *sym_nchw, int32_t *idx_nchw, void *stream) {
+template <typename PlaneT>
+static int export_symbols_impl(const lssvc_view *q, const lssvc_view *sigma, const int32_t *chunk_of_mask, float log_min,
+                               float log_step, float add, int32_t levels, PlaneT *sym_nchw, PlaneT *idx_nchw, int32_t *overflow,
+                               void *stream) {
     const lssvc_view *ref = (q && q->ptr) ? q : sigma;
     LSSVC_CHECK(view_ok(ref) && (sym_nchw || idx_nchw), "export_symbols: bad arguments");
     LSSVC_CHECK(!sym_nchw || view_ok(q), "export_symbols: symbols requested without q");
@@ -385,14 +397,28 @@ extern "C" int lssvc_export_symbols(const lssvc_view *q, const lssvc_view *sigma
     const long long total = (long long)ref->H * ref->W * C_out;
     const int32_t none[4] = {-1, -1, -1, -1};
     const int32_t *cm = chunk_of_mask ? chunk_of_mask : none;
-    hipLaunchKernelGGL(export_symbols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, opt(q),
-                       opt(sigma), cm[0], cm[1], cm[2], cm[3], log_min, log_step, add, levels, sym_nchw, idx_nchw, C_out, ref->H,
-                       ref->W, total);
+    hipLaunchKernelGGL(export_symbols_kernel<PlaneT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, opt(q),
+                       opt(sigma), cm[0], cm[1], cm[2], cm[3], log_min, log_step, add, levels, sym_nchw, idx_nchw, overflow, C_out,
+                       ref->H, ref->W, total);
     return launch_status("export_symbols");
 }
 
-extern "C" int lssvc_import_symbols(const int32_t *sym_nchw, const lssvc_view *mean, const float *channel_add,
-                                    const int32_t *chunk_of_mask, const lssvc_view *out, void *stream) {
+extern "C" int lssvc_export_symbols(const lssvc_view *q, const lssvc_view *sigma, const int32_t *chunk_of_mask, float log_min,
+                                    float log_step, float add, int32_t levels, int32_t *sym_nchw, int32_t *idx_nchw, void *stream) {
+    return export_symbols_impl<int32_t>(q, sigma, chunk_of_mask, log_min, log_step, add, levels, sym_nchw, idx_nchw, nullptr, stream);
+}
+
+extern "C" int lssvc_export_symbols_i16(const lssvc_view *q, const lssvc_view *sigma, const int32_t *chunk_of_mask, float log_min,
+                                        float log_step, float add, int32_t levels, int16_t *sym_nchw, int16_t *idx_nchw,
+                                        int32_t *overflow, void *stream) {
+    LSSVC_CHECK(overflow || !sym_nchw, "export_symbols_i16: symbols requested without an overflow flag");
+    LSSVC_CHECK(levels <= 32768, "export_symbols_i16: %d table levels do not fit 16 bits", levels);
+    return export_symbols_impl<int16_t>(q, sigma, chunk_of_mask, log_min, log_step, add, levels, sym_nchw, idx_nchw, overflow, stream);
+}
+
+template <typename PlaneT>
+static int import_symbols_impl(const PlaneT *sym_nchw, const lssvc_view *mean, const float *channel_add,
+                               const int32_t *chunk_of_mask, const lssvc_view *out, void *stream) {
     LSSVC_CHECK(sym_nchw && view_ok(out), "import_symbols: bad arguments");
     LSSVC_CHECK(!(mean && mean->ptr) || same_shape(mean, out), "import_symbols: mean shape mismatch");
     LSSVC_CHECK(chunk_masks_ok(chunk_of_mask) && (!chunk_of_mask || out->C % 4 == 0), "import_symbols: bad chunk_of_mask");
@@ -400,9 +426,19 @@ extern "C" int lssvc_import_symbols(const int32_t *sym_nchw, const lssvc_view *m
     const long long total = (long long)out->H * out->W * C_in;
     const int32_t none[4] = {-1, -1, -1, -1};
     const int32_t *cm = chunk_of_mask ? chunk_of_mask : none;
-    hipLaunchKernelGGL(import_symbols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym_nchw,
+    hipLaunchKernelGGL(import_symbols_kernel<PlaneT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sym_nchw,
                        opt(mean), channel_add, cm[0], cm[1], cm[2], cm[3], mk(out), C_in, out->H, out->W, total);
     return launch_status("import_symbols");
+}
+
+extern "C" int lssvc_import_symbols(const int32_t *sym_nchw, const lssvc_view *mean, const float *channel_add,
+                                    const int32_t *chunk_of_mask, const lssvc_view *out, void *stream) {
+    return import_symbols_impl<int32_t>(sym_nchw, mean, channel_add, chunk_of_mask, out, stream);
+}
+
+extern "C" int lssvc_import_symbols_i16(const int16_t *sym_nchw, const lssvc_view *mean, const float *channel_add,
+                                        const int32_t *chunk_of_mask, const lssvc_view *out, void *stream) {
+    return import_symbols_impl<int16_t>(sym_nchw, mean, channel_add, chunk_of_mask, out, stream);
 }
 
 // ---- error plumbing ---------------------------------------------------------------------------------

@@ -548,6 +548,34 @@ extern "C" int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float sl
     return binary(in, nullptr, out, 2, slope, stream, "lrelu");
 }
 
+// ---- range audit: max |x| of a view (NaN / Inf count as +Inf) ------------------------------------------------------------
+// Non-negative floats order like their bit patterns, so the grid reduces with one integer atomicMax per wave: no workspace,
+// no fp64, order-independent. The caller zeroes *out_max (or keeps accumulating the maximum over several views into it).
+__global__ void absmax_kernel(V x, unsigned int *out_max, long long total) {
+    unsigned int m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % x.C);
+        const size_t pix = (size_t)(i / x.C);
+        const float v = fabsf(x.p[pix * x.ld + c]);
+        const unsigned int b = (v == v) ? __float_as_uint(v) : 0x7f800000u;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int other = (unsigned int)__shfl_xor((int)m, o, 64);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_max, m);
+}
+
+extern "C" int lssvc_absmax(const lssvc_view *x, float *out_max, void *stream) {
+    LSSVC_CHECK(view_ok(x) && out_max, "absmax: bad arguments");
+    const long long total = (long long)x->H * x->W * x->C;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, mk(x),
+                       reinterpret_cast<unsigned int *>(out_max), total);
+    return launch_status("absmax");
+}
+
 extern "C" int lssvc_offset_diversity(const lssvc_view *x, const lssvc_view *om, const lssvc_view *flow,
                                       const float *fusion_w, const float *fusion_b, const lssvc_view *out, void *stream) {
     LSSVC_CHECK(view_ok(x) && view_ok(om) && view_ok(flow) && view_ok(out) && fusion_w && fusion_b, "offset_diversity: bad arguments");

@@ -5,8 +5,9 @@
 // symbols pushed in coding order and entropy-coded in reverse at flush, out-of-table symbols escaped through
 // the table's last slot followed by 4-bit raw digits (reference: src/cpp/rans/rans_interface.cpp:85-244,
 // rANS64 core = rygorous/ryg_rans rans64.h, public domain). What differs from the reference is the host
-// interface: symbols and indexes arrive as flat int32 planes straight from pinned D2H copies (no Python
-// lists), tables are passed by pointer, the pending symbols are packed in 32 bits, and the decoder finds
+// interface: symbols and indexes arrive as flat int32 or int16 planes (no Python lists; the product path hands over
+// int16 planes in one pinned staging buffer filled by an asynchronous D2H copy, lssvc_amd/entropy_coder.py), tables
+// are passed by pointer, the pending symbols are packed in 32 bits, and the decoder finds
 // the symbol by binary search and checks every read against the end of the stream.
 #include <cmath>
 #include <cstdint>
@@ -71,8 +72,8 @@ extern "C" void lssvc_rans_encoder_reset(void *h) {
     e->is_raw.clear();
 }
 
-extern "C" int lssvc_rans_encode_with_indexes(void *h, const int32_t *symbols, const int32_t *indexes, int64_t n,
-                                              const lssvc_cdf_table *t) {
+template <typename PlaneT>
+static int encode_with_indexes_impl(void *h, const PlaneT *symbols, const PlaneT *indexes, int64_t n, const lssvc_cdf_table *t) {
     LSSVC_CHECK(h && symbols && indexes && n >= 0 && table_ok(t), "rans_encode_with_indexes: bad arguments");
     Encoder *e = static_cast<Encoder *>(h);
     e->syms.reserve(e->syms.size() + (size_t)n + 16);
@@ -130,6 +131,15 @@ extern "C" int lssvc_rans_encode_with_indexes(void *h, const int32_t *symbols, c
     return 0;
 }
 
+extern "C" int lssvc_rans_encode_with_indexes(void *h, const int32_t *symbols, const int32_t *indexes, int64_t n,
+                                              const lssvc_cdf_table *t) {
+    return encode_with_indexes_impl<int32_t>(h, symbols, indexes, n, t);
+}
+extern "C" int lssvc_rans_encode_with_indexes_i16(void *h, const int16_t *symbols, const int16_t *indexes, int64_t n,
+                                                  const lssvc_cdf_table *t) {
+    return encode_with_indexes_impl<int16_t>(h, symbols, indexes, n, t);
+}
+
 // Entropy-codes the pending symbols (last pushed first, so the decoder pops them in pushing order) and
 // returns the byte count; lssvc_rans_encoder_bytes() then points at the stream until the next call.
 extern "C" int64_t lssvc_rans_encoder_flush(void *h) {
@@ -180,7 +190,8 @@ extern "C" int lssvc_rans_decoder_set_stream(void *h, const uint8_t *bytes, int6
     return 0;
 }
 
-extern "C" int lssvc_rans_decode_stream(void *h, const int32_t *indexes, int64_t n, const lssvc_cdf_table *t, int32_t *out) {
+template <typename PlaneT>
+static int decode_stream_impl(void *h, const PlaneT *indexes, int64_t n, const lssvc_cdf_table *t, PlaneT *out) {
     LSSVC_CHECK(h && indexes && out && n >= 0 && table_ok(t), "rans_decode_stream: bad arguments");
     Decoder *d = static_cast<Decoder *>(h);
     LSSVC_CHECK(d->words.size() >= 2, "rans_decode_stream: no stream set");
@@ -213,10 +224,20 @@ extern "C" int lssvc_rans_decode_stream(void *h, const int32_t *indexes, int64_t
             v = (int32_t)(raw >> 1);
             v = (raw & 1) ? -v - 1 : v + escape;
         }
-        out[i] = v + t->offsets[ci];
+        const int32_t s = v + t->offsets[ci];
+        if constexpr (sizeof(PlaneT) == 2)
+            LSSVC_CHECK(s >= -32768 && s <= 32767, "rans_decode_stream: symbol %d at %lld does not fit the 16-bit plane", s, (long long)i);
+        out[i] = (PlaneT)s;
     }
     LSSVC_CHECK(!d->overrun, "rans_decode_stream: read past the end of the stream");
     return 0;
+}
+
+extern "C" int lssvc_rans_decode_stream(void *h, const int32_t *indexes, int64_t n, const lssvc_cdf_table *t, int32_t *out) {
+    return decode_stream_impl<int32_t>(h, indexes, n, t, out);
+}
+extern "C" int lssvc_rans_decode_stream_i16(void *h, const int16_t *indexes, int64_t n, const lssvc_cdf_table *t, int16_t *out) {
+    return decode_stream_impl<int16_t>(h, indexes, n, t, out);
 }
 
 // Round a pmf to `precision`-bit frequencies whose CDF is strictly increasing (every symbol stays

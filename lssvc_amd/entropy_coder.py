@@ -3,6 +3,7 @@ liblssvc_hip.so (include/lssvc_hip.h, "host entropy coder"). API mirrors what th
 calls on its pybind11 modules (video_entropy_models.py:8-61): reset / encode_with_indexes / flush,
 set_stream / decode_stream, pmf_to_quantized_cdf -- but with int32 numpy planes instead of Python lists."""
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -44,6 +45,14 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
 
 
+def _prof(key, t0, count_key=None, n=0):
+    from . import hip_ops
+    if hip_ops.STREAM_PROF is not None:
+        hip_ops.STREAM_PROF[key] = hip_ops.STREAM_PROF.get(key, 0.0) + time.perf_counter() - t0
+        if count_key:
+            hip_ops.STREAM_PROF[count_key] = hip_ops.STREAM_PROF.get(count_key, 0) + int(n)
+
+
 class RansEncoder:
     def __init__(self):
         self.h = C.c_void_p(lib.lssvc_rans_encoder_new())
@@ -52,13 +61,25 @@ class RansEncoder:
         lib.lssvc_rans_encoder_reset(self.h)
 
     def encode_with_indexes(self, symbols, indexes, tables):
-        s, i = _i32(symbols), _i32(indexes)
-        assert s.size == i.size
-        check(lib.lssvc_rans_encode_with_indexes(self.h, s.ctypes.data, i.ctypes.data, s.size, C.byref(tables.c)))
+        t0 = time.perf_counter()
+        if getattr(symbols, "dtype", None) == np.int16 and getattr(indexes, "dtype", None) == np.int16 \
+                and symbols.flags.c_contiguous and indexes.flags.c_contiguous:
+            assert symbols.size == indexes.size
+            check(lib.lssvc_rans_encode_with_indexes_i16(self.h, symbols.ctypes.data, indexes.ctypes.data, symbols.size, C.byref(tables.c)))
+            n = symbols.size
+        else:
+            s, i = _i32(symbols), _i32(indexes)
+            assert s.size == i.size
+            check(lib.lssvc_rans_encode_with_indexes(self.h, s.ctypes.data, i.ctypes.data, s.size, C.byref(tables.c)))
+            n = s.size
+        _prof("rans_enc_s", t0, "enc_symbols", n)
 
     def flush(self):
+        t0 = time.perf_counter()
         n = lib.lssvc_rans_encoder_flush(self.h)
-        return C.string_at(lib.lssvc_rans_encoder_bytes(self.h), n)
+        out = C.string_at(lib.lssvc_rans_encoder_bytes(self.h), n)
+        _prof("rans_enc_s", t0)
+        return out
 
     def __del__(self):
         if lib is not None:
@@ -72,10 +93,19 @@ class RansDecoder:
     def set_stream(self, data):
         check(lib.lssvc_rans_decoder_set_stream(self.h, data, len(data)))
 
-    def decode_stream(self, indexes, tables):
-        i = _i32(indexes)
-        out = np.empty(i.size, dtype=np.int32)
-        check(lib.lssvc_rans_decode_stream(self.h, i.ctypes.data, i.size, C.byref(tables.c), out.ctypes.data))
+    def decode_stream(self, indexes, tables, out=None):
+        """-> decoded symbols. int16 indexes give int16 symbols (written into `out` if given: a pinned staging view)."""
+        t0 = time.perf_counter()
+        if getattr(indexes, "dtype", None) == np.int16 and indexes.flags.c_contiguous:
+            if out is None:
+                out = np.empty(indexes.size, dtype=np.int16)
+            assert out.dtype == np.int16 and out.size == indexes.size and out.flags.c_contiguous
+            check(lib.lssvc_rans_decode_stream_i16(self.h, indexes.ctypes.data, indexes.size, C.byref(tables.c), out.ctypes.data))
+        else:
+            i = _i32(indexes)
+            out = np.empty(i.size, dtype=np.int32)
+            check(lib.lssvc_rans_decode_stream(self.h, i.ctypes.data, i.size, C.byref(tables.c), out.ctypes.data))
+        _prof("rans_dec_s", t0, "dec_symbols", out.size)
         return out
 
     def __del__(self):
@@ -85,25 +115,46 @@ class RansDecoder:
 
 class SymbolSink:
     """Encoder side of one rANS string: latents are pushed in coding order (as the reference's
-    entropy_coder.reset_encoder / *.encode(...) / flush_encoder sequence, dmc_net_extend.py:89-95)."""
+    entropy_coder.reset_encoder / *.encode(...) / flush_encoder sequence, dmc_net_extend.py:89-95).
+    With a hip_ops.SymbolStage the pushes are PlaneRefs into the stage's device buffer: nothing crosses PCIe until flush(),
+    which brings the whole staged region down in one asynchronous copy into pinned memory and codes the planes in place."""
 
-    def __init__(self):
+    def __init__(self, stage=None):
         self.enc = RansEncoder()
         self.enc.reset()
+        self.stage = stage
+        self.pending = []
+        self.symbols = 0
 
     def push(self, symbols, indexes, tables):
-        self.enc.encode_with_indexes(symbols, indexes, tables)
+        if self.stage is not None and hasattr(indexes, "off"):
+            self.pending.append((symbols, indexes, tables))
+        else:
+            self.enc.encode_with_indexes(symbols, indexes, tables)
+            self.symbols += int(np.asarray(indexes).size)
 
     def flush(self):
+        if self.pending:
+            st = self.stage
+            st.download(min(min(r.off for r in (r_sym, r_idx) if r is not None) for r_sym, r_idx, _ in self.pending), st.used)
+            for r_sym, r_idx, tables in self.pending:
+                self.enc.encode_with_indexes(st.numpy(r_sym), st.numpy(r_idx), tables)
+                self.symbols += r_idx.n
+            self.pending = []
         return self.enc.flush()
 
 
 class SymbolSource:
-    """Decoder side: pulls latents from one rANS string in the same order."""
+    """Decoder side: pulls latents from one rANS string in the same order. With a SymbolStage, int16 index planes that live
+    in its pinned buffer are decoded into a fresh region of the same buffer (which the import kernel's upload reads)."""
 
-    def __init__(self, string):
+    def __init__(self, string, stage=None):
         self.dec = RansDecoder()
         self.dec.set_stream(string)
+        self.stage = stage
 
     def pull(self, indexes, tables):
-        return self.dec.decode_stream(indexes, tables)
+        out = None
+        if self.stage is not None and getattr(indexes, "dtype", None) == np.int16:
+            out = self.stage.numpy(self.stage.alloc(indexes.size))
+        return self.dec.decode_stream(indexes, tables, out=out)

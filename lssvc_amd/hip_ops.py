@@ -117,6 +117,48 @@ class Fork:
             self.join(i)
 
 
+# ---- fp16 range audit of the f16x3 conv mode ------------------------------------------------------------------------------
+# The f16x3 kernels split every activation into fp16 hi + lo parts while staging and SATURATE at +-65504 (GDN's 1x1 squares
+# first, so its limit is 255.9); the reference computes in fp32 and has no such limit. Pretrained checkpoints are not
+# available here, so instead of trusting that "all tensors on this path are O(1-100)" the models run the FIRST frame of every
+# frame type (I / first-P / steady-P, per size) under a RangeAudit: max |x| of every f16x3 conv input is reduced on the device
+# (lssvc_absmax; the fused DepthConvBlock kernels are split into their convs for that one frame so that their internal
+# tensors are seen too), and every layer whose input comes within a factor two of the limit is moved to the exact fp32
+# kernel for good, with a warning, and the frame is recomputed. LSSVC_RANGE_AUDIT=0 switches the audit off.
+RANGE_AUDIT = None                    # the RangeAudit of the frame being audited, else None
+RANGE_AUDIT_DEFAULT = _os.environ.get("LSSVC_RANGE_AUDIT", "1") == "1"
+F16_INPUT_LIMIT = 2.0 ** 15           # half of fp16's largest finite value: a 2x margin for the frames that follow
+F16_SQUARE_INPUT_LIMIT = 2.0 ** 7.5   # GDN squares while staging: x^2 <= 2^15
+
+
+class RangeAudit:
+    def __init__(self, device, max_layers=4096):
+        self.slots = torch.zeros(max_layers, dtype=torch.float32, device=device)
+        self.names, self.limits = [], []
+        self.report = {}
+
+    def watch(self, name, tensors, squared):
+        i = len(self.names)
+        if i >= self.slots.numel():
+            raise RuntimeError("RangeAudit: more than %d audited layers in one frame" % self.slots.numel())
+        self.names.append(name)
+        self.limits.append(F16_SQUARE_INPUT_LIMIT if squared else F16_INPUT_LIMIT)
+        ptr = C.c_void_p(self.slots.data_ptr() + 4 * i)
+        for t in tensors:
+            check(lib.lssvc_absmax(t.ref, ptr, stream_ptr()))
+
+    def finish(self):
+        """-> {layer name: max |input|} of the layers over their limit; self.report holds every audited layer."""
+        torch.cuda.synchronize(self.slots.device)
+        vals = self.slots[:len(self.names)].cpu().tolist()
+        bad = {}
+        for name, v, lim in zip(self.names, vals, self.limits):
+            self.report[name] = max(v, self.report.get(name, 0.0))
+            if not v < lim:
+                bad[name] = v
+        return bad
+
+
 class T:
     """An H x W x C fp32 view (batch 1) with pixel pitch `ld` into a flat torch buffer."""
     __slots__ = ("buf", "H", "W", "C", "ld", "off", "_v")
@@ -222,6 +264,8 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
     d.out_scale = out_scale
     d.pixel_shuffle = 1 if pixel_shuffle else 0
     d.out = out.v
+    if RANGE_AUDIT is not None and w16 is not None:
+        RANGE_AUDIT.watch(name, inputs, in_act == "square")
     if w16 is not None and CONV_CHECK:
         # debug aid (LSSVC_CONV_CHECK=1): run the launch in fp32 into a scratch output first, compare afterwards
         scratch = T.empty(out.H, out.W, out.C, out.device)
@@ -294,7 +338,7 @@ def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slo
         out = T.empty(hout * 2, wout * 2, cout // 4, x.device) if pixel_shuffle else T.empty(hout, wout, cout, x.device)
     w16 = None
     if CONV_PRECISION == "f16x3" and (stride == 1 and KH in (1, 3, 7) or stride == 2 and KH == 3) \
-            and all(t.C % 4 == 0 and t.ld % 4 == 0 for t in inputs):
+            and name not in W.force_f32 and all(t.C % 4 == 0 and t.ld % 4 == 0 for t in inputs):
         w16 = W.conv_f16x3(name, splits, pixel_shuffle)
     return _conv_launch(inputs, (w_dev, b_dev, cout, m_pad), KH, KW, stride, pad, pad, out, in_act=in_act,
                         in_slope=in_slope, act=act, slope=slope, residual=residual, out_scale=out_scale,
@@ -328,7 +372,7 @@ def gdn(W, name, x, flavour, inverse=False, *, residual=None, act=None, slope=0.
     if out is None:
         out = x.like()
     w16 = None
-    if CONV_PRECISION == "f16x3" and GDN_F16X3 and x.C % 4 == 0 and x.ld % 4 == 0:
+    if CONV_PRECISION == "f16x3" and GDN_F16X3 and x.C % 4 == 0 and x.ld % 4 == 0 and name not in W.force_f32:
         w16 = W.gdn_f16x3(name, flavour)
     return _conv_launch([x], (w_dev, b_dev, cout, m_pad), 1, 1, 1, 0, 0, out, in_act="square",
                         epilogue=_GDN_EPI[(flavour, inverse)], gdn_x=x, act=act, slope=slope, residual=residual,
@@ -351,8 +395,8 @@ def conv1x1_dw3x3(W, conv_name, dw_name, inputs, *, slope=0.01, out=None):
     or None if this shape is not covered (the caller then issues the two ops)."""
     if isinstance(inputs, T):
         inputs = [inputs]
-    if not (FUSE_DW and CONV_PRECISION == "f16x3") or len(inputs) > 3:
-        return None
+    if not (FUSE_DW and CONV_PRECISION == "f16x3") or len(inputs) > 3 or RANGE_AUDIT is not None or conv_name in W.force_f32:
+        return None                      # (an audited frame runs the two ops separately so that the tensor between them is seen)
     if any(t.C % 4 or t.ld % 4 for t in inputs) or sum((t.C + 15) // 16 for t in inputs) > 4:
         return None
     w_dev, b_dev, cout, m_pad, KH, KW = W.conv(conv_name, [t.C for t in inputs], False)
@@ -401,7 +445,9 @@ _FFN_LDS_LIMIT = 160 * 1024
 
 def ffn_fusable(W, ffn_prefix, pre_name, c_out, pre_cin):
     """Can DepthConv.conv2 (+identity) + ConvFFN of this block run as one lssvc_ffn_f16x3 launch?"""
-    if not (FUSE_FFN and CONV_PRECISION == "f16x3" and c_out in (32, 48, 64, 96, 128)):
+    if not (FUSE_FFN and CONV_PRECISION == "f16x3" and c_out in (32, 48, 64, 96, 128)) or RANGE_AUDIT is not None:
+        return False                     # (an audited frame runs the block's convs one by one: o1 and the hidden tensor are seen)
+    if W.force_f32 and (pre_name in W.force_f32 or ffn_prefix + ".conv.0" in W.force_f32 or ffn_prefix + ".conv.2" in W.force_f32):
         return False
     w1 = W.raw(ffn_prefix + ".conv.0.weight")
     if w1.shape[1] != c_out or w1.shape[0] % 32 or not W.has(ffn_prefix + ".conv.0.bias") or not W.has(ffn_prefix + ".conv.2.bias"):
@@ -485,6 +531,24 @@ def add(a, b, out=None):
 
 def copy(a, out):
     check(lib.lssvc_copy(a.ref, out.ref, stream_ptr()))
+    return out
+
+
+def pad_crop(x, pad):
+    """F.pad(x, (left, right, top, bottom), value=0) of an NHWC view, negative entries cropping: the reference's
+    get_depadded_feature (IntraSS.py:124-135, LSSVC_net.py:271-282). Pure data movement (a strided device copy); all
+    zeros in `pad` returns x itself."""
+    l, r, t, b = (int(v) for v in pad)
+    if l == r == t == b == 0:
+        return x
+    H, W = x.H + t + b, x.W + l + r
+    assert H > 0 and W > 0, "pad_size %s leaves nothing of a %dx%d map" % (pad, x.H, x.W)
+    out = T.zeros(H, W, x.C, x.device)
+    y0, y1, x0, x1 = max(0, -t), min(x.H, H - t), max(0, -l), min(x.W, W - l)      # source rectangle that survives
+    if y1 > y0 and x1 > x0:
+        src = x.buf.view(-1).as_strided((x.H, x.W, x.C), (x.W * x.ld, x.ld, 1), x.off)
+        dst = out.buf.view(H, W, x.C)
+        dst[y0 + t:y1 + t, x0 + l:x1 + l].copy_(src[y0:y1, x0:x1])
     return out
 
 
@@ -576,27 +640,162 @@ def entropy_bottleneck(z, params, slots, slot, z_hat=None, z_q=None):
                                        slots.wsp, stream_ptr()))
 
 
-def export_symbols(q, sigma, index_params=None, chunk_of_mask=None):
-    """-> (symbols, indexes) as host int32 numpy planes in NCHW order (either may be None).
+# ---- write_stream = 1: symbol / index planes between the device and the host coder ---------------------------------------
+# The reference moves every latent through Python lists (`.tolist()` of ~2.3 M symbols per P-frame,
+# video_entropy_models.py:234-236,317-319). Here a layer's planes are int16, written by the export kernels into ONE device
+# staging buffer and brought down by ONE asynchronous copy into pinned host memory when the layer's string is flushed; the
+# C coder reads them in place. STREAM_PROF (a dict, or None) collects where the time of a write_stream frame goes.
+STREAM_PROF = None
+
+
+def _prof(key, t0):
+    if STREAM_PROF is not None:
+        import time
+        STREAM_PROF[key] = STREAM_PROF.get(key, 0.0) + time.perf_counter() - t0
+
+
+def _prof_start(sync_device=None):
+    """-> perf_counter() or None; with profiling on, the device is drained first so that the interval that follows holds
+    only the work it brackets (the GPU forward that precedes a copy is then booked under 'gpu_wait_s')."""
+    if STREAM_PROF is None:
+        return None
+    import time
+    if sync_device is not None:
+        t0 = time.perf_counter()
+        torch.cuda.synchronize(sync_device)
+        STREAM_PROF["gpu_wait_s"] = STREAM_PROF.get("gpu_wait_s", 0.0) + time.perf_counter() - t0
+    return time.perf_counter()
+
+
+class PlaneRef:
+    """n int16 entries at element offset `off` of a SymbolStage."""
+    __slots__ = ("off", "n")
+
+    def __init__(self, off, n):
+        self.off, self.n = off, n
+
+
+class SymbolStage:
+    """Device + pinned-host int16 staging of one layer's symbol and index planes."""
+
+    def __init__(self, device):
+        self.device = device
+        self.capacity = self.used = 0
+        self.dev = self.host = self.host_np = None
+        self._down = (0, 0)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)           # set by a symbol that does not fit 16 bits
+        self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.done = torch.cuda.Event()
+
+    def begin(self, capacity):
+        """Start a layer: everything staged before is dead (its copies were waited for when its string was flushed)."""
+        if capacity > self.capacity:
+            self.capacity = int(capacity)
+            self.dev = torch.empty(self.capacity, dtype=torch.int16, device=self.device)
+            self.host = torch.empty(self.capacity, dtype=torch.int16).pin_memory()
+            self.host_np = self.host.numpy()
+        self.used = 0
+        self._down = (0, 0)
+        self.flag.zero_()
+        return self
+
+    def alloc(self, n):
+        off = self.used
+        self.used += (n + 7) // 8 * 8                                           # 16-byte aligned planes
+        if self.used > self.capacity:
+            raise RuntimeError("SymbolStage: %d entries staged, capacity %d" % (self.used, self.capacity))
+        return PlaneRef(off, n)
+
+    def dev_ptr(self, ref):
+        return C.c_void_p(self.dev.data_ptr() + 2 * ref.off)
+
+    def host_ptr(self, ref):
+        return C.c_void_p(self.host.data_ptr() + 2 * ref.off)
+
+    def numpy(self, ref):
+        return self.host_np[ref.off:ref.off + ref.n]
+
+    def download(self, lo, hi):
+        """dev[lo:hi] -> pinned host, asynchronously on the current stream; returns after the copy has landed."""
+        if lo >= self._down[0] and hi <= self._down[1]:
+            return                                                              # a sink sharing the stage already brought it down
+        self._down = (lo, hi)
+        t0 = _prof_start(self.device)
+        self.host[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
+        self.flag_host.copy_(self.flag, non_blocking=True)
+        self.done.record()
+        self.done.synchronize()
+        if t0 is not None:
+            _prof("d2h_s", t0)
+            STREAM_PROF["d2h_bytes"] = STREAM_PROF.get("d2h_bytes", 0) + 2 * (hi - lo)
+        if int(self.flag_host[0]) != 0:
+            raise RuntimeError("a quantised latent does not fit the 16-bit symbol planes")
+
+    def upload(self, ref):
+        t0 = _prof_start()
+        self.dev[ref.off:ref.off + ref.n].copy_(self.host[ref.off:ref.off + ref.n], non_blocking=True)
+        if t0 is not None:
+            _prof("h2d_s", t0)
+            STREAM_PROF["h2d_bytes"] = STREAM_PROF.get("h2d_bytes", 0) + 2 * ref.n
+
+
+def export_symbols(q, sigma, index_params=None, chunk_of_mask=None, stage=None):
+    """Symbol / index planes of a latent in NCHW order (either may be None). Without `stage`: host int32 numpy planes
+    (synchronous; tests and the compat modules). With a SymbolStage: the planes are written as int16 into the stage's
+    device buffer and (PlaneRef | None, PlaneRef) is returned -- nothing is copied or waited for here.
     index_params = (log_min, log_step, add, levels) when sigma is given; chunk_of_mask folds C -> C/4."""
     ref = q if q is not None else sigma
     c_out = ref.C // 4 if chunk_of_mask is not None else ref.C
     n = ref.H * ref.W * c_out
-    sym = torch.empty(n, dtype=torch.int32, device=ref.device) if q is not None else None
-    idx = torch.empty(n, dtype=torch.int32, device=ref.device)
     lo, step, add, levels = index_params if index_params is not None else (0.0, 1.0, 0.0, 1)
     cm = (C.c_int32 * 4)(*chunk_of_mask) if chunk_of_mask is not None else None
+    if stage is not None:
+        r_sym = stage.alloc(n) if q is not None else None
+        r_idx = stage.alloc(n)
+        check(lib.lssvc_export_symbols_i16(_opt(q), _opt(sigma), cm, lo, step, add, levels,
+                                           stage.dev_ptr(r_sym) if r_sym is not None else None, stage.dev_ptr(r_idx),
+                                           C.c_void_p(stage.flag.data_ptr()), stream_ptr()))
+        return r_sym, r_idx
+    sym = torch.empty(n, dtype=torch.int32, device=ref.device) if q is not None else None
+    idx = torch.empty(n, dtype=torch.int32, device=ref.device)
     check(lib.lssvc_export_symbols(_opt(q), _opt(sigma), cm, lo, step, add, levels,
                                    C.c_void_p(sym.data_ptr()) if sym is not None else None, C.c_void_p(idx.data_ptr()),
                                    stream_ptr()))
-    return (sym.cpu().numpy() if sym is not None else None), idx.cpu().numpy()
+    t0 = _prof_start(ref.device)
+    out = (sym.cpu().numpy() if sym is not None else None), idx.cpu().numpy()
+    if t0 is not None:
+        _prof("d2h_s", t0)
+        STREAM_PROF["d2h_bytes"] = STREAM_PROF.get("d2h_bytes", 0) + 4 * n * (2 if sym is not None else 1)
+    return out
 
 
-def import_symbols(symbols, out, mean=None, channel_add=None, chunk_of_mask=None):
-    """Host int32 NCHW plane -> device, out = sym + mean + channel_add[c] (unfolding C/4 -> C with chunk_of_mask)."""
-    dev = torch.from_numpy(symbols).to(out.device)
+def export_indexes(sigma, index_params, chunk_of_mask=None, stage=None):
+    """Decoder side: the table-index plane of `sigma` ON THE HOST (the coder needs it to decode): int16 view of the
+    stage's pinned buffer, or an int32 array without a stage. Waits for the device."""
+    if stage is None:
+        return export_symbols(None, sigma, index_params, chunk_of_mask)[1]
+    _, r = export_symbols(None, sigma, index_params, chunk_of_mask, stage=stage)
+    stage.download(r.off, r.off + r.n)
+    return stage.numpy(r)
+
+
+def import_symbols(symbols, out, mean=None, channel_add=None, chunk_of_mask=None, stage=None):
+    """Host NCHW plane -> device, out = sym + mean + channel_add[c] (unfolding C/4 -> C with chunk_of_mask). An int16 plane
+    that lives in `stage`'s pinned buffer goes up by an asynchronous copy; anything else through a pageable copy."""
     cm = (C.c_int32 * 4)(*chunk_of_mask) if chunk_of_mask is not None else None
-    check(lib.lssvc_import_symbols(C.c_void_p(dev.data_ptr()), _opt(mean),
-                                   C.c_void_p(channel_add.data_ptr()) if channel_add is not None else None, cm, out.ref,
-                                   stream_ptr()))
+    add = C.c_void_p(channel_add.data_ptr()) if channel_add is not None else None
+    if stage is not None and symbols.dtype.name == "int16" and symbols.ctypes.data >= stage.host.data_ptr() \
+            and symbols.ctypes.data + 2 * symbols.size <= stage.host.data_ptr() + 2 * stage.capacity:
+        ref = PlaneRef((symbols.ctypes.data - stage.host.data_ptr()) // 2, symbols.size)
+        stage.upload(ref)
+        check(lib.lssvc_import_symbols_i16(stage.dev_ptr(ref), _opt(mean), add, cm, out.ref, stream_ptr()))
+        return out
+    assert symbols.dtype.name in ("int16", "int32"), symbols.dtype
+    t0 = _prof_start()
+    dev = torch.from_numpy(symbols).to(out.device)
+    if t0 is not None:
+        _prof("h2d_s", t0)
+        STREAM_PROF["h2d_bytes"] = STREAM_PROF.get("h2d_bytes", 0) + symbols.nbytes
+    fn = lib.lssvc_import_symbols_i16 if symbols.dtype.name == "int16" else lib.lssvc_import_symbols
+    check(fn(C.c_void_p(dev.data_ptr()), _opt(mean), add, cm, out.ref, stream_ptr()))
     return out

@@ -55,15 +55,13 @@ class LSSVC_extend(_HostModel):
 
     def _pull_factorized(self, source, table, c, h, w):
         """BitEstimator.decode_stream (video_entropy_models.py:240-245): z_hat = decoded symbols."""
-        z_hat = T.empty(h, w, c, self.device)
-        return ops.import_symbols(source.pull(_channel_indexes(c, h, w), table), z_hat)
+        return self._pull(source, table, T.empty(h, w, c, self.device))
 
     def _pull_laplace(self, source, scales, means, chunk_of_mask=None, out=None):
         """GaussianEncoder.decode_stream (video_entropy_models.py:321-326) + the `+ means` that follows it."""
-        _, idx = ops.export_symbols(None, scales, LAPLACE_IDX, chunk_of_mask=chunk_of_mask)
         if out is None:
             out = T.empty(scales.H, scales.W, scales.C, self.device)
-        return ops.import_symbols(source.pull(idx, self._tables["laplace"]), out, mean=means, chunk_of_mask=chunk_of_mask)
+        return self._pull(source, self._tables["laplace"], out, sigma=scales, idx_params=LAPLACE_IDX, mean=means, chunk_of_mask=chunk_of_mask)
 
     def _bl_codec(self, x, ref_frame, ref_feature, sink=None, source=None, fk=None):
         """DMC base layer in one of two roles sharing every decoder-side kernel:
@@ -96,7 +94,7 @@ class LSSVC_extend(_HostModel):
             ops.factorized_quant_bits(mv_z, W.bit_estimator(p + ".bit_estimator_z_mv"), S, 3, z_hat=mv_z_hat)
             self._tap("bl_mv_z", mv_z_hat)
             if sink:
-                sink.push(*ops.export_symbols(mv_z_hat, None), tb["bl_z_mv"])
+                self._push(sink, mv_z_hat, None, tb["bl_z_mv"])
         else:
             zh, zw = bitstream.get_downsampled_shape(ref_frame.H, ref_frame.W, 64)
             mv_z_hat = self._pull_factorized(source, tb["bl_z_mv"], 64, zh, zw)
@@ -107,7 +105,7 @@ class LSSVC_extend(_HostModel):
             ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 2, y_q=mv_y_q, y_hat=mv_y_hat)
             self._tap("bl_mv_y", mv_y_q)
             if sink:
-                sink.push(*ops.export_symbols(mv_y_q, mv_scales, LAPLACE_IDX), tb["laplace"])
+                self._push(sink, mv_y_q, mv_scales, tb["laplace"], LAPLACE_IDX)
         else:
             mv_y_hat = self._pull_laplace(source, mv_scales, mv_means)
 
@@ -140,7 +138,7 @@ class LSSVC_extend(_HostModel):
             ops.factorized_quant_bits(z, W.bit_estimator(p + ".bit_estimator_z"), S, 1, z_hat=z_hat)
             self._tap("bl_z", z_hat)
             if sink:
-                sink.push(*ops.export_symbols(z_hat, None), tb["bl_z"])
+                self._push(sink, z_hat, None, tb["bl_z"])
         else:
             z_hat = self._pull_factorized(source, tb["bl_z"], 64, zh, zw)
 
@@ -157,7 +155,7 @@ class LSSVC_extend(_HostModel):
             ops.laplace_quant_bits(y, means, scales, S, 0, y_q=y_q, y_hat=y_hat)
             self._tap("bl_y", y_q)
             if sink:
-                sink.push(*ops.export_symbols(y_q, scales, LAPLACE_IDX), tb["laplace"])
+                self._push(sink, y_q, scales, tb["laplace"], LAPLACE_IDX)
         else:
             y_hat = self._pull_laplace(source, scales, means)
 
@@ -281,7 +279,7 @@ class LSSVC_extend(_HostModel):
                 self._pull_laplace(source, scales, means, chunk_of_mask=CHUNK_OF_MASK[step], out=y_hat)
         if sink:
             for step in range(4):          # y_q_w_0..3 / scales_w_0..3 (LSSVC_net.py:432-442), pushed after the loop
-                sink.push(*ops.export_symbols(y_q, s_hat, LAPLACE_IDX, chunk_of_mask=CHUNK_OF_MASK[step]), self._tables["laplace"])
+                self._push(sink, y_q, s_hat, self._tables["laplace"], LAPLACE_IDX, chunk_of_mask=CHUNK_OF_MASK[step])
         return y_q, y_hat, s_hat
 
     def _el_codec(self, xe, bl, ref_el, feat_el, sink=None, source=None, fk=None, pre=None):
@@ -297,6 +295,8 @@ class LSSVC_extend(_HostModel):
         decoding = source is not None
         fk = fk if fk is not None else ops.Fork(self.device, enabled=False)
         pre = pre or {}
+        # ILP (LSSVC_net.py:454-456): the three base-layer tensors the EL reads, de-padded (a no-op for test.py's zeros)
+        bl = {"feature": self._depad(bl["feature"]), "mv_hat": self._depad(bl["mv_hat"]), "y_hat": self._depad(bl["y_hat"], 16)}
         fused = T.empty(H // 16, Wd // 16, 384, self.device)       # cat(hyper 128, temporal 128, layer 128), filled in place
         with fk.branch(1):        # BL texture -> EL pyramid (lssvc_modules.py:368-397,157-177): beside the whole EL MV codec
             spat = B.pyramid_extractor(W, "texture_extractor", self._texture_resampler(bl["feature"]))
@@ -332,7 +332,7 @@ class LSSVC_extend(_HostModel):
             ops.factorized_quant_bits(mv_z, W.bit_estimator("bit_estimator_z_mv"), S, 7, z_hat=mv_z_hat)
             self._tap("el_mv_z", mv_z_hat)
             if sink:
-                sink.push(*ops.export_symbols(mv_z_hat, None), tb["el_z_mv"])
+                self._push(sink, mv_z_hat, None, tb["el_z_mv"])
         else:
             mv_z_hat = self._pull_factorized(source, tb["el_z_mv"], 64, zh, zw)
         q = "mv_prior_decoder"
@@ -349,7 +349,7 @@ class LSSVC_extend(_HostModel):
             ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 5, y_q=mv_y_q, y_hat=mv_y_hat)
             self._tap("el_mv_y", mv_y_q)
             if sink:
-                sink.push(*ops.export_symbols(mv_y_q, mv_scales, LAPLACE_IDX), tb["laplace"])
+                self._push(sink, mv_y_q, mv_scales, tb["laplace"], LAPLACE_IDX)
         else:
             mv_y_hat = self._pull_laplace(source, mv_scales, mv_means)
         # MVResDecoder (lssvc_modules.py:472-494)
@@ -393,7 +393,7 @@ class LSSVC_extend(_HostModel):
             ops.factorized_quant_bits(z, W.bit_estimator("bit_estimator_z"), S, 6, z_hat=z_hat)
             self._tap("el_z", z_hat)
             if sink:
-                sink.push(*ops.export_symbols(z_hat, None), tb["el_z"])
+                self._push(sink, z_hat, None, tb["el_z"])
         else:
             y = None
             z_hat = self._pull_factorized(source, tb["el_z"], 128, zh, zw)
@@ -448,6 +448,11 @@ class LSSVC_extend(_HostModel):
         return {"recon_bl": bl["recon"], "feature_bl": bl["feature"], "recon_el": recon_el, "feature_el": feature,
                 "mv_hat": mv_hat, "warp_frame": warp_frame}
 
+    @staticmethod
+    def _frame_key(tensors):
+        """Frame type + sizes: first-P (no BL feature, 64-channel EL feature) and steady-P differ in their shapes."""
+        return ("p",) + tuple(None if v is None else tuple(v.shape) for v in tensors.values())
+
     def forward_one_frame(self, x_bl, x_el, ref_frame_bl, ref_frame_el, ref_feature_bl, ref_feature_el):
         """LSSVC.forward_one_frame (LSSVC_net.py:445-528): estimate mode."""
         self._require_device()
@@ -456,10 +461,10 @@ class LSSVC_extend(_HostModel):
                    "ref_feature_bl": ref_feature_bl, "ref_feature_el": ref_feature_el}
         t_issue = time.perf_counter()
         if self.graph_mode:
-            key = ("p",) + tuple(None if v is None else tuple(v.shape) for v in tensors.values())
-            r = self._run_planned(key, tensors, self._frame_body)
+            r = self._run_planned(self._frame_key(tensors), tensors, self._frame_body)
         else:
-            r = self._frame_body({k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()})
+            ins = {k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()}
+            r = self._with_range_audit(self._frame_key(tensors), lambda: self._frame_body(ins))
         self.last_issue_s = time.perf_counter() - t_issue        # host time to put the frame on the stream (no GPU wait)
         dpb = {"ref_frame_bl": r["recon_bl"].to_nchw(remember=True), "ref_feature_bl": r["feature_bl"].to_nchw(remember=True),
                "ref_frame_el": r["recon_el"].to_nchw(remember=True), "ref_feature_el": r["feature_el"].to_nchw(remember=True)}
@@ -481,25 +486,28 @@ class LSSVC_extend(_HostModel):
         xb, xe = nhwc(x_bl), nhwc(x_el)
         ref_bl, ref_el = nhwc(dpb["ref_frame_bl"]), nhwc(dpb["ref_frame_el"])
         feat_bl, feat_el = nhwc(dpb["ref_feature_bl"]), nhwc(dpb["ref_feature_el"])
+        ins = {"x_bl": xb, "x_el": xe, "ref_frame_bl": ref_bl, "ref_frame_el": ref_el, "ref_feature_bl": feat_bl, "ref_feature_el": feat_el}
+        self._with_range_audit(("p",) + tuple(None if v is None else (1, v.C, v.H, v.W) for v in ins.values()),
+                               lambda: self._frame_body(ins))                # first frame of a type only (hip_ops.RangeAudit)
         sync = lambda: torch.cuda.synchronize(self.device)
         # ---- base layer ----
         sync(); t0 = time.time()
-        sink = SymbolSink()
+        sink = SymbolSink(self._begin_layer())
         bl_e = self._bl_codec(xb, ref_bl, feat_bl, sink=sink)
         bitstream.encode_p(sink.flush(), output_path_bl)
         bit_bl = bitstream.filesize(output_path_bl) * 8
         sync(); t1 = time.time()
-        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(output_path_bl)))
+        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(output_path_bl), self._begin_layer()))
         recon_bl = bl["recon"].to_nchw(copy=True).clamp_(0, 1)                         # dmc_net_extend.py:138
         sync(); t2 = time.time()
         # ---- enhancement layer ----
-        sink = SymbolSink()
+        sink = SymbolSink(self._begin_layer())
         feature_e, recon_e, mv_hat, warp_frame = self._el_codec(xe, bl, ref_el, feat_el, sink=sink)
         bitstream.encode_p(sink.flush(), output_path_el)
         bit_el = bitstream.filesize(output_path_el) * 8
         est = self.slots.fetch()
         sync(); t3 = time.time()
-        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(output_path_el)))
+        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(output_path_el), self._begin_layer()))
         sync(); t4 = time.time()
         out_dpb = {"ref_frame_bl": recon_bl, "ref_feature_bl": bl["feature"].to_nchw(),
                    "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()}
@@ -521,9 +529,9 @@ class LSSVC_extend(_HostModel):
         nhwc = lambda t: None if t is None else T.from_nchw(t)
         ref_bl, ref_el = nhwc(dpb["ref_frame_bl"]), nhwc(dpb["ref_frame_el"])
         feat_bl, feat_el = nhwc(dpb["ref_feature_bl"]), nhwc(dpb["ref_feature_el"])
-        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(input_path_bl)))
+        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(input_path_bl), self._begin_layer()))
         recon_bl = bl["recon"].to_nchw(copy=True).clamp_(0, 1)                         # dmc_net_extend.py:138
-        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(input_path_el)))
+        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(input_path_el), self._begin_layer()))
         return {"dpb": {"ref_frame_bl": recon_bl, "ref_feature_bl": bl["feature"].to_nchw(remember=True),
                         "ref_frame_el": recon_el.to_nchw(remember=True), "ref_feature_el": feature.to_nchw(remember=True)}}
 

@@ -82,6 +82,9 @@ class _HostModel:
         self.graph_mode = _os.environ.get("LSSVC_GRAPH", "0") == "1"
         self._plans = {}
         self.last_issue_s = 0.0
+        self.range_audit = ops.RANGE_AUDIT_DEFAULT     # audit the first frame of every type for fp16 range (hip_ops.RangeAudit)
+        self._audited = set()
+        self.audit_report = {}    # frame-type key -> {layer: max |input|} of the audited frame
         self.taps = None          # diagnostics: set to a dict and every encoder pass stores its quantised latents in it
 
     def set_graph_mode(self, on=True):
@@ -99,6 +102,7 @@ class _HostModel:
         The key is extended by everything a captured launch sequence bakes in besides the tensor shapes (scale factor,
         padded size, inter-layer padding, conv precision, single- or multi-stream order); plans are evicted least recently
         used, so a harness that walks through sizes and ratios does not pile up graph pools."""
+        frame_type = key
         key = key + (float(self.scale_factor), self.shape_hr, self.pad_size, ops.CONV_PRECISION, ops.MULTI_STREAM)
         plan = self._plans.pop(key, None)
         if plan is None:
@@ -109,7 +113,8 @@ class _HostModel:
         self._plans[key] = plan                                      # (re-)insert as most recently used
         if plan.calls == 0:
             plan.calls = 1
-            return body({k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()})
+            ins = {k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()}
+            return self._with_range_audit(frame_type, lambda: body(ins))
         plan.load(tensors)
         if plan.graph is None:
             torch.cuda.synchronize(self.device)
@@ -129,6 +134,7 @@ class _HostModel:
         self.device = device
         self.W = WeightStore(self._sd, device)
         self.slots = ops.BitSlots(device)
+        self.stage = ops.SymbolStage(device)
         return self
 
     def cuda(self, index=0):
@@ -141,15 +147,76 @@ class _HostModel:
     def set_scale_information(self, scale, shape_hr, pad_size):
         self.scale_factor = scale
         self.shape_hr = (int(shape_hr[0]), int(shape_hr[1]))
-        self.pad_size = tuple(pad_size)
-        if any(int(v) != 0 for v in self.pad_size):
-            # test.py:212-213 always passes (0,0,0,0); the de-pad path is a no-op there.
-            raise NotImplementedError("non-zero inter-layer pad_size is not supported")
+        self.pad_size = tuple(int(v) for v in pad_size)      # test.py:212-213 always passes (0,0,0,0)
+
+    def _depad(self, t, p=1):
+        """get_depadded_feature (IntraSS.py:124-135, LSSVC_net.py:271-282): F.pad by pad_size / p (zeros; negative = crop)."""
+        return None if t is None else ops.pad_crop(t, tuple(int(v / p) for v in self.pad_size))
+
+    def _with_range_audit(self, key, run):
+        """run() -> the frame's outputs. In the f16x3 mode the first frame of type `key` is first run DRY under a RangeAudit
+        (its outputs are discarded: the audited pass splits the fused DepthConvBlock kernels, whose sums are ordered
+        differently, and every result handed out must come from the one normal launch sequence); layers whose input comes
+        within 2x of what their fp16 staging can hold are moved to the exact fp32 kernel, with a warning; then the frame runs
+        normally. Until no layer moves any more, at most three rounds (an fp32 layer changes nothing upstream of itself)."""
+        if not self.range_audit or ops.CONV_PRECISION != "f16x3" or key in self._audited:
+            return run()
+        self._audited.add(key)
+        for _ in range(3):
+            audit = ops.RANGE_AUDIT = ops.RangeAudit(self.device)
+            try:
+                run()
+            finally:
+                ops.RANGE_AUDIT = None
+            bad = audit.finish()
+            self.audit_report[key] = audit.report
+            if not bad:
+                break
+            import warnings
+            self.W.force_f32 |= set(bad)
+            worst = max(bad, key=bad.get)
+            warnings.warn("fp16 range audit (%s): %d conv layer(s) moved to the exact fp32 kernel, e.g. %s with max |input| = %.3g; a "
+                          "separate decoder process must be given the same set (get_f32_layers / set_f32_layers)"
+                          % (key[0], len(bad), worst, bad[worst]))
+        return run()
+
+    def get_f32_layers(self):
+        """Conv layers the range audit moved to the exact fp32 kernel (sorted names). With write_stream=1 the choice of kernel
+        is part of what encoder and decoder must share: a decoder running in another process has to be given this list
+        (set_f32_layers) before its first frame, like the checkpoint itself."""
+        return sorted(self.W.force_f32)
+
+    def set_f32_layers(self, names):
+        self._require_device()
+        self.W.force_f32 = set(names)
+        self._plans = {}                       # captured launch sequences bake the kernel choice in
 
     def _tap(self, name, t):
         """Diagnostic tap (tests/test_gpu_golden_full.py): the quantised latent `t` as an int16 NCHW host tensor."""
         if self.taps is not None and t is not None:
             self.taps[name] = t.to_nchw(copy=True).round().to(torch.int16).cpu()
+
+    # ---- write_stream = 1 plumbing: symbol planes between the kernels and the host coder (entropy_coder.py) ----
+    def _begin_layer(self):
+        """Start coding / decoding one layer: its int16 planes are staged in self.stage (device + pinned host)."""
+        H, W = self.shape_hr
+        return self.stage.begin(6 * 256 * (H // 16) * (W // 16) + 4096)
+
+    def _push(self, sink, q, sigma, tables, idx_params=None, chunk_of_mask=None):
+        """Encoder: hand the symbols of `q` (table index from `sigma`, or the channel number) to a sink."""
+        sink.push(*ops.export_symbols(q, sigma, idx_params, chunk_of_mask, stage=getattr(sink, "stage", None)), tables)
+
+    def _pull(self, source, tables, out, sigma=None, idx_params=None, mean=None, channel_add=None, chunk_of_mask=None):
+        """Decoder: out = decoded symbols (+ mean / per-channel medians); the table index plane comes from `sigma`
+        (GaussianConditional / GaussianEncoder.build_indexes) or is the channel number (factorised tables)."""
+        st = getattr(source, "stage", None)
+        if sigma is not None:
+            idx = ops.export_indexes(sigma, idx_params, chunk_of_mask, stage=st)
+        else:
+            idx = _channel_indexes(out.C, out.H, out.W)
+            if st is not None:
+                idx = idx.astype("int16")
+        return ops.import_symbols(source.pull(idx, tables), out, mean=mean, channel_add=channel_add, chunk_of_mask=chunk_of_mask, stage=st)
 
     def _require_device(self):
         if self.W is None:
@@ -215,12 +282,11 @@ class IntraSS(_HostModel):
             ops.entropy_bottleneck(z, W.entropy_bottleneck(p + ".entropy_bottleneck"), self.slots, 1, z_hat=z_hat, z_q=z_q)
             self._tap("bl_z", z_q)
             if sinks:
-                sinks[1].push(*ops.export_symbols(z_q, None), T_["bl_eb"][0])
+                self._push(sinks[1], z_q, None, T_["bl_eb"][0])
         else:
             zh, zw = lat_hw
             z_hat = T.empty(zh, zw, N, self.device)
-            idx = _channel_indexes(N, zh, zw)
-            ops.import_symbols(sources[1].pull(idx, T_["bl_eb"][0]), z_hat, channel_add=self._dev_medians("bl_eb"))
+            self._pull(sources[1], T_["bl_eb"][0], z_hat, channel_add=self._dev_medians("bl_eb"))
         params = _lrelu_conv_seq(W, p + ".h_s", z_hat,
                                  [(0, "conv", 1), (2, "subpel", 1), (4, "conv", 1), (6, "subpel", 1), (8, "conv", 1)])
         scales, means = params.chunk(2)
@@ -230,11 +296,10 @@ class IntraSS(_HostModel):
             ops.gaussian_conditional(y, scales, means, self.slots, 0, y_hat=y_hat, y_q=y_q)
             self._tap("bl_y", y_q)
             if sinks:
-                sinks[0].push(*ops.export_symbols(y_q, scales, GAUSS_IDX), T_["gauss"])
+                self._push(sinks[0], y_q, scales, T_["gauss"], GAUSS_IDX)
         else:
             y_hat = T.empty(scales.H, scales.W, scales.C, self.device)
-            _, idx = ops.export_symbols(None, scales, GAUSS_IDX)
-            ops.import_symbols(sources[0].pull(idx, T_["gauss"]), y_hat, mean=means)
+            self._pull(sources[0], T_["gauss"], y_hat, sigma=scales, idx_params=GAUSS_IDX, mean=means)
         g = p + ".g_s"
         t = B.residual_block(W, g + ".0", y_hat)
         t = B.residual_block_upsample(W, g + ".1", t)
@@ -251,6 +316,7 @@ class IntraSS(_HostModel):
         W = self.W
         T_ = self._tables
         H, Wd = self.shape_hr
+        x_hat_bl, y_hat_bl = self._depad(x_hat_bl), self._depad(y_hat_bl, 16)                  # IntraSS.py:146-147
         # multi_scale_context_mining (IntraSS.py:119-122)
         t = ops.conv(W, "texture_resampler.conv_adaptor.0", x_hat_bl, act="lrelu")
         t = ops.conv(W, "texture_resampler.conv_adaptor.2", t)
@@ -266,12 +332,11 @@ class IntraSS(_HostModel):
             ops.entropy_bottleneck(z, W.entropy_bottleneck("entropy_bottleneck"), self.slots, 3, z_hat=z_hat, z_q=z_q)
             self._tap("el_z", z_q)
             if sinks:
-                sinks[1].push(*ops.export_symbols(z_q, None), T_["eb"][0])
+                self._push(sinks[1], z_q, None, T_["eb"][0])
         else:
             zh, zw = lat_hw
             z_hat = T.empty(zh, zw, 64, self.device)
-            ops.import_symbols(sources[1].pull(_channel_indexes(64, zh, zw), T_["eb"][0]), z_hat,
-                               channel_add=self._dev_medians("eb"))
+            self._pull(sources[1], T_["eb"][0], z_hat, channel_add=self._dev_medians("eb"))
 
         # PriorFusion input cat(hyper 192, layer 96, context_params 192) is written in place (layers.py:489-492)
         fused = T.empty(H // 16, Wd // 16, 480, self.device)
@@ -291,11 +356,10 @@ class IntraSS(_HostModel):
             ops.gaussian_conditional(y, scales, means, self.slots, 2, y_hat=y_hat, y_q=y_q)
             self._tap("el_y", y_q)
             if sinks:
-                sinks[0].push(*ops.export_symbols(y_q, scales, GAUSS_IDX), T_["gauss"])
+                self._push(sinks[0], y_q, scales, T_["gauss"], GAUSS_IDX)
         else:
             y_hat = T.empty(scales.H, scales.W, scales.C, self.device)
-            _, idx = ops.export_symbols(None, scales, GAUSS_IDX)
-            ops.import_symbols(sources[0].pull(idx, T_["gauss"]), y_hat, mean=means)
+            self._pull(sources[0], T_["gauss"], y_hat, sigma=scales, idx_params=GAUSS_IDX, mean=means)
 
         res_hat = B.res_decoder_gdn(W, "g_s", y_hat, c2, c3, "intra")
         feature, x_hat = B.recon_generation(W, "recon_net", res_hat, c1)
@@ -316,7 +380,8 @@ class IntraSS(_HostModel):
         if self.graph_mode:
             r = self._run_planned(("i", tuple(x_bl.shape), tuple(x_el.shape)), tensors, self._frame_body)
         else:
-            r = self._frame_body({k: T.from_nchw(v) for k, v in tensors.items()})
+            ins = {k: T.from_nchw(v) for k, v in tensors.items()}
+            r = self._with_range_audit(("i", tuple(x_bl.shape), tuple(x_el.shape)), lambda: self._frame_body(ins))
         self.last_issue_s = _time.perf_counter() - t_issue       # host time to put the frame on the stream (no GPU wait)
         x_hat_bl, x_hat, feature = r["x_hat_bl"], r["x_hat_el"], r["feature_el"]
         out = {"x_hat_bl": x_hat_bl.to_nchw(remember=True), "x_hat_el": x_hat.to_nchw(remember=True), "feature_el": feature.to_nchw(remember=True)}
@@ -336,22 +401,27 @@ class IntraSS(_HostModel):
             raise ValueError("Uninitialized CDFs. Run update() first")       # img_entropy_models.py:265-267
         assert pic_height_el is not None and pic_width_el is not None
         xb, xe = T.from_nchw(x_bl), T.from_nchw(x_el)
+        self._with_range_audit(("i", tuple(x_bl.shape), tuple(x_el.shape)), lambda: self._frame_body({"x_bl": xb, "x_el": xe}))   # first frame only
         # ---- encode ----
-        sinks = (SymbolSink(), SymbolSink())
+        st = self._begin_layer()
+        sinks = (SymbolSink(st), SymbolSink(st))
         x_hat_bl_e, y_hat_bl_e = self._bl_codec(xb, sinks=sinks)
         bitstream.encode_i(pic_height_bl, pic_width_bl, sinks[0].flush(), sinks[1].flush(), bin_path_bl)
         bit_bl = bitstream.filesize(bin_path_bl) * 8
-        sinks = (SymbolSink(), SymbolSink())
+        st = self._begin_layer()
+        sinks = (SymbolSink(st), SymbolSink(st))
         feature_e, x_hat_e = self._el_codec(xe, x_hat_bl_e, y_hat_bl_e, sinks=sinks)
         bitstream.encode_i(pic_height_el, pic_width_el, sinks[0].flush(), sinks[1].flush(), bin_path_el)
         bit_el = bitstream.filesize(bin_path_el) * 8
         est = self.slots.fetch()
         # ---- decode ----
         h, w, y_string, z_string = bitstream.decode_i(bin_path_bl)
-        x_hat_bl, y_hat_bl = self._bl_codec(None, sources=(SymbolSource(y_string), SymbolSource(z_string)),
+        st = self._begin_layer()
+        x_hat_bl, y_hat_bl = self._bl_codec(None, sources=(SymbolSource(y_string, st), SymbolSource(z_string, st)),
                                             lat_hw=bitstream.get_downsampled_shape(h, w, 64))
         h, w, y_string, z_string = bitstream.decode_i(bin_path_el)
-        feature, x_hat = self._el_codec(None, x_hat_bl, y_hat_bl, sources=(SymbolSource(y_string), SymbolSource(z_string)),
+        st = self._begin_layer()
+        feature, x_hat = self._el_codec(None, x_hat_bl, y_hat_bl, sources=(SymbolSource(y_string, st), SymbolSource(z_string, st)),
                                         lat_hw=bitstream.get_downsampled_shape(h, w, 64))
         return {"bit_bl": bit_bl, "bit_el": bit_el, "x_hat_bl": x_hat_bl.to_nchw(), "x_hat_el": x_hat.to_nchw(),
                 "feature_el": feature.to_nchw(),
@@ -368,10 +438,12 @@ class IntraSS(_HostModel):
         if self._tables is None:
             raise ValueError("Uninitialized CDFs. Run update() first")
         h, w, y_string, z_string = bitstream.decode_i(bin_path_bl)
-        x_hat_bl, y_hat_bl = self._bl_codec(None, sources=(SymbolSource(y_string), SymbolSource(z_string)),
+        st = self._begin_layer()
+        x_hat_bl, y_hat_bl = self._bl_codec(None, sources=(SymbolSource(y_string, st), SymbolSource(z_string, st)),
                                             lat_hw=bitstream.get_downsampled_shape(h, w, 64))
         h, w, y_string, z_string = bitstream.decode_i(bin_path_el)
-        feature, x_hat = self._el_codec(None, x_hat_bl, y_hat_bl, sources=(SymbolSource(y_string), SymbolSource(z_string)),
+        st = self._begin_layer()
+        feature, x_hat = self._el_codec(None, x_hat_bl, y_hat_bl, sources=(SymbolSource(y_string, st), SymbolSource(z_string, st)),
                                         lat_hw=bitstream.get_downsampled_shape(h, w, 64))
         return {"x_hat_bl": x_hat_bl.to_nchw(remember=True), "x_hat_el": x_hat.to_nchw(remember=True),
                 "feature_el": feature.to_nchw(remember=True)}

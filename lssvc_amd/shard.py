@@ -44,12 +44,16 @@ def max_over_ranks(seconds, dist=None, device=None):
     return t.item()
 
 
-def broadcast_state_dicts(paths, dist=None, device="cpu", loader=None):
+def broadcast_state_dicts(paths, dist=None, device="cpu", loader=None, force=False):
     """{path: state_dict} on every rank, with only rank 0 touching the file system: rank 0 loads each checkpoint
     (`loader(path)`, default torch.load + unwrap of {"state_dict": ...}), packs all tensors of all checkpoints into ONE
     flat byte blob and broadcasts it (RCCL over xGMI when `device` is a GPU: ~245 MB once per run; gloo on CPUs) together
     with a small manifest; the other ranks cut their state dicts out of the blob. This is the "RCCL broadcast of the
-    I-frame reference / weights" step of SURVEY 8(e): the only collective besides the end-of-run gather of scalars."""
+    I-frame reference / weights" step of SURVEY 8(e): the only collective besides the end-of-run gather of scalars.
+    Entries that are not tensors (a checkpoint may carry an epoch number or a config dict) travel inside the manifest.
+    `paths` are only keys for `loader` (bench.py passes model names and a loader that draws the synthetic weights).
+    force=True takes the pack / broadcast / unpack path even in a world of one rank (tests/test_gpu_shard.py runs it over
+    RCCL on a single GPU)."""
     import torch
 
     def default_loader(path):
@@ -58,7 +62,7 @@ def broadcast_state_dicts(paths, dist=None, device="cpu", loader=None):
 
     loader = loader or default_loader
     paths = list(dict.fromkeys(paths))
-    solo = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
+    solo = dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force)
     if solo:
         return {p: loader(p) for p in paths}
     rank = dist.get_rank()
@@ -67,6 +71,9 @@ def broadcast_state_dicts(paths, dist=None, device="cpu", loader=None):
         manifest, chunks, off = [], [], 0
         for p in paths:
             for name, t in loader(p).items():
+                if not torch.is_tensor(t):
+                    manifest.append((p, name, None, t, 0, 0))              # plain Python value: rides in the manifest
+                    continue
                 t = t.detach().contiguous().cpu()
                 raw = t.reshape(-1).view(torch.uint8) if t.numel() else torch.empty(0, dtype=torch.uint8)    # (0-dim scalars too)
                 manifest.append((p, name, str(t.dtype).replace("torch.", ""), tuple(t.shape), off, raw.numel()))
@@ -85,6 +92,9 @@ def broadcast_state_dicts(paths, dist=None, device="cpu", loader=None):
     buf = buf.cpu()
     out = {p: {} for p in paths}
     for p, name, dtype, shape, off, n in manifest:
+        if dtype is None:
+            out[p][name] = shape                                          # the value itself
+            continue
         t = buf[off:off + n].clone().view(getattr(torch, dtype)).reshape(shape)
         out[p][name] = t
     return out
@@ -97,12 +107,26 @@ def run_sharded(units, run, dist=None):
     if solo:
         return [run(u) for u in units]
     world, rank = dist.get_world_size(), dist.get_rank()
-    mine = [(i, run(u)) for i, u in enumerate(units) if i % world == rank]
+    # A unit that raises (a truncated YUV file, say) must not leave the other ranks waiting in the gather until a watchdog
+    # tears the job down: every rank finishes its share, failures travel with the results, and ALL ranks raise afterwards
+    # with the failing unit and rank named.
+    import traceback
+    mine = []
+    for i, u in enumerate(units):
+        if i % world != rank:
+            continue
+        try:
+            mine.append((i, True, run(u)))
+        except Exception:                                                 # noqa: BLE001 -- reported below, on every rank
+            mine.append((i, False, "rank %d, unit %d: %s" % (rank, i, traceback.format_exc())))
     parts = [None] * world
     dist.all_gather_object(parts, mine)
+    failed = [msg for part in parts for _, ok, msg in part if not ok]
+    if failed:
+        raise RuntimeError("%d of %d work units failed:\n%s" % (len(failed), len(units), "\n".join(failed)))
     merged = {}
     for part in parts:
-        for i, r in part:
+        for i, _, r in part:
             if i in merged:
                 raise RuntimeError("unit %d was run by more than one rank" % i)
             merged[i] = r

@@ -183,6 +183,7 @@ class WeightStore:
                    for k, v in sd.items()}
         self.device = device
         self._cache = {}
+        self.force_f32 = set()          # layers the fp16 range audit moved to the exact fp32 conv kernel (hip_ops.RangeAudit)
 
     def has(self, key):
         return key in self.sd

@@ -331,12 +331,14 @@ class _ELParams(Params):
     shape_hr = None
 
 
-def inter_forward(sd, x_bl, x_el, dpb, shape_hr, scale, extras=False):
-    """LSSVC.forward_one_frame (LSSVC_net.py:445-528), pad_size=(0,0,0,0)."""
+def inter_forward(sd, x_bl, x_el, dpb, shape_hr, scale, extras=False, pad_size=(0, 0, 0, 0)):
+    """LSSVC.forward_one_frame (LSSVC_net.py:445-528); pad_size=(0,0,0,0) is what test.py:213 always passes."""
     p = _ELParams(sd)
     p.shape_hr = tuple(shape_hr)
     bl = bl_inter_layer_information(x_bl, dpb["ref_frame_bl"], dpb["ref_feature_bl"], p.sub("base_layer_model"))
     feature_bl, mv_bl_hat, y_bl_hat = bl["feature"], bl["mv_hat"], bl["y_hat"]
+    from .intra import depad                                                   # ILP, LSSVC_net.py:454-456
+    texture_bl, mv_bl_hat, y_bl_hat = depad(feature_bl, pad_size), depad(mv_bl_hat, pad_size), depad(y_bl_hat, pad_size, 16)
 
     mv_up = mv_resampler(mv_bl_hat, p.sub("mv_resampler"), shape_hr, scale)
     mv_ctx_prior = _mv_ctx_prior_encoder(mv_up, p.sub("mv_ctx_prior_encoder"))
@@ -357,7 +359,7 @@ def inter_forward(sd, x_bl, x_el, dpb, shape_hr, scale, extras=False):
     mv_y_hat = mv_y_q + mv_means
     mv_hat = _mv_res_decoder(mv_y_hat, mv_ctx, p.sub("mv_decoder"))
 
-    c1, c2, c3, warp_frame = el_context(feature_bl, mv_hat, dpb["ref_frame_el"], dpb["ref_feature_el"], p)
+    c1, c2, c3, warp_frame = el_context(texture_bl, mv_hat, dpb["ref_frame_el"], dpb["ref_feature_el"], p)
 
     y = _res_encoder_el(x_el, c1, c2, c3, p.sub("res_encoder"))
     z = _prior_encoder(y, p.sub("res_prior_encoder"))

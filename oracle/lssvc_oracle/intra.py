@@ -128,11 +128,20 @@ def prior_fusion(hyper, layer, ctx3, p):
     return conv(t, p, "params_net.4")
 
 
-def intra_forward(sd, x_bl, x_el, shape_hr, extras=False):
-    """IntraSS.forward (IntraSS.py:137-172), pad_size=(0,0,0,0) as test.py:212 always passes."""
+def depad(feature, pad_size, p=1):
+    """get_depadded_feature (IntraSS.py:124-135, LSSVC_net.py:271-282): F.pad by pad_size / p, zeros in, negative = crop."""
+    if feature is None:
+        return None
+    return torch.nn.functional.pad(feature, tuple(int(v / p) for v in pad_size), mode="constant", value=0)
+
+
+def intra_forward(sd, x_bl, x_el, shape_hr, extras=False, pad_size=(0, 0, 0, 0)):
+    """IntraSS.forward (IntraSS.py:137-172); pad_size=(0,0,0,0) is what test.py:212 always passes."""
     p = Params(sd)
     bl = bl_layer_information(x_bl, p.sub("base_layer_model"))
     x_hat_bl, y_hat_bl = bl["x_hat"], bl["y_hat"]
+    x_hat_bl_full = x_hat_bl
+    x_hat_bl, y_hat_bl = depad(x_hat_bl, pad_size), depad(y_hat_bl, pad_size, 16)       # IntraSS.py:146-147
 
     tex = texture_resampler(x_hat_bl, p.sub("texture_resampler"), shape_hr)
     t1, t2, t3 = texture_extractor(tex, p.sub("texture_extractor"))
@@ -150,7 +159,7 @@ def intra_forward(sd, x_bl, x_el, shape_hr, extras=False):
     feature, x_hat = recon_generation(res_hat, c1, p.sub("recon_net"))
 
     out = {"bit_bl": bl["bits"].item(), "bit_el": bits_from_likelihoods(y_lik, z_lik).item(),
-           "x_hat_bl": x_hat_bl, "x_hat_el": x_hat, "feature_el": feature}
+           "x_hat_bl": x_hat_bl_full, "x_hat_el": x_hat, "feature_el": feature}
     if extras:
         out.update({"y_bl": bl["y"], "z_bl": bl["z"], "y_hat_bl": y_hat_bl, "ctx": (c1, c2, c3), "y": y, "z": z,
                     "scales": scales, "means": means, "y_hat": y_hat})

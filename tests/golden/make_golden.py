@@ -29,7 +29,11 @@ CASES = {
     "x2_128_ip_wide": (2, 128, 128, 64, 64, 2.0, 0.65, 1),
     "x1_5_192_ip": (2, 192, 192, 128, 128, 1.5, 0.6, 2),
     "x2_128x256_ip": (2, 128, 256, 64, 128, 2.0, 0.6, 3),
+    # a non-zero inter-layer pad_size (test.py always passes zeros; IntraSS.py:124-147, LSSVC_net.py:271-282,454-456): the BL
+    # codes a 128x128 picture of which the EL uses the top-left 64x64 (negative padding = crop; /16 on the latent grid)
+    "x2_128_ip_depad": (2, 128, 128, 128, 128, 2.0, 0.6, 4),
 }
+PAD_SIZE = {"x2_128_ip_depad": (0, -64, 0, -64)}
 
 
 def psnr(a, b):
@@ -49,8 +53,9 @@ def run_case(name, IntraSS, LSSVC_extend, imresize):
     pnet.load_dict(sd_p)
     pnet.eval()
     clip = synth_clip(frames, H, W, seed=seed)
+    pad_size = PAD_SIZE.get(name, (0, 0, 0, 0))
     out = {"x_el_u8": clip.numpy(), "meta": np.array([frames, H, W, h, w, seed], dtype=np.int64),
-           "scale_gain": np.array([scale, gain], dtype=np.float64)}
+           "scale_gain": np.array([scale, gain], dtype=np.float64), "pad_size": np.array(pad_size, dtype=np.int64)}
     x_bls = []
     dpb = None
     with torch.no_grad():
@@ -58,8 +63,8 @@ def run_case(name, IntraSS, LSSVC_extend, imresize):
             x_el = clip[t:t + 1].float() / 255.0
             x_bl = imresize(x_el, sizes=(h, w), kernel="cubic").clamp_(0, 1)
             x_bls.append(x_bl)
-            inet.set_scale_information(scale, (H, W), (0, 0, 0, 0))
-            pnet.set_scale_information(scale, (H, W), (0, 0, 0, 0))
+            inet.set_scale_information(scale, (H, W), pad_size)
+            pnet.set_scale_information(scale, (H, W), pad_size)
             if t == 0:
                 r = inet.encode_decode(x_bl, x_el, None, None, h, w, H, W)
                 dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None,

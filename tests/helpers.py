@@ -5,14 +5,15 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ("x2_128_ipp", "x2_128_ip_wide", "x1_5_192_ip", "x2_128x256_ip")
+CASES = ("x2_128_ipp", "x2_128_ip_wide", "x1_5_192_ip", "x2_128x256_ip", "x2_128_ip_depad")
 
 
 def load_case(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     frames, H, W, h, w, seed = (int(v) for v in z["meta"])
     scale, gain = (float(v) for v in z["scale_gain"])
-    return z, dict(frames=frames, H=H, W=W, h=h, w=w, seed=seed, scale=scale, gain=gain)
+    pad = tuple(int(v) for v in z["pad_size"]) if "pad_size" in z.files else (0, 0, 0, 0)
+    return z, dict(frames=frames, H=H, W=W, h=h, w=w, seed=seed, scale=scale, gain=gain, pad=pad)
 
 
 def psnr(a, b):

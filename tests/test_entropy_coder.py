@@ -130,3 +130,35 @@ def test_stream_length_is_the_tables_ideal_code_length():
     enc.encode_with_indexes(sym, idx, t)
     bits = len(enc.flush()) * 8
     assert ideal <= bits <= ideal * 1.0005 + 96, (bits, ideal)
+
+
+@pytest.mark.parametrize("seed,n,spread", [(5, 9, 3), (6, 30000, 40), (7, 30000, 20000)])
+def test_int16_planes_give_the_same_stream(seed, n, spread):
+    """The 16-bit entry points (lssvc_rans_encode_with_indexes_i16 / lssvc_rans_decode_stream_i16: what the product path
+    feeds from its pinned int16 staging buffer) write byte-identical streams to the int32 ones and decode them back, incl.
+    escapes up to the edges of the 16-bit range; a decoded symbol that does not fit 16 bits is an error, not a wrap."""
+    from lssvc_amd.entropy_coder import RansEncoder, RansDecoder
+    from lssvc_amd._lib import LssvcHipError
+    rng = np.random.default_rng(seed)
+    t = _tables(rng)
+    idx = rng.integers(0, t.cdfs.shape[0], n).astype(np.int32)
+    sym = rng.integers(-spread, spread + 30, n).astype(np.int32)
+    sym[:4] = (32767, -32768, 0, -1)[:min(4, n)]
+    e32, e16 = RansEncoder(), RansEncoder()
+    e32.reset(), e16.reset()
+    e32.encode_with_indexes(sym, idx, t)
+    e16.encode_with_indexes(sym.astype(np.int16), idx.astype(np.int16), t)
+    data = e32.flush()
+    assert data == e16.flush()
+    dec = RansDecoder()
+    dec.set_stream(data)
+    out = np.empty(n, dtype=np.int16)
+    got = dec.decode_stream(idx.astype(np.int16), t, out=out)
+    assert got is out and got.dtype == np.int16 and np.array_equal(got.astype(np.int32), sym)
+    # a symbol beyond 16 bits codes fine as int32 but must be refused by the 16-bit decoder
+    e32.reset()
+    big = np.array([40000], dtype=np.int32)
+    e32.encode_with_indexes(big, idx[:1], t)
+    dec.set_stream(e32.flush())
+    with pytest.raises(LssvcHipError):
+        dec.decode_stream(idx[:1].astype(np.int16), t)

@@ -268,7 +268,7 @@ def test_persistent_7x7_is_bit_identical_to_tiled(hip, cins, cout, H, W):
     assert (a.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 576, 960), (48, 48, 576, 960), (64, 64, 290, 350)])
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 576, 960), (48, 48, 576, 960), (64, 64, 290, 350), (64, 64, 1152, 1920)])
 def test_persistent_3x3_hand_off_is_race_free(hip, cin, cout, H, W):
     """The persistent kernel's producer and consumer waves hand LDS buffers over through per-wave slots, not barriers: the
     consumers run ahead of each other and of the producers by up to a phase. Forty launches with an input activation (the

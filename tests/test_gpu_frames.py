@@ -37,11 +37,11 @@ def test_frames_match_reference(case, precision):
     inet, pnet = _nets(m)
 
     def i_fn(xb, xe, hr):
-        inet.set_scale_information(m["scale"], hr, (0, 0, 0, 0))
+        inet.set_scale_information(m["scale"], hr, m["pad"])
         return inet.encode_decode(xb, xe, None, None, m["h"], m["w"], m["H"], m["W"])
 
     def p_fn(xb, xe, dpb, hr, s):
-        pnet.set_scale_information(s, hr, (0, 0, 0, 0))
+        pnet.set_scale_information(s, hr, m["pad"])
         return pnet.encode_decode(xb, xe, dpb, None, None, m["W"], m["H"], m["w"], m["h"])
 
     for t, r, raw, dpb, p_bl, p_el in replay(case, i_fn, p_fn, device=DEV):
@@ -121,6 +121,10 @@ def _gpu_gop_against_oracle(n, H, W, seed, gain, want_kernels=()):
     pnet.to(DEV).eval()
     inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
     pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+    if want_kernels:
+        # the first frame of a type is range-audited, which splits the fused DepthConvBlock kernels into their convs
+        # (bit-identical); this run must dispatch the kernels the benchmark is timed on
+        inet.range_audit = pnet.range_audit = False
     dg, seen = None, set()
     for t in range(n):
         xb, xe = x_bl[t:t + 1], clip[t:t + 1]

@@ -112,7 +112,9 @@ def test_graph_mode_host_time_per_frame():
           (e_issue * 1e3, g_issue * 1e3, e_wall * 1e3, g_wall * 1e3))
     print("256x256 I-frame (configs[0]): host issue eager %.2f ms -> graph %.2f ms; latency eager %.2f ms, graph %.2f ms" %
           (ei_issue * 1e3, gi_issue * 1e3, ei_wall * 1e3, gi_wall * 1e3))
-    assert g_issue < 2e-3 and g_issue < 0.5 * e_issue, (e_issue, g_issue)
+    # (a plan with parallel branches costs the host ~2 ms to launch -- hipGraphLaunch submits every branch to its own
+    # stream -- against ~0.2 ms for the single-stream I-frame plan; still a quarter of the eager issue time)
+    assert g_issue < 4e-3 and g_issue < 0.5 * e_issue, (e_issue, g_issue)
     assert g_wall <= 1.1 * e_wall, (e_wall, g_wall)
 
 

@@ -109,3 +109,48 @@ def test_harness_write_stream_and_intra_only(workdir):
     assert ws["ave_all_frame_bpp"] == pytest.approx(est["ave_all_frame_bpp"], rel=0.3)
     intra = _run(workdir, "out_i", ["--force_intra", "1", "--force_frame_num", "2"])["EL"]["SYN"]["seq0"]["i.pth"]
     assert intra["i_frame_num"] == 2 and intra["p_frame_num"] == 0 and intra["ave_p_frame_bpp"] == 0
+
+
+def test_harness_matches_the_references_run_test(tmp_path):
+    """The harness row pinned to the REFERENCE: tests/golden/make_harness_golden.py ran the reference's own `run_test`
+    (test.py:121-537: YUV reader, scipy colour conversion, padding, bicubic base layer, model calls, in-place clamp, RGB and
+    Y/U/V PSNRs, aggregation, filter_dict) on a 4-frame 4:2:0 clip + seeded checkpoints; the same clip and checkpoints go
+    through `python -m lssvc_amd.harness` here and the three result files are compared key by key. MS-SSIM (not computed:
+    null) and times are the only fields left out."""
+    from lssvc_amd.synth import synth_state_dict
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gdir, "harness_x2.json")) as f:
+        g = json.load(f)
+    z = np.load(os.path.join(gdir, "harness_x2_clip.npz"))
+    m = g["meta"]
+    os.makedirs(tmp_path / "data" / "seq0")
+    with open(tmp_path / "data" / "seq0" / "x1.yuv", "wb") as f:
+        for t in range(m["frames"]):
+            f.write(z["y"][t].tobytes() + z["u"][t].tobytes() + z["v"][t].tobytes())
+    torch.save(synth_state_dict("intra_ss", m["seed"], m["gain"]), tmp_path / "i.pth")
+    torch.save(synth_state_dict("lssvc_extend", m["seed"], m["gain"]), tmp_path / "p.pth")
+    cfg = {"SYN": {"test": 1, "base_path": str(tmp_path / "data"), "x1": {"width": m["width"], "height": m["height"]},
+                   "x2": {"width": m["width"] // 2, "height": m["height"] // 2}, "sequences": {"seq0": {"frames": m["frames"], "gop": m["gop"]}}}}
+    with open(tmp_path / "cfg.json", "w") as f:
+        json.dump(cfg, f)
+    res = _run(tmp_path, "out")
+    pix = {"BL": (m["height"] // 2) * (m["width"] // 2), "EL": m["height"] * m["width"], "FL": m["height"] * m["width"]}
+    checked = 0
+    for tag in ("BL", "EL", "FL"):
+        got, want = res[tag]["SYN"]["seq0"]["p.pth"], g[tag]
+        assert set(got) == set(want), (tag, set(got) ^ set(want))
+        for k, w in want.items():
+            if "msssim" in k or k.endswith("_time"):
+                continue
+            if k.endswith("_num"):
+                assert got[k] == w, (tag, k)
+            elif k.endswith("_bpp"):
+                assert abs(got[k] - w) <= 1e-5, (tag, k, got[k], w)                      # north-star bar on the rate
+            elif k.endswith("YUV_psnr"):
+                assert np.abs(np.array(got[k]) - np.array(w)).max() <= 1e-3, (tag, k, got[k], w)
+            else:                                                                        # *_psnr, *_rgb_psnr
+                assert abs(got[k] - w) <= (1e-4 if "rgb" in k else 1e-3), (tag, k, got[k], w)
+            checked += 1
+    assert checked >= 3 * 8
+    # frame order and types as test.py writes them
+    assert res["EL"]["SYN"]["seq0"]["p.pth"]["i_frame_num"] == 1 and g["frame_type"] == [0, 1, 1, 1]

@@ -646,3 +646,62 @@ def test_second_residual_equals_separate_add(hip, cin, cout, k, H, W):
         assert torch.equal(one, two), mode
     want = F.leaky_relu(F.conv2d(x, w, b, padding=k // 2), 0.1) + r1 + r2
     close(one, want)
+
+
+def test_fp16_range_audit_moves_saturating_layers_to_fp32():
+    """The f16x3 kernels saturate activations at +-65504 while staging them as fp16 hi/lo parts; the reference's fp32 convs
+    do not. A checkpoint whose FUNCTION is unchanged but whose intermediate tensor is 2^17 times larger (conv1 scaled by
+    2^17, conv2 by 2^-17 around a positively homogeneous LeakyReLU; exact powers of two) must therefore give the same
+    I-frame: the range audit of the first frame sees max |input| of g_a.0.conv2 beyond 2^15, moves that layer to the exact
+    fp32 kernel, warns, and recomputes. Without the audit the same checkpoint saturates silently and the frame is wrong."""
+    import warnings
+    from lssvc_amd import IntraSS, hip_ops
+    from lssvc_amd.synth import synth_state_dict, synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic
+    old_precision = hip_ops.CONV_PRECISION
+    hip_ops.set_conv_precision("f16x3")
+    try:
+        _range_audit_case(IntraSS, hip_ops, synth_state_dict, synth_clip, imresize_bicubic, warnings)
+    finally:
+        hip_ops.set_conv_precision(old_precision)
+
+
+def _range_audit_case(IntraSS, hip_ops, synth_state_dict, synth_clip, imresize_bicubic, warnings):
+    sd = synth_state_dict("intra_ss", 0, 0.6)
+    big = dict(sd)
+    K = 2.0 ** 17
+    big["base_layer_model.g_a.0.conv1.weight"] = sd["base_layer_model.g_a.0.conv1.weight"] * K
+    big["base_layer_model.g_a.0.conv1.bias"] = sd["base_layer_model.g_a.0.conv1.bias"] * K
+    big["base_layer_model.g_a.0.conv2.weight"] = sd["base_layer_model.g_a.0.conv2.weight"] / K
+    x_el = synth_clip(1, 128, 128, seed=1).float().div(255.0).to(DEV)
+    x_bl = imresize_bicubic(x_el.cpu(), (64, 64)).clamp_(0, 1).to(DEV)
+
+    def code(state, audit):
+        net = IntraSS.from_state_dict(state).to(DEV).eval()
+        net.range_audit = audit
+        net.set_scale_information(2.0, (128, 128), (0, 0, 0, 0))
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            r = net.encode_decode(x_bl, x_el, None, None)
+        return net, r, [str(m.message) for m in w]
+
+    ref_net, ref, ref_w = code(sd, True)
+    assert not ref_w and not ref_net.W.force_f32                      # the ordinary checkpoint stays entirely on f16x3
+    rep = next(iter(ref_net.audit_report.values()))
+    assert len(rep) > 50 and 0 < max(rep.values()) < hip_ops.F16_INPUT_LIMIT
+    net, got, msgs = code(big, True)
+    assert net.W.force_f32 == {"base_layer_model.g_a.0.conv2"}, net.W.force_f32
+    assert len(msgs) == 1 and "g_a.0.conv2" in msgs[0]
+    assert abs(got["bit_bl"] - ref["bit_bl"]) / (64 * 64) <= 1e-5 and abs(got["bit_el"] - ref["bit_el"]) / (128 * 128) <= 1e-5
+    assert (got["x_hat_el"] - ref["x_hat_el"]).abs().max().item() <= 2e-4
+    assert net.get_f32_layers() == ["base_layer_model.g_a.0.conv2"]
+    r2 = net.encode_decode(x_bl, x_el, None, None)                     # later frames: no audit, the layer stays on fp32
+    assert r2["bit_bl"] == got["bit_bl"] and torch.equal(r2["x_hat_el"], got["x_hat_el"])
+    fresh = IntraSS.from_state_dict(big).to(DEV).eval()                # a second process is handed the list instead of auditing
+    fresh.range_audit = False
+    fresh.set_f32_layers(net.get_f32_layers())
+    fresh.set_scale_information(2.0, (128, 128), (0, 0, 0, 0))
+    r3 = fresh.encode_decode(x_bl, x_el, None, None)
+    assert r3["bit_bl"] == got["bit_bl"] and torch.equal(r3["x_hat_el"], got["x_hat_el"])
+    _, blind, _ = code(big, False)                                     # audit off: silent saturation, visibly wrong
+    assert abs(blind["bit_bl"] - ref["bit_bl"]) / (64 * 64) > 1e-3 or (blind["x_hat_el"] - ref["x_hat_el"]).abs().max().item() > 1e-2

@@ -36,6 +36,7 @@ def _check_rate(bits, est):
     # With seeded random weights the analytic likelihoods and the 16-bit quantised, level-snapped tables differ
     # by several percent (the tight bound -- stream length vs the tables' own ideal code length -- is checked on
     # the coder itself in tests/test_entropy_coder.py); here only that the real rate tracks the estimate.
+    print("stream bits %d vs estimated %.1f (ratio %.4f)" % (bits, est, bits / max(est, 1.0)))
     assert abs(bits - est) <= 0.25 * est + 512, (bits, est)
 
 
@@ -104,9 +105,15 @@ class _Recorder:
         return b""
 
 
-def _agree(a, b, what, tol=2e-3):
-    bad = (a != b).mean()
-    assert bad <= tol, "%s: %.4f%% of entries differ" % (what, 100 * bad)
+def _agree(a, b, what, tol=2e-4):
+    """Equal up to rounding ties: a handful of entries (<= max(3, 0.02 %)) may differ, each by exactly one (a symbol whose
+    pre-round value sits within fp32 noise of .5, or a sigma within fp32 noise of a table-level boundary)."""
+    import numpy as np
+    d = np.asarray(a).astype(np.int64) - np.asarray(b).astype(np.int64)
+    n_bad = int(np.count_nonzero(d))
+    print("%s: %d of %d entries differ" % (what, n_bad, d.size))
+    assert n_bad <= max(3, tol * d.size) and (n_bad == 0 or np.abs(d).max() == 1), "%s: %d of %d entries differ, max |d| %d" % (
+        what, n_bad, d.size, np.abs(d).max())
 
 
 def test_symbol_and_index_planes_match_oracle():

@@ -117,3 +117,43 @@ def test_four_step_fold_bit_exact(step):
         sl = (slice(None), slice(ch * 32, (ch + 1) * 32), slice(r, None, 2), slice(c, None, 2))
         want[sl] = q[sl].int().float() + mean[sl]
     assert torch.equal(out.to_nchw().cpu(), want)
+
+
+def test_staged_int16_planes_equal_the_int32_planes():
+    """The product path's hand-off (hip_ops.SymbolStage: int16 planes written by lssvc_export_symbols_i16 into one device
+    buffer, one asynchronous copy into pinned memory, lssvc_import_symbols_i16 on the way back) carries exactly the
+    integers of the int32 planes, plain and folded; a symbol that does not fit 16 bits is refused loudly."""
+    from lssvc_amd import hip_ops as hip, tables
+    from lssvc_amd.inter import CHUNK_OF_MASK
+    g = torch.Generator().manual_seed(11)
+    C_, H, W = 128, 12, 20
+    q = torch.round(torch.randn(1, C_, H, W, generator=g) * 30)
+    q[0, 0, 0, :2] = torch.tensor([32767.0, -32768.0])
+    sig = _sigma_cases(tables.LAPLACE, C_ * H * W, 2)[torch.randperm(C_ * H * W, generator=g)].view(1, C_, H, W)
+    mean = torch.randn(1, C_, H, W, generator=g)
+    lap = tables.index_params(tables.LAPLACE, 0.0)
+    tq, ts, tm = hip.T.from_nchw(q.to(DEV)), hip.T.from_nchw(sig.to(DEV)), hip.T.from_nchw(mean.to(DEV))
+    st = hip.SymbolStage(torch.device(DEV)).begin(8 * C_ * H * W)
+    refs = [hip.export_symbols(tq, ts, lap, stage=st), hip.export_symbols(tq, None, stage=st)]
+    refs += [hip.export_symbols(tq, ts, lap, chunk_of_mask=CHUNK_OF_MASK[s], stage=st) for s in range(4)]
+    st.download(0, st.used)
+    want = [hip.export_symbols(tq, ts, lap), hip.export_symbols(tq, None)]
+    want += [hip.export_symbols(tq, ts, lap, chunk_of_mask=CHUNK_OF_MASK[s]) for s in range(4)]
+    for (r_sym, r_idx), (w_sym, w_idx) in zip(refs, want):
+        assert st.numpy(r_sym).dtype == np.int16
+        assert np.array_equal(st.numpy(r_sym).astype(np.int32), w_sym) and np.array_equal(st.numpy(r_idx).astype(np.int32), w_idx)
+    # back up: plain and folded, through the pinned buffer
+    out16, out32 = hip.T.zeros(H, W, C_, DEV), hip.T.zeros(H, W, C_, DEV)
+    hip.import_symbols(st.numpy(refs[0][0]), out16, mean=tm, stage=st)
+    hip.import_symbols(want[0][0], out32, mean=tm)
+    assert torch.equal(out16.to_nchw(), out32.to_nchw())
+    for s in range(4):
+        hip.import_symbols(st.numpy(refs[2 + s][0]), out16, mean=tm, chunk_of_mask=CHUNK_OF_MASK[s], stage=st)
+        hip.import_symbols(want[2 + s][0], out32, mean=tm, chunk_of_mask=CHUNK_OF_MASK[s])
+    assert torch.equal(out16.to_nchw(), out32.to_nchw())
+    # out of range: flagged on the device, refused on the host
+    q[0, 3, 2, 1] = 40000.0
+    st.begin(8 * C_ * H * W)
+    hip.export_symbols(hip.T.from_nchw(q.to(DEV)), None, stage=st)
+    with pytest.raises(RuntimeError):
+        st.download(0, st.used)

@@ -161,3 +161,33 @@ def test_collect_is_independent_of_job_order(tmp_path):
     assert a["x1_5"][1]["DS"]["seqA"] == {}
     with pytest.raises(RuntimeError):
         H.collect(args, cfg, res + res[:1])
+
+
+def test_colour_conversion_matches_reference_outputs(golden_dir):
+    """The same two conversions against what the REFERENCE's own functions returned for frame 0 of the harness clip
+    (tests/golden/make_harness_golden.py ran src/utils/functional.py:16-58 from /root/reference and stored the arrays)."""
+    z = np.load(os.path.join(golden_dir, "harness_x2_clip.npz"))
+    rgb, _, _, _ = H.yuv420_to_rgb(z["y"][0], z["u"][0], z["v"][0], "cpu")
+    assert np.abs(rgb[0].numpy() - z["rgb0"]).max() <= 2e-6
+    yy, cb, cr = H.rgb_to_yuv420(torch.from_numpy(z["rgb0"][None]))
+    assert np.abs(yy.numpy() - z["y_back"][0]).max() <= 1e-6
+    assert np.abs(cb.numpy() - z["uv_back"][0]).max() <= 1e-6 and np.abs(cr.numpy() - z["uv_back"][1]).max() <= 1e-6
+
+
+def test_aggregate_reproduces_the_references_result_dicts(golden_dir):
+    """aggregate() (test.py:329-535) fed with per-frame records rebuilt from the reference's own per-frame numbers must
+    give the reference's averaged fields: the I/P split, the bpp normalisation by the UNPADDED layer size, FL = BL + EL bits
+    over EL pixels."""
+    with open(os.path.join(golden_dir, "harness_x2.json")) as f:
+        g = json.load(f)
+    m = g["meta"]
+    pix_el, pix_bl = m["height"] * m["width"], (m["height"] // 2) * (m["width"] // 2)
+    recs = [{"frame": t, "type": g["frame_type"][t], "bits_bl": g["frame_bpp"]["BL"][t] * pix_bl, "bits_el": g["frame_bpp"]["EL"][t] * pix_el,
+             "rgb_psnr_bl": 0.0, "rgb_psnr_el": 0.0, "yuv_bl": (0.0, 0.0, 0.0), "yuv_el": (0.0, 0.0, 0.0),
+             "enc_bl": 0.0, "dec_bl": 0.0, "enc_el": 0.0, "dec_el": 0.0} for t in range(m["frames"])]
+    bl, el, fl = H.aggregate(recs, pix_bl, pix_el, 0.0)
+    for got, want in ((bl, g["BL"]), (el, g["EL"]), (fl, g["FL"])):
+        for k in ("i_frame_num", "p_frame_num"):
+            assert got[k] == want[k]
+        for k in ("ave_i_frame_bpp", "ave_p_frame_bpp", "ave_all_frame_bpp"):
+            assert got[k] == pytest.approx(want[k], rel=1e-6), k

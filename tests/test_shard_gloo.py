@@ -135,3 +135,49 @@ def test_harness_jobs_and_checkpoints_across_two_ranks(tmp_path):
     a, b = json.loads(logs2), json.loads(json.dumps(single, sort_keys=True))
     for ratio in a:                                    # test_time sums wall seconds per job: identical here (1.0 each)
         assert a[ratio] == b[ratio]
+
+
+# ---- failure path and non-tensor checkpoint entries -----------------------------------------------------------
+def _failing_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def loader(path):
+        assert dist.get_rank() == 0
+        sd = _ckpt(3)
+        sd["epoch"] = 12                                 # plain Python values must not crash rank 0 before the broadcast
+        sd["cfg"] = {"q": [1, 2]}
+        return sd
+
+    sd = broadcast_state_dicts(["p.pth"], dist, "cpu", loader)["p.pth"]
+    meta_ok = sd["epoch"] == 12 and sd["cfg"] == {"q": [1, 2]} and torch.equal(sd["a.bias"], _ckpt(3)["a.bias"])
+
+    def run(u):
+        if u == 3:                                       # unit 3 belongs to rank 1
+            raise ValueError("sequence ends before frame 7")
+        return u * 10
+
+    try:
+        run_sharded(list(range(6)), run, dist)
+        msg = None
+    except RuntimeError as e:                            # BOTH ranks get here, after the gather: nobody is left waiting
+        msg = str(e)
+    q.put((rank, meta_ok, msg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_unit_is_reported_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, meta_ok, msg in got:
+        assert meta_ok
+        assert msg is not None and "rank 1, unit 3" in msg and "sequence ends before frame 7" in msg and "1 of 6" in msg
