@@ -254,7 +254,7 @@ def config0_latency(device, graph=True, reps=30):
     from lssvc_amd.prepost import FramePrep
     from lssvc_amd.synth import synth_clip, synth_state_dict
     inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", 0, GAIN)).to(device).eval()
-    inet.set_graph_mode(graph)
+    inet.set_graph_mode(graph, alias_outputs=True)
     prep = FramePrep(device)
     x_bl, x_el, pad = prep.make_layers_rgb8(synth_clip(1, 256, 256, seed=1)[0].to(device), 2.0)
     inet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))
@@ -380,8 +380,8 @@ def config3_2160p(device, gop=12):
         pnet = LSSVC_extend()
         pnet.load_dict(synth_state_dict("lssvc_extend", 0, GAIN))
         pnet.to(device).eval()
-        inet.set_graph_mode(True)
-        pnet.set_graph_mode(True)
+        inet.set_graph_mode(True, alias_outputs=True)
+        pnet.set_graph_mode(True, alias_outputs=True)
         x_bls, x_els, pad, _ = build_inputs(device, seed=5, frames=gop)
         shape_hr = pad["HR_padded_size"]
         with torch.no_grad():
@@ -510,8 +510,8 @@ def main():
     del sds
 
     if not args.no_graph:
-        inet.set_graph_mode(True)                  # FramePlan: the per-frame launch sequence replayed as a hipGraph
-        pnet.set_graph_mode(True)
+        inet.set_graph_mode(True, alias_outputs=True)                  # FramePlan: the per-frame launch sequence replayed as a hipGraph
+        pnet.set_graph_mode(True, alias_outputs=True)
     hip_ops.reserve_device_memory(device)          # one hipMalloc up front instead of pool growth during the first GOPs
     t0 = time.time()
     x_bls, x_els, pad, clip_u8 = build_inputs(device, seed=rank, frames=args.frames)   # each rank codes its own GOP

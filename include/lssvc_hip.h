@@ -167,6 +167,10 @@ int lssvc_add(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, v
 int lssvc_copy(const lssvc_view *in, const lssvc_view *out, void *stream);
 /* out = lrelu(in, slope) (the stand-alone nn.LeakyReLU between blocks, e.g. dmc_net.py:178). */
 int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float slope, void *stream);
+/* Zero `nbytes` of device memory / clamp n floats in place (what torch.zeros and the caller's `clamp_(0, 1)` of the
+ * reconstructions, test.py:249-250, are for a caller without PyTorch; compiled frame plans record these as launches). */
+int lssvc_fill_zero(void *ptr, int64_t nbytes, void *stream);
+int lssvc_clamp_inplace(float *x, int64_t n, float lo, float hi, void *stream);
 /* Range audit of the f16x3 conv mode: *out_max = max(*out_max, max |x| over the view) as a non-negative float (NaN / Inf
  * give +Inf); the caller zeroes it. The f16x3 kernels split activations into fp16 hi/lo parts and saturate at +-65504 while
  * staging (GDN squares first), which the reference's fp32 convs (e.g. src/IntraModules/gdn.py:29-44) do not: the host runs
@@ -317,6 +321,36 @@ int lssvc_rans_decode_stream_i16(void *dec, const int16_t *indexes, int64_t n, c
 
 /* cdf_out has n + 1 entries */
 int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, uint32_t *cdf_out);
+
+/* ---- engine: compiled frame plans (csrc/plan_runtime.cpp) ------------------------------------------------
+ * Frame-level entry points for a caller without Python or PyTorch (last row). They replace, per frame,
+ * IntraSS.encode_decode(bin_path=None) = IntraSS.forward (src/models/IntraSS.py:245-249,137-172) and
+ * LSSVC.encode_decode(output_path_el=None) = LSSVC.forward_one_frame (src/models/LSSVC_net.py:172-185,445-528).
+ * A plan file holds ONE frame type at ONE size for ONE checkpoint: the prepared weights and the fixed sequence of library
+ * launches the Python front end issues for it (lssvc_amd/plan_compiler.py: compile_iframe / compile_pframe). The engine owns
+ * the device memory, the side streams and the hipGraph it captures from the sequence (hipStreamBeginCapture inside the
+ * library, after one eager pass). All tensors are fp32 NCHW, batch 1, as at the reference's model API; input / output
+ * pointers may be device or host memory (hipMemcpyDefault); an output pointer may be NULL if the caller does not want it.
+ * The caller owns the DPB between frames, exactly as with the reference: clamp the two reconstructions to [0, 1]
+ * (test.py:249-250; lssvc_clamp_inplace) and hand them back with the two features as the next frame's references. */
+void *lssvc_engine_create(int32_t device);
+void lssvc_engine_destroy(void *engine);
+int lssvc_engine_load_intra(void *engine, const char *iframe_plan_path);
+/* first_p: the plan of the first P-frame after an I-frame (no BL reference feature, 64-channel EL reference feature),
+ * steady_p: every later P-frame of the GOP */
+int lssvc_engine_load_inter(void *engine, const char *first_p_plan_path, const char *steady_p_plan_path);
+/* set_scale_information (IntraSS.py:229-232, LSSVC_net.py:266-269): checks the loaded plans were compiled for this
+ * scale and padded EL size; plans are size-specific */
+int lssvc_engine_set_scale(void *engine, float scale, int32_t H_el_padded, int32_t W_el_padded);
+/* bits[0] = bit_bl, bits[1] = bit_el (estimated, as the reference's result dict) */
+int lssvc_engine_iframe(void *engine, const float *x_bl, const float *x_el, double bits[2], float *x_hat_bl, float *x_hat_el,
+                        float *feature_el, void *stream);
+/* ref_feature_bl NULL selects the first-P plan. Outputs = the reference's result['dpb'] (un-clamped) + mv_hat + warp_frame */
+int lssvc_engine_pframe(void *engine, const float *x_bl, const float *x_el, const float *ref_frame_bl, const float *ref_frame_el,
+                        const float *ref_feature_bl, const float *ref_feature_el, double bits[2], float *recon_bl, float *feature_bl,
+                        float *recon_el, float *feature_el, float *mv_hat, float *warp_frame, void *stream);
+/* which: 0 intra, 1 first-P, 2 steady-P -> launches, streams, arena bytes, weight bytes, H, W */
+int lssvc_engine_plan_info(void *engine, int32_t which, int64_t *out6);
 
 /* Runtime tuning switches (each also reads an environment variable at first use):
  *   "f16x3_persist"            1/0   use the persistent warp-specialised 3x3 kernel (LSSVC_F16X3_PERSIST)

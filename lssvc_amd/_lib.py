@@ -76,6 +76,8 @@ SIGNATURES = {
     "lssvc_copy": (C.c_int, [VP, VP, C.c_void_p]),
     "lssvc_lrelu": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
     "lssvc_absmax": (C.c_int, [VP, C.c_void_p, C.c_void_p]),
+    "lssvc_fill_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "lssvc_clamp_inplace": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
     "lssvc_offset_diversity": (C.c_int, [VP, VP, VP, C.c_void_p, C.c_void_p, VP, C.c_void_p]),
     "lssvc_nchw_to_nhwc": (C.c_int, [C.c_void_p, VP, C.c_void_p]),
     "lssvc_nhwc_to_nchw": (C.c_int, [VP, C.c_void_p, C.c_void_p]),
@@ -110,6 +112,14 @@ SIGNATURES = {
     "lssvc_rans_decode_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, TP, C.c_void_p]),
     "lssvc_rans_decode_stream_i16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, TP, C.c_void_p]),
     "lssvc_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lssvc_engine_create": (C.c_void_p, [C.c_int32]),
+    "lssvc_engine_destroy": (None, [C.c_void_p]),
+    "lssvc_engine_load_intra": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "lssvc_engine_load_inter": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "lssvc_engine_set_scale": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, C.c_int32]),
+    "lssvc_engine_iframe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lssvc_engine_pframe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.POINTER(C.c_double)] + [C.c_void_p] * 7),
+    "lssvc_engine_plan_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "lssvc_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
     "lssvc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "lssvc_last_error": (C.c_char_p, []),

@@ -567,6 +567,26 @@ __global__ void absmax_kernel(V x, unsigned int *out_max, long long total) {
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out_max, m);
 }
 
+// ---- plumbing the compiled frame plans need as library calls (csrc/plan_runtime.cpp replays only C-ABI launches) ----------
+__global__ void clamp_flat_kernel(float *x, float lo, float hi, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+extern "C" int lssvc_fill_zero(void *ptr, int64_t nbytes, void *stream) {
+    LSSVC_CHECK(ptr && nbytes >= 0, "fill_zero: bad arguments");
+    if (nbytes) LSSVC_HIP(hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int lssvc_clamp_inplace(float *x, int64_t n, float lo, float hi, void *stream) {
+    LSSVC_CHECK(x && n >= 0, "clamp_inplace: bad arguments");
+    if (n == 0) return 0;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(clamp_flat_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, lo, hi,
+                       (long long)n);
+    return launch_status("clamp_inplace");
+}
+
 extern "C" int lssvc_absmax(const lssvc_view *x, float *out_max, void *stream) {
     LSSVC_CHECK(view_ok(x) && out_max, "absmax: bad arguments");
     const long long total = (long long)x->H * x->W * x->C;

@@ -355,9 +355,9 @@ def _load_nets(job, device):
             p_net.load_dict(_checkpoint(job["p_path"]))
             p_net = p_net.to(device).eval()
         if os.environ.get("LSSVC_GRAPH", "0") == "1" and not job["write_stream"]:
-            i_net.set_graph_mode(True)               # hipGraph frame plans (intra.FramePlan)
+            i_net.set_graph_mode(True, alias_outputs=True)               # hipGraph frame plans (intra.FramePlan)
             if p_net is not None:
-                p_net.set_graph_mode(True)
+                p_net.set_graph_mode(True, alias_outputs=True)
         if job["write_stream"]:
             if p_net is not None:
                 p_net.update(force=True)

@@ -60,8 +60,16 @@ def stream_ptr():
 # only safe if every other stream that touched the block has been joined since. Every buffer touched by a launch inside
 # a branch is therefore kept alive until the Fork is closed (end of the frame body, after all joins).
 MULTI_STREAM = _os.environ.get("LSSVC_STREAMS", "1") == "1"
-_KEEP = None              # buffers touched while a branch is open (None outside branches)
-_SIDE_STREAMS = {}
+import threading as _threading
+
+
+class _Tls(_threading.local):
+    keep = None           # buffers touched while a branch is open (None outside branches); per host thread, because several
+    #                       GOPs may be in flight on one GPU, each coded by its own thread on its own stream (bench.py)
+
+
+_TLS = _Tls()
+_SIDE_STREAMS = {}        # (device, main stream) -> its side streams
 
 
 class _Branch:
@@ -69,22 +77,22 @@ class _Branch:
         self.fork, self.i, self.ctx = fork, i, None
 
     def __enter__(self):
-        global _KEEP
         f = self.fork
         if f.enabled:
-            assert _KEEP is None, "branches do not nest"
+            assert _TLS.keep is None, "branches do not nest"
             s = f.streams[self.i]
             s.wait_stream(torch.cuda.current_stream())
+            if PLAN_RECORDER is not None:
+                PLAN_RECORDER.wait(s.cuda_stream, torch.cuda.current_stream().cuda_stream)
             self.ctx = torch.cuda.stream(s)
             self.ctx.__enter__()
-            _KEEP = f.keep
+            _TLS.keep = f.keep
             f.open.add(self.i)
         return self
 
     def __exit__(self, *exc):
-        global _KEEP
         if self.fork.enabled:
-            _KEEP = None
+            _TLS.keep = None
             self.ctx.__exit__(*exc)
         return False
 
@@ -99,7 +107,8 @@ class Fork:
         self.enabled = MULTI_STREAM if enabled is None else bool(enabled)
         self.keep, self.open = [], set()
         if self.enabled:
-            key = (device.index, n)
+            main = torch.cuda.current_stream(device)
+            key = (device.index, n, main.cuda_stream if not torch.cuda.is_current_stream_capturing() else "capture")
             if key not in _SIDE_STREAMS:
                 _SIDE_STREAMS[key] = [torch.cuda.Stream(device) for _ in range(n)]
             self.streams = _SIDE_STREAMS[key]
@@ -110,6 +119,8 @@ class Fork:
     def join(self, i):
         if self.enabled and i in self.open:
             torch.cuda.current_stream().wait_stream(self.streams[i])
+            if PLAN_RECORDER is not None:
+                PLAN_RECORDER.wait(torch.cuda.current_stream().cuda_stream, self.streams[i].cuda_stream)
             self.open.discard(i)
 
     def close(self):
@@ -159,6 +170,10 @@ class RangeAudit:
         return bad
 
 
+ARENA = None                  # plan_compiler.Arena while a frame plan is being recorded
+PLAN_RECORDER = None          # plan_compiler.Recorder while a frame plan is being recorded (fork / join edges are reported to it)
+
+
 class T:
     """An H x W x C fp32 view (batch 1) with pixel pitch `ld` into a flat torch buffer."""
     __slots__ = ("buf", "H", "W", "C", "ld", "off", "_v")
@@ -169,11 +184,15 @@ class T:
 
     @staticmethod
     def empty(H, W, Cc, device):
+        if ARENA is not None:                    # a frame plan is being compiled (plan_compiler.py): activations from ONE arena
+            return T(ARENA.alloc_f32(H * W * Cc), H, W, Cc, Cc)
         return T(torch.empty(H * W * Cc, dtype=torch.float32, device=device), H, W, Cc, Cc)
 
     @staticmethod
     def zeros(H, W, Cc, device):
-        return T(torch.zeros(H * W * Cc, dtype=torch.float32, device=device), H, W, Cc, Cc)
+        t = T.empty(H, W, Cc, device)
+        check(lib.lssvc_fill_zero(C.c_void_p(t.buf.data_ptr()), 4 * H * W * Cc, stream_ptr()))     # a library launch, so plans see it
+        return t
 
     @property
     def device(self):
@@ -181,14 +200,16 @@ class T:
 
     @property
     def v(self):
-        if _KEEP is not None:
-            _KEEP.append(self.buf)          # touched by a side-stream launch: alive until the frame's Fork closes
+        k = _TLS.keep
+        if k is not None:
+            k.append(self.buf)              # touched by a side-stream launch: alive until the frame's Fork closes
         return self._v
 
     @property
     def ref(self):
-        if _KEEP is not None:
-            _KEEP.append(self.buf)
+        k = _TLS.keep
+        if k is not None:
+            k.append(self.buf)
         return C.byref(self._v)
 
     def slice(self, c0, c1):

@@ -466,6 +466,7 @@ class LSSVC_extend(_HostModel):
             ins = {k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()}
             r = self._with_range_audit(self._frame_key(tensors), lambda: self._frame_body(ins))
         self.last_issue_s = time.perf_counter() - t_issue        # host time to put the frame on the stream (no GPU wait)
+        r = {k: self._own(v) for k, v in r.items()}
         dpb = {"ref_frame_bl": r["recon_bl"].to_nchw(remember=True), "ref_feature_bl": r["feature_bl"].to_nchw(remember=True),
                "ref_frame_el": r["recon_el"].to_nchw(remember=True), "ref_feature_el": r["feature_el"].to_nchw(remember=True)}
         out = {"dpb": dpb, "mv_hat": r["mv_hat"].to_nchw(), "warp_frame": r["warp_frame"].to_nchw(),

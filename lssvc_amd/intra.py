@@ -80,6 +80,7 @@ class _HostModel:
         self._tables = None
         self._medians = {}
         self.graph_mode = _os.environ.get("LSSVC_GRAPH", "0") == "1"
+        self.alias_outputs = _os.environ.get("LSSVC_GRAPH_ALIAS", "0") == "1"
         self._plans = {}
         self.last_issue_s = 0.0
         self.range_audit = ops.RANGE_AUDIT_DEFAULT     # audit the first frame of every type for fp16 range (hip_ops.RangeAudit)
@@ -87,13 +88,22 @@ class _HostModel:
         self.audit_report = {}    # frame-type key -> {layer: max |input|} of the audited frame
         self.taps = None          # diagnostics: set to a dict and every encoder pass stores its quantised latents in it
 
-    def set_graph_mode(self, on=True):
-        """Estimate-mode frames through captured hipGraphs (FramePlan). Results are bit-identical to the eager path;
-        returned tensors then alias plan-owned memory that the next call of the same frame type overwrites."""
+    def set_graph_mode(self, on=True, alias_outputs=False):
+        """Estimate-mode frames through captured hipGraphs (FramePlan). Results are bit-identical to the eager path. The
+        returned tensors are copies the caller owns, as with the reference; alias_outputs=True hands out views of the
+        plan's own memory instead, which the next call of the same frame type overwrites (no copy: for loops like
+        test.py's that consume a frame's outputs before coding the next frame)."""
         self.graph_mode = bool(on)
+        self.alias_outputs = bool(alias_outputs)
         if not on:
             self._plans = {}
         return self
+
+    def _own(self, t):
+        """A frame output for the caller: in graph mode (unless alias_outputs) a copy outside the plan's memory."""
+        if not self.graph_mode or self.alias_outputs:
+            return t
+        return ops.copy(t, T.empty(t.H, t.W, t.C, t.device))
 
     MAX_PLANS = 4          # I / first-P / steady-P of one size (+1): a plan owns a hipGraph memory pool of several GiB at 1080p
 
@@ -383,7 +393,7 @@ class IntraSS(_HostModel):
             ins = {k: T.from_nchw(v) for k, v in tensors.items()}
             r = self._with_range_audit(("i", tuple(x_bl.shape), tuple(x_el.shape)), lambda: self._frame_body(ins))
         self.last_issue_s = _time.perf_counter() - t_issue       # host time to put the frame on the stream (no GPU wait)
-        x_hat_bl, x_hat, feature = r["x_hat_bl"], r["x_hat_el"], r["feature_el"]
+        x_hat_bl, x_hat, feature = self._own(r["x_hat_bl"]), self._own(r["x_hat_el"]), self._own(r["feature_el"])
         out = {"x_hat_bl": x_hat_bl.to_nchw(remember=True), "x_hat_el": x_hat.to_nchw(remember=True), "feature_el": feature.to_nchw(remember=True)}
         s = self.slots.fetch()
         out["bit_bl"] = (s[0] + s[1]) / (-math.log(2))

@@ -1,0 +1,304 @@
+"""Compile a frame plan: the Python model objects are the FRONT END, a plan file is what the C++ runtime executes.
+
+SURVEY 8b's last row asks for engine-level entry points a caller without Python can use (`lssvc_engine_create / load_* /
+iframe / pframe`, owning the weights and the captured graph). The estimate-mode forward of a frame type at a given size is a
+FIXED sequence of C-ABI launches, so instead of restating the ~1000 lines of graph logic in C++ this
+module records that sequence once while the front end runs it for real:
+
+  * every activation is taken from ONE arena (hip_ops.ARENA: first-fit with lifetime reuse, same stream rules as PyTorch's
+    caching allocator), so each device pointer in a launch is (region, offset): the arena, the prepared weight tensors
+    (lssvc_amd.weights layouts, stored in the file), zero-initialised scratch (bit accumulators, reduction workspaces), or one
+    of the caller's input / output buffers;
+  * a launch is stored as (function name, stream index, arguments), structs as byte images with their pointer fields listed
+    for rebasing; fork / join edges between the side streams of a frame (hip_ops.Fork) are stored as waits.
+
+csrc/plan_runtime.cpp loads such a file, allocates the regions, rebases the pointers, replays the launches (once eagerly,
+then as a hipGraph captured inside the library with hipStreamBeginCapture) and exposes lssvc_engine_* -- no Python, no torch.
+What stays in the front end: checkpoint validation, the weight re-layout (weights.py) and the graph logic, i.e. everything
+that runs once per (checkpoint, frame size); a plan is specific to that pair, like an engine file of any inference runtime.
+"""
+import ctypes as C
+import struct
+import weakref
+
+import torch
+
+from . import _lib
+from . import hip_ops as ops
+
+MAGIC = b"LSSVCPL1"
+REGION_ARENA, REGION_WEIGHTS, REGION_SCRATCH, REGION_INPUT, REGION_OUTPUT = range(5)
+TAG_NULL, TAG_PTR, TAG_STRUCT, TAG_F32, TAG_I32, TAG_I64, TAG_I32ARRAY, TAG_STREAM = range(8)
+FN_WAIT = "__wait__"
+
+
+class Arena:
+    """One device buffer, first-fit allocation with coalescing; a block returns to the free list when the tensor view that
+    was handed out dies (the same moment PyTorch's allocator would recycle it, so the stream-ordering argument of
+    hip_ops.Fork carries over unchanged)."""
+
+    def __init__(self, nbytes, device):
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        self.free = [(0, int(nbytes))]
+        self.peak = 0
+
+    def alloc_f32(self, n):
+        need = (4 * n + 255) // 256 * 256
+        for i, (off, size) in enumerate(self.free):
+            if size >= need:
+                if size == need:
+                    self.free.pop(i)
+                else:
+                    self.free[i] = (off + need, size - need)
+                self.peak = max(self.peak, off + need)
+                t = self.buf[off:off + 4 * n].view(torch.float32)
+                weakref.finalize(t, self._release, off, need)
+                return t
+        raise RuntimeError("plan arena of %d bytes is too small" % self.buf.numel())
+
+    def _release(self, off, size):
+        self.free.append((off, size))
+        self.free.sort()
+        merged = []
+        for o, s in self.free:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1] = (merged[-1][0], merged[-1][1] + s)
+            else:
+                merged.append((o, s))
+        self.free = merged
+
+
+def _pointer_fields(ctype, base=0):
+    """[(byte offset, ...)] of every c_void_p inside a ctypes Structure type, nested structs and arrays included."""
+    out = []
+    for name, ft in ctype._fields_:
+        off = base + getattr(ctype, name).offset
+        if ft is C.c_void_p:
+            out.append(off)
+        elif isinstance(ft, type) and issubclass(ft, C.Structure):
+            out += _pointer_fields(ft, off)
+        elif isinstance(ft, type) and issubclass(ft, C.Array) and issubclass(ft._type_, C.Structure):
+            for k in range(ft._length_):
+                out += _pointer_fields(ft._type_, off + k * C.sizeof(ft._type_))
+    return out
+
+
+_PTR_FIELDS = {}
+
+
+class Recorder:
+    def __init__(self, device, arena_bytes, weight_stores, scratch, inputs, outputs):
+        """scratch / inputs / outputs: {name: tensor}; weight_stores: the models' WeightStore objects."""
+        self.device = device
+        self.arena = Arena(arena_bytes, device)
+        self.regions = [{"kind": REGION_ARENA, "name": "arena", "ptr": self.arena.buf.data_ptr(), "nbytes": self.arena.buf.numel(), "data": None}]
+        for kind, group in ((REGION_SCRATCH, scratch), (REGION_INPUT, inputs), (REGION_OUTPUT, outputs)):
+            for name, t in group.items():
+                self.regions.append({"kind": kind, "name": name, "ptr": t.data_ptr(), "nbytes": t.numel() * t.element_size(), "data": None,
+                                     "shape": tuple(t.shape)})
+        self.weight_stores = weight_stores
+        self._weight_regions = {}
+        self.launches = []
+        self.streams = {}
+        self._orig = {}
+
+    # ---- pointers ------------------------------------------------------------------------------------------------
+    def _resolve(self, p):
+        for i, r in enumerate(self.regions):
+            if r["ptr"] <= p < r["ptr"] + max(r["nbytes"], 1):
+                return i, p - r["ptr"]
+        for ws in self.weight_stores:                      # a prepared weight tensor (registered by WeightStore._dev)
+            for ptr, (nbytes, host) in ws.regions.items():
+                if ptr <= p < ptr + max(nbytes, 1):
+                    if ptr not in self._weight_regions:
+                        self.regions.append({"kind": REGION_WEIGHTS, "name": "w%d" % len(self._weight_regions), "ptr": ptr, "nbytes": nbytes,
+                                             "data": host})
+                        self._weight_regions[ptr] = len(self.regions) - 1
+                    return self._weight_regions[ptr], p - ptr
+        raise RuntimeError("launch uses device memory at 0x%x that is neither arena, weights, scratch nor a declared input/output" % p)
+
+    def _stream(self, handle):
+        h = int(handle or 0)
+        if h not in self.streams:
+            self.streams[h] = len(self.streams)
+        return self.streams[h]
+
+    def wait(self, waiter, signaler):
+        """stream `waiter` waits for everything issued so far on `signaler` (a fork or a join of hip_ops.Fork)."""
+        self.launches.append((FN_WAIT, self._stream(waiter), [(TAG_I32, self._stream(signaler))]))
+
+    # ---- launches ------------------------------------------------------------------------------------------------
+    def _encode(self, name, args):
+        restype, argtypes = _lib.SIGNATURES[name]
+        enc, stream = [], 0
+        last_ptr = max(i for i, t in enumerate(argtypes) if t is C.c_void_p)
+        for i, (a, t) in enumerate(zip(args, argtypes)):
+            if t is C.c_void_p:
+                v = a.value if isinstance(a, C.c_void_p) else a
+                if i == last_ptr:                              # every launching entry point ends with `void *stream`
+                    stream = self._stream(v)
+                    enc.append((TAG_STREAM, 0))
+                elif v is None or v == 0:
+                    enc.append((TAG_NULL, 0))
+                else:
+                    enc.append((TAG_PTR,) + self._resolve(int(v)))
+            elif t is C.c_float:
+                enc.append((TAG_F32, float(a)))
+            elif t is C.c_int32:
+                enc.append((TAG_I32, int(a)))
+            elif t is C.c_int64:
+                enc.append((TAG_I64, int(a)))
+            elif t is C.POINTER(C.c_int32):
+                enc.append((TAG_I32ARRAY, [int(x) for x in a]))
+            else:                                              # POINTER(struct): byref(obj) or a pointer instance
+                obj = a._obj if hasattr(a, "_obj") else a.contents
+                st = type(obj)
+                if st not in _PTR_FIELDS:
+                    _PTR_FIELDS[st] = _pointer_fields(st)
+                blob = bytearray(C.string_at(C.addressof(obj), C.sizeof(obj)))
+                fixes = []
+                for off in _PTR_FIELDS[st]:
+                    (p,) = struct.unpack_from("<Q", blob, off)
+                    if p:
+                        fixes.append((off,) + self._resolve(p))
+                        struct.pack_into("<Q", blob, off, 0)
+                enc.append((TAG_STRUCT, bytes(blob), fixes))
+        return stream, enc
+
+    def __enter__(self):
+        lib = _lib.lib
+        for name in _lib.SIGNATURES:
+            restype, argtypes = _lib.SIGNATURES[name]
+            if restype is not C.c_int or not argtypes or argtypes[-1] is not C.c_void_p or not name.startswith("lssvc_") \
+                    or name.startswith("lssvc_rans") or name in ("lssvc_pmf_to_quantized_cdf", "lssvc_conv2d_variant"):
+                continue
+            fn = getattr(lib, name)
+            self._orig[name] = fn
+
+            def wrapper(*args, _fn=fn, _name=name):
+                stream, enc = self._encode(_name, args)
+                self.launches.append((_name, stream, enc))
+                return _fn(*args)
+            setattr(lib, name, wrapper)
+        ops.ARENA = self.arena
+        ops.PLAN_RECORDER = self
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(_lib.lib, name, fn)
+        ops.ARENA = None
+        ops.PLAN_RECORDER = None
+        return False
+
+    # ---- file ------------------------------------------------------------------------------------------------------
+    def save(self, path, kind, scale, shape_hr, meta=()):
+        """meta: extra (name, int) pairs, e.g. channel counts of optional inputs."""
+        def s48(x):
+            b = x.encode()[:47]
+            return b + b"\0" * (48 - len(b))
+        out = bytearray()
+        out += MAGIC
+        out += struct.pack("<5I", len(self.regions), len(self.launches), max(len(self.streams), 1), len(meta), 0)
+        out += struct.pack("<d2i", float(scale), int(shape_hr[0]), int(shape_hr[1]))
+        out += s48(kind)
+        for name, v in meta:
+            out += s48(name) + struct.pack("<q", int(v))
+        for r in self.regions:
+            nbytes = self.arena.peak if r["kind"] == REGION_ARENA else r["nbytes"]
+            shape = list(r.get("shape", ())) + [0] * 4
+            out += struct.pack("<IQ4q", r["kind"], nbytes, *shape[:4]) + s48(r["name"])
+        for name, stream, args in self.launches:
+            out += s48(name) + struct.pack("<2I", stream, len(args))
+            for a in args:
+                tag = a[0]
+                out += struct.pack("<I", tag)
+                if tag == TAG_PTR:
+                    out += struct.pack("<IQ", a[1], a[2])
+                elif tag == TAG_STRUCT:
+                    out += struct.pack("<2I", len(a[1]), len(a[2])) + a[1] + b"\0" * (-len(a[1]) % 8)
+                    for off, reg, roff in a[2]:
+                        out += struct.pack("<2IQ", off, reg, roff)
+                elif tag == TAG_F32:
+                    out += struct.pack("<f", a[1])
+                elif tag == TAG_I32:
+                    out += struct.pack("<i", a[1])
+                elif tag == TAG_I64:
+                    out += struct.pack("<q", a[1])
+                elif tag == TAG_I32ARRAY:
+                    out += struct.pack("<I", len(a[1])) + struct.pack("<%di" % len(a[1]), *a[1])
+        with open(path, "wb") as f:
+            f.write(out)
+            for r in self.regions:                              # weight payloads, in region order, 256-byte aligned
+                if r["kind"] == REGION_WEIGHTS:
+                    pad = -f.tell() % 256
+                    f.write(b"\0" * pad)
+                    f.write(r["data"].contiguous().cpu().numpy().tobytes())
+        return {"launches": len(self.launches), "regions": len(self.regions), "arena_bytes": self.arena.peak, "streams": len(self.streams)}
+
+
+def _record(model, body_inputs, run, outputs, path, kind, arena_gib, meta=()):
+    """Run `run()` (which must issue the frame through `model` from the NCHW tensors in body_inputs and write the NCHW
+    results into the tensors in `outputs`) once eagerly to warm everything up, then once under the recorder."""
+    device = model.device
+    assert not model.graph_mode, "compile plans from a model in eager mode"
+    run()                                                   # weights laid out, LDS granted, range audit done
+    torch.cuda.synchronize(device)
+    scratch = {"bits": model.slots.vals}
+    for i, ws in enumerate(list(model.slots._ws.values()) + list(model.slots._free)):
+        scratch["reduce_ws%d" % i] = ws
+    rec = Recorder(device, int(arena_gib * 2 ** 30), [model.W], scratch, body_inputs, outputs)
+    with rec:
+        run()
+    torch.cuda.synchronize(device)
+    info = rec.save(path, kind, model.scale_factor, model.shape_hr, meta)
+    return info
+
+
+def compile_iframe(inet, x_bl, x_el, path, arena_gib=None):
+    """Plan of IntraSS.forward (estimate mode) for frames shaped like x_bl / x_el (NCHW fp32, contiguous, on the device).
+    Inputs of the plan: x_bl, x_el. Outputs: x_hat_bl, x_hat_el, feature_el (NCHW) and the four bit accumulators."""
+    from .hip_ops import T
+    H, W = inet.shape_hr
+    arena_gib = arena_gib if arena_gib is not None else max(0.25, 6.0 * H * W / (1152.0 * 1920.0))
+    dev = inet.device
+    outs = {"x_hat_bl": torch.empty(1, 3, x_bl.shape[2], x_bl.shape[3], device=dev), "x_hat_el": torch.empty(1, 3, H, W, device=dev),
+            "feature_el": torch.empty(1, 64, H, W, device=dev)}
+    ins = {"x_bl": x_bl.contiguous(), "x_el": x_el.contiguous()}
+
+    def run():
+        r = inet._frame_body({k: T.from_nchw(v) for k, v in ins.items()})
+        for k in outs:
+            _lib.check(_lib.lib.lssvc_nhwc_to_nchw(r[k].ref, C.c_void_p(outs[k].data_ptr()), ops.stream_ptr()))
+
+    info = _record(inet, ins, run, outs, path, "iframe", arena_gib)
+    return info, outs
+
+
+def compile_pframe(pnet, x_bl, x_el, dpb, path, arena_gib=None):
+    """Plan of LSSVC.forward_one_frame (estimate mode). The DPB decides the frame type: ref_feature_bl None and a 64-channel
+    ref_feature_el give the first-P plan (after an I-frame), otherwise the steady-P plan. All inputs NCHW contiguous."""
+    from .hip_ops import T
+    H, W = pnet.shape_hr
+    arena_gib = arena_gib if arena_gib is not None else max(0.5, 14.0 * H * W / (1152.0 * 1920.0))
+    dev = pnet.device
+    ins = {"x_bl": x_bl.contiguous(), "x_el": x_el.contiguous(), "ref_frame_bl": dpb["ref_frame_bl"].contiguous(),
+           "ref_frame_el": dpb["ref_frame_el"].contiguous(), "ref_feature_el": dpb["ref_feature_el"].contiguous()}
+    if dpb["ref_feature_bl"] is not None:
+        ins["ref_feature_bl"] = dpb["ref_feature_bl"].contiguous()
+    h, w = x_bl.shape[2], x_bl.shape[3]
+    outs = {"recon_bl": torch.empty(1, 3, h, w, device=dev), "feature_bl": torch.empty(1, 64, h, w, device=dev),
+            "recon_el": torch.empty(1, 3, H, W, device=dev), "feature_el": torch.empty(1, 48, H, W, device=dev),
+            "mv_hat": torch.empty(1, 2, H, W, device=dev), "warp_frame": torch.empty(1, 3, H, W, device=dev)}
+
+    def run():
+        t = {k: T.from_nchw(v) for k, v in ins.items()}
+        t.setdefault("ref_feature_bl", None)
+        r = pnet._frame_body(t)
+        for k in outs:
+            _lib.check(_lib.lib.lssvc_nhwc_to_nchw(r[k].ref, C.c_void_p(outs[k].data_ptr()), ops.stream_ptr()))
+
+    first = dpb["ref_feature_bl"] is None
+    info = _record(pnet, ins, run, outs, path, "pframe_first" if first else "pframe", arena_gib,
+                   meta=(("ref_feature_el_channels", ins["ref_feature_el"].shape[1]),))
+    return info, outs

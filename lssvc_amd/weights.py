@@ -183,6 +183,7 @@ class WeightStore:
                    for k, v in sd.items()}
         self.device = device
         self._cache = {}
+        self.regions = {}               # device pointer -> (bytes, host tensor) of every prepared tensor (plan_compiler.py stores them)
         self.force_f32 = set()          # layers the fp16 range audit moved to the exact fp32 conv kernel (hip_ops.RangeAudit)
 
     def has(self, key):
@@ -192,7 +193,10 @@ class WeightStore:
         return self.sd[key]
 
     def _dev(self, t):
-        return t.contiguous().to(self.device)
+        host = t.contiguous()
+        dev = host.to(self.device)
+        self.regions[dev.data_ptr()] = (dev.numel() * dev.element_size(), host)
+        return dev
 
     def conv(self, name, splits, pixel_shuffle=False):
         key = ("conv", name, tuple(splits), pixel_shuffle)

@@ -1,0 +1,104 @@
+"""The engine entry points (include/lssvc_hip.h "engine", csrc/plan_runtime.cpp) from a caller WITHOUT Python: frame plans
+compiled here by the Python front end (lssvc_amd/plan_compiler.py), then tests/engine_demo.c -- plain C, gcc, linked with
+liblssvc_hip.so only -- runs as its own process, codes I + P + P + P + P + P and writes what the engine returned. Every
+bit count and every tensor must equal the Python path's bit for bit (same kernels, same arguments, same order; the engine's
+first call of a plan is eager, the second captures a hipGraph inside the library, later ones replay it), and the first
+three frames are the golden case x2_128_ipp, held to the north-star bars against the REFERENCE's stored outputs."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_program_codes_a_gop_through_compiled_plans(tmp_path):
+    from lssvc_amd import IntraSS, LSSVC_extend, plan_compiler
+    from lssvc_amd.preprocess import psnr
+    from lssvc_amd.synth import synth_state_dict
+    z, m = load_case("x2_128_ipp")
+    H, W, h, w = m["H"], m["W"], m["h"], m["w"]
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", m["seed"], m["gain"])).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", m["seed"], m["gain"]))
+    pnet.to(DEV).eval()
+    order = [0, 1, 2, 1, 2, 1]                                     # six frames: the golden's three, then three more P-frames
+    x_el = [(torch.from_numpy(z["x_el_u8"][t:t + 1]).float() / 255.0).to(DEV) for t in order]
+    x_bl = [torch.from_numpy(z["x_bl"][t:t + 1]).to(DEV) for t in order]
+    for net in (inet, pnet):
+        net.set_scale_information(m["scale"], (H, W), (0, 0, 0, 0))
+
+    # ---- the Python path: expected results, and the DPBs the plans are compiled from
+    want, dpbs, dpb = [], [], None
+    for t in range(len(order)):
+        if t == 0:
+            r = inet.encode_decode(x_bl[t], x_el[t], None, None, h, w, H, W)
+            dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+            extra = []
+        else:
+            r = pnet.encode_decode(x_bl[t], x_el[t], dpb, None, None, W, H, w, h)
+            dpb = r["dpb"]
+            extra = [dpb["ref_feature_bl"], r["mv_hat"], r["warp_frame"]]
+        want.append((r["bit_bl"], r["bit_el"], [v.contiguous().clone() for v in (dpb["ref_frame_bl"], dpb["ref_frame_el"], dpb["ref_feature_el"])]
+                     + [v.contiguous().clone() for v in extra]))
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        dpbs.append({k: (None if v is None else v.contiguous().clone()) for k, v in dpb.items()})
+
+    # ---- compile: one plan per frame type
+    plans = [str(tmp_path / n) for n in ("iframe.plan", "first_p.plan", "steady_p.plan")]
+    info_i, _ = plan_compiler.compile_iframe(inet, x_bl[0], x_el[0], plans[0])
+    info_1, _ = plan_compiler.compile_pframe(pnet, x_bl[1], x_el[1], dpbs[0], plans[1])
+    info_2, _ = plan_compiler.compile_pframe(pnet, x_bl[2], x_el[2], dpbs[1], plans[2])
+    print("plans:", info_i, info_1, info_2)
+    assert info_1["streams"] >= 2 and info_2["launches"] > 300       # side-stream branches are part of the P plans
+
+    # ---- the C program, in its own process
+    case, outp, exe = str(tmp_path / "case.bin"), str(tmp_path / "out.bin"), str(tmp_path / "engine_demo")
+    with open(case, "wb") as f:
+        f.write(struct.pack("<5if", len(order), H, W, h, w, m["scale"]))
+        for t in range(len(order)):
+            f.write(x_bl[t].cpu().contiguous().numpy().tobytes())
+            f.write(x_el[t].cpu().contiguous().numpy().tobytes())
+    libdir = os.path.join(ROOT, "lssvc_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "engine_demo.c"),
+                           "-L", libdir, "-llssvc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    res = subprocess.run([exe] + plans + [case, outp], capture_output=True, text=True, env=env, timeout=600)
+    print(res.stdout, res.stderr)
+    assert res.returncode == 0, res.stderr
+
+    # ---- compare
+    raw = np.fromfile(outp, dtype=np.uint8)
+    pos = 0
+
+    def take(shape):
+        nonlocal pos
+        n = int(np.prod(shape)) * 4
+        a = torch.from_numpy(raw[pos:pos + n].view(np.float32).reshape(shape).copy())
+        pos += n
+        return a
+
+    for t in range(len(order)):
+        bits = raw[pos:pos + 16].view(np.float64)
+        pos += 16
+        shapes = [(1, 3, h, w), (1, 3, H, W), (1, 64 if t == 0 else 48, H, W)] + ([(1, 64, h, w), (1, 2, H, W), (1, 3, H, W)] if t else [])
+        got = [take(s) for s in shapes]
+        wb, we, tens = want[t]
+        assert (float(bits[0]), float(bits[1])) == (wb, we), (t, bits, wb, we)
+        for g, x in zip(got, tens):
+            assert torch.equal(g, x.cpu()), (t, tuple(g.shape), (g - x.cpu()).abs().max().item())
+        if t < 3:                                                  # the golden frames: the reference's own numbers
+            ref_bits = z["f%d_bits" % t]
+            assert abs(bits[0] - ref_bits[0]) / (h * w) <= 1e-5 and abs(bits[1] - ref_bits[1]) / (H * W) <= 1e-5
+            p_el = psnr(x_el[t].cpu(), got[1].clamp(0, 1))
+            assert abs(p_el - z["f%d_psnr" % t][1]) <= 1e-4
+    assert pos == raw.size
