@@ -356,6 +356,8 @@ int lssvc_engine_plan_info(void *engine, int32_t which, int64_t *out6);
  *   "f16x3_persist"            1/0   use the persistent warp-specialised 3x3 kernel (LSSVC_F16X3_PERSIST)
  *   "f16x3_persist_min_tiles"  n     ... for convs with at least n output tiles (LSSVC_F16X3_PERSIST_MIN_TILES, 256)
  *   "f16x3_persist7"           1/0   the persistent warp-specialised kernel for 7x7 convs too (LSSVC_F16X3_PERSIST7)
+ *   "dwpre_deep"               1/0   the fused 1x1 + depthwise kernel prefetches the next tile's inputs one whole tile ahead
+ *                                    (a second register set) instead of only during its depthwise phase (LSSVC_DWPRE_DEEP)
  *   "pointwise_blocks"         1/0   x2 bilinear resize and depthwise 3x3 compute a 2x2 output block per thread (the input
  *                                    neighbourhood is loaded once: 9 / 16 loads instead of 16 / 36) (LSSVC_POINTWISE_BLOCKS)
  * Results do not depend on them (the kernels they choose between are bit-identical); tests use them to pin that. */

@@ -9,7 +9,21 @@ from . import hip_ops as ops
 from .hip_ops import T
 
 
+import os as _os
+
 FOLD_SKIP_ADDS = True      # fold `skip + res_block(x)` into the block's last conv (second residual operand); False: separate add
+
+
+def _vec4(t):
+    """16-byte addressable view: what lssvc_conv2d's straight-line epilogue needs of out / residual / residual2 (vec4_ok)."""
+    return t.C % 4 == 0 and t.ld % 4 == 0 and t.v.ptr % 16 == 0
+
+
+def _can_fold(x, skip, out, slope):
+    """Exactly the conditions under which lssvc_conv2d accepts a second residual (csrc/conv_mfma.hip: fast_epi == 1); anything
+    else takes the separate add instead of a hard error (e.g. LSSVC_FAST_EPI=0, a documented debug switch)."""
+    return FOLD_SKIP_ADDS and _os.environ.get("LSSVC_FAST_EPI", "1") != "0" and 0.0 <= slope <= 1.0 and _vec4(x) and _vec4(skip) \
+        and (out is None or _vec4(out))
 
 
 def res_block(W, p, x, slope=0.01, start_from_relu=True, end_with_relu=False, out=None, skip=None):
@@ -19,7 +33,7 @@ def res_block(W, p, x, slope=0.01, start_from_relu=True, end_with_relu=False, ou
     t = ops.conv(W, p + ".conv1", x, in_act="lrelu" if start_from_relu else None, in_slope=slope, act="lrelu", slope=slope)
     if skip is None:
         return ops.conv(W, p + ".conv2", t, act="lrelu" if end_with_relu else None, slope=slope, residual=x, out=out)
-    if FOLD_SKIP_ADDS and x.C % 4 == 0 and x.ld % 4 == 0 and skip.ld % 4 == 0 and (out is None or out.ld % 4 == 0):
+    if _can_fold(x, skip, out, slope):
         return ops.conv(W, p + ".conv2", t, act="lrelu" if end_with_relu else None, slope=slope, residual=x, residual2=skip, out=out)
     return ops.add(skip, ops.conv(W, p + ".conv2", t, act="lrelu" if end_with_relu else None, slope=slope, residual=x), out=out)
 

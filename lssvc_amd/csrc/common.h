@@ -53,18 +53,24 @@ constexpr int kReduceMaxBlocks = 1024;  // partial-sum slots in the reduction wo
 // ---- per-device launch state. A process may drive several GPUs (one stream each); the CU count and the
 // dynamic-LDS grant of a kernel (hipFuncSetAttribute acts on the CURRENT device) are therefore cached per
 // device ordinal, not per process.
-constexpr int kMaxDevices = 16;
-inline int current_device() {
+constexpr int kMaxDevices = 64;          // far above any node (8 GPUs); an ordinal beyond it shares the last slot's cache,
+inline int current_device() {            // which only costs a repeated hipFuncSetAttribute, never a wrong grant: see ensure()
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
-    return d;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d < kMaxDevices ? d : kMaxDevices - 1;
+}
+inline bool device_slot_is_shared() {
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess && d >= kMaxDevices - 1;
 }
 inline int device_cus() {
     static std::atomic<int> cus[kMaxDevices];
     const int d = current_device();
-    int v = cus[d].load(std::memory_order_relaxed);
+    int v = device_slot_is_shared() ? 0 : cus[d].load(std::memory_order_relaxed);
     if (v > 0) return v;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    int real = 0;
+    if (hipGetDevice(&real) != hipSuccess) real = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, real) != hipSuccess || v <= 0) v = 256;
     cus[d].store(v, std::memory_order_relaxed);
     return v;
 }
@@ -74,7 +80,7 @@ struct LdsGrant {
     std::atomic<size_t> granted[kMaxDevices];
     int ensure(const void *fn, size_t bytes, size_t base = 0) {
         const int d = current_device();
-        size_t g = granted[d].load(std::memory_order_relaxed);
+        size_t g = device_slot_is_shared() ? 0 : granted[d].load(std::memory_order_relaxed);   // shared slot: always (re)grant
         if (g < base) g = base;
         if (bytes <= g) return 0;
         LSSVC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -85,6 +91,6 @@ struct LdsGrant {
 
 // runtime tuning switches (lssvc_set_option / environment), see conv_mfma.hip
 int option_get(int which);
-enum { OPT_P3_ON = 0, OPT_P3_MIN_TILES = 1, OPT_P7_ON = 2, OPT_POINTWISE_BLOCKS = 3, OPT_COUNT = 4 };
+enum { OPT_P3_ON = 0, OPT_P3_MIN_TILES = 1, OPT_P7_ON = 2, OPT_POINTWISE_BLOCKS = 3, OPT_DWPRE_DEEP = 4, OPT_COUNT = 5 };
 
 }  // namespace lssvc

@@ -11,7 +11,12 @@
 //            256-byte pixel row per 16 lanes.
 // The halo costs (TH+2)*18 / (TH*16) extra conv1 work and x reads (1.27x at TH = 16, served by L2); the weights
 // (<= 64x64 hi/lo = 16 KB) and dw taps stay in LDS / registers for the life of the persistent workgroup, and the next
-// tile's x fragments are prefetched into registers while phase 2 runs.
+// tile's x fragments are prefetched into the SAME registers: with DEEP (option dwpre_deep, default) a wave reloads each of
+// its 16-pixel groups for the next tile as soon as phase 1 has consumed that group, so that global loads are in flight
+// during both phases (the kernel is HBM-bound, and with the prefetch issued only at the start of phase 2 the memory pipeline
+// idled through every phase 1: 3.5 TB/s against the 5.3 TB/s a plain device copy of the same tensors reaches,
+// tools/bw_copy_probe.py; a second register set for a whole-tile-ahead prefetch spilled 28 registers at C = 64); without
+// it all groups are reloaded at the start of phase 2 (round-2 behaviour).
 #include <cstdlib>
 
 #include "conv_f16x3_kernel.h"
@@ -33,7 +38,7 @@ struct DwPreP {
 constexpr int kDwThreads = 512;
 
 // TH output rows per tile; CF = C / 16 accumulator fragments; NS = K-steps of conv1 (32 input channels each)
-template <int CF, int NS, int TH>
+template <int CF, int NS, int TH, bool DEEP>
 __global__ __launch_bounds__(kDwThreads, 1) void dwpre_f16x3_kernel(const DwPreP p) {
     constexpr int PW = 18, PH = TH + 2, NPIX = PH * PW, NGRP = (NPIX + 15) / 16, WAVES = kDwThreads / 64;
     constexpr int GPW = (NGRP + WAVES - 1) / WAVES;                 // halo groups per wave
@@ -103,10 +108,9 @@ __global__ __launch_bounds__(kDwThreads, 1) void dwpre_f16x3_kernel(const DwPreP
     }
 
     float4 raw[GPW][NS][2];
-    auto load_tile = [&](int tile) {
+    auto load_group = [&](int tile, int g) {
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-#pragma unroll
-        for (int g = 0; g < GPW; ++g) {
+        {
             const int hp = (wave + WAVES * g) * 16 + li;                 // halo pixel index of this lane's column
             const int py = hp / PW, px = hp - py * PW;
             const int gy = ty * TH - 1 + py, gx = tx * 16 - 1 + px;
@@ -120,10 +124,13 @@ __global__ __launch_bounds__(kDwThreads, 1) void dwpre_f16x3_kernel(const DwPreP
             }
         }
     };
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) load_group(tile, g);
+    };
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) load_tile(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    // one tile: phase 1 from `raw` (loaded earlier), barrier, [shallow prefetch], phase 2, barrier
+    auto do_tile = [&](int tile, int prefetch_tile) {
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
         // ---------------------------------------------------------------- phase 1: t = lrelu(W1 x + b1) on the halo patch
 #pragma unroll
@@ -178,9 +185,10 @@ __global__ __launch_bounds__(kDwThreads, 1) void dwpre_f16x3_kernel(const DwPreP
                     *reinterpret_cast<float4 *>(t_lds + hp * PITCH + f * 16 + 4 * lg) = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
+            if (DEEP && prefetch_tile >= 0) load_group(prefetch_tile, g);      // raw[g] is consumed: refill it for the next tile now
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);      // in flight during phase 2
+        if (!DEEP && prefetch_tile >= 0) load_tile(prefetch_tile);             // shallow mode: in flight during phase 2 only
         // ---------------------------------------------------------------- phase 2: depthwise 3x3 out of LDS
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
@@ -205,24 +213,34 @@ __global__ __launch_bounds__(kDwThreads, 1) void dwpre_f16x3_kernel(const DwPreP
             }
         }
         __syncthreads();                                                       // t_lds is rewritten by the next tile
-    }
+    };
+
+    const int stride = (int)gridDim.x;
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += stride) do_tile(tile, tile + stride < ntiles ? tile + stride : -1);
 }
 
-template <int CF, int NS, int TH>
-static int launch_dwpre(const DwPreP &p, hipStream_t st) {
+template <int CF, int NS, int TH, bool DEEP>
+static int launch_dwpre_impl(const DwPreP &p, hipStream_t st) {
     constexpr int C = 16 * CF;
     constexpr size_t lds = (size_t)(TH + 2) * 18 * (C + 4) * 4 + (size_t)2 * (2 * NS) * C * CK16 * 2;
     static_assert(lds <= 160 * 1024, "dwpre tile does not fit LDS");
     const int cus = device_cus();
     static LdsGrant grant;
-    if (grant.ensure(reinterpret_cast<const void *>(dwpre_f16x3_kernel<CF, NS, TH>), lds)) return 1;
+    if (grant.ensure(reinterpret_cast<const void *>(dwpre_f16x3_kernel<CF, NS, TH, DEEP>), lds)) return 1;
     DwPreP q = p;
     q.tiles_x = (p.out.W + 15) / 16;
     q.tiles_y = (p.out.H + TH - 1) / TH;
     long long blocks = (long long)q.tiles_x * q.tiles_y;
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL((dwpre_f16x3_kernel<CF, NS, TH>), dim3((unsigned)blocks), dim3(kDwThreads), lds, st, q);
+    hipLaunchKernelGGL((dwpre_f16x3_kernel<CF, NS, TH, DEEP>), dim3((unsigned)blocks), dim3(kDwThreads), lds, st, q);
     return launch_status("conv1x1_dw3x3_f16x3");
+}
+
+template <int CF, int NS, int TH>
+static int launch_dwpre(const DwPreP &p, hipStream_t st) {
+    return option_get(OPT_DWPRE_DEEP) ? launch_dwpre_impl<CF, NS, TH, true>(p, st) : launch_dwpre_impl<CF, NS, TH, false>(p, st);
 }
 
 }  // namespace lssvc

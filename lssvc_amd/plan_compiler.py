@@ -260,7 +260,7 @@ def compile_iframe(inet, x_bl, x_el, path, arena_gib=None):
     Inputs of the plan: x_bl, x_el. Outputs: x_hat_bl, x_hat_el, feature_el (NCHW) and the four bit accumulators."""
     from .hip_ops import T
     H, W = inet.shape_hr
-    arena_gib = arena_gib if arena_gib is not None else max(0.25, 6.0 * H * W / (1152.0 * 1920.0))
+    arena_gib = arena_gib if arena_gib is not None else max(0.25, 8.0 * H * W / (1152.0 * 1920.0))
     dev = inet.device
     outs = {"x_hat_bl": torch.empty(1, 3, x_bl.shape[2], x_bl.shape[3], device=dev), "x_hat_el": torch.empty(1, 3, H, W, device=dev),
             "feature_el": torch.empty(1, 64, H, W, device=dev)}
@@ -280,7 +280,7 @@ def compile_pframe(pnet, x_bl, x_el, dpb, path, arena_gib=None):
     ref_feature_el give the first-P plan (after an I-frame), otherwise the steady-P plan. All inputs NCHW contiguous."""
     from .hip_ops import T
     H, W = pnet.shape_hr
-    arena_gib = arena_gib if arena_gib is not None else max(0.5, 14.0 * H * W / (1152.0 * 1920.0))
+    arena_gib = arena_gib if arena_gib is not None else max(0.5, 26.0 * H * W / (1152.0 * 1920.0))
     dev = pnet.device
     ins = {"x_bl": x_bl.contiguous(), "x_el": x_el.contiguous(), "ref_frame_bl": dpb["ref_frame_bl"].contiguous(),
            "ref_frame_el": dpb["ref_frame_el"].contiguous(), "ref_feature_el": dpb["ref_feature_el"].contiguous()}
