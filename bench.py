@@ -135,15 +135,16 @@ def roofline_from_log(op_log):
         sig = {}
         for e in op_log:
             k = (e["kind"], e["cin"], e["cout"], e["hout"], e["wout"], e["kernel"])
-            g = sig.setdefault(k, [0.0, 0, 0])
+            g = sig.setdefault(k, [0.0, 0, 0, 0])
             g[0] += e["events"][0].elapsed_time(e["events"][1])
             g[1] += e["macs"]
             g[2] += 1
+            g[3] += e["bytes"]
         with open(os.environ["LSSVC_BENCH_SIGNATURES"], "w") as f:
             tot = sum(g[0] for g in sig.values())
             for k, g in sorted(sig.items(), key=lambda kv: -kv[1][0]):
-                f.write("%-10s cin %4d cout %4d @%4dx%-4d %-40s n=%4d  %8.2f ms (%4.1f%%)  %6.1f TF\n" % (
-                    k[0], k[1], k[2], k[3], k[4], k[5], g[2], g[0], 100 * g[0] / tot, 2e-9 * g[1] / g[0]))
+                f.write("%-10s cin %4d cout %4d @%4dx%-4d %-40s n=%4d  %8.2f ms (%4.1f%%)  %7.1f us  %6.1f TF  %5.2f TB/s\n" % (
+                    k[0], k[1], k[2], k[3], k[4], k[5], g[2], g[0], 100 * g[0] / tot, 1e3 * g[0] / g[2], 2e-9 * g[1] / g[0], 1e-9 * g[3] / g[0]))
     dom = table[0]
     common = {"kernel": dom["kernel"], "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
               "gflop_per_launch": dom["gflop_per_launch"], "mbytes_per_launch": dom["mbytes_per_launch"],

@@ -35,9 +35,11 @@ def _clip(n, H, W, seed):
 def _check_rate(bits, est):
     # With seeded random weights the analytic likelihoods and the 16-bit quantised, level-snapped tables differ
     # by several percent (the tight bound -- stream length vs the tables' own ideal code length -- is checked on
-    # the coder itself in tests/test_entropy_coder.py); here only that the real rate tracks the estimate.
+    # the coder itself in tests/test_entropy_coder.py); here only that the real rate tracks the estimate. Measured ratios
+    # (round 3, every layer of every case): 0.85-1.16 at 128x128, 0.88-1.002 at 1152x1920 and 2176x3840; the low end is the
+    # I-frame base layer, whose Gaussian likelihoods carry a 1e-9 floor the tables do not have.
     print("stream bits %d vs estimated %.1f (ratio %.4f)" % (bits, est, bits / max(est, 1.0)))
-    assert abs(bits - est) <= 0.25 * est + 512, (bits, est)
+    assert abs(bits - est) <= 0.18 * est + 512, (bits, est)
 
 
 @pytest.mark.parametrize("H,W,gain,frames", [(128, 128, 0.6, 3), (128, 256, 0.65, 2), (1152, 1920, 0.55, 2),
