@@ -5,7 +5,7 @@ benchmark's own sizes on seeded synthetic weights and an integer-exact synthetic
 
     x2_1080p_ipp    BASELINE configs[1] shape: EL 1152x1920 / BL 576x960, I + first P + steady P
     x1_5_1080p_ip   EL 1152x1920 / BL 768x1280 (the non-integer ratio at full size), I + first P
-    x2_2160p_i      BASELINE configs[3] shape: EL 2176x3840 / BL 1088x1920, the I-frame
+    x2_2160p_ip     BASELINE configs[3] shape: EL 2176x3840 / BL 1088x1920, I + first P (the P-frame: ~40 GB of host memory)
 
 The frame loop is test.py's (test.py:182-250), exactly as tests/golden/make_golden.py replays it. What is stored per
 frame: bits, PSNR, strided samples and double-precision sums of every tensor the model hands back, and -- so that a
@@ -37,7 +37,7 @@ CASES = {
     # name: (frames, picture H, picture W, scale, gain, seed)
     "x2_1080p_ipp": (3, 1080, 1920, 2.0, 0.55, 0),
     "x1_5_1080p_ip": (2, 1080, 1920, 1.5, 0.55, 1),
-    "x2_2160p_i": (1, 2160, 3840, 2.0, 0.55, 2),
+    "x2_2160p_ip": (2, 2160, 3840, 2.0, 0.55, 2),
     "_dev_x2_128_ipp": (3, 120, 128, 2.0, 0.55, 3),       # generator self-check only, not committed
 }
 # (spatial stride, channel stride) of the stored samples
@@ -170,7 +170,7 @@ def run_case(name, IntraSS, LSSVC_extend, imresize):
                   "peak RSS %.1f GB" % (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6), flush=True)
     out["reference_seconds"] = np.array(secs)
     out["reference_threads"] = np.array(torch.get_num_threads())
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(os.environ.get("LSSVC_GOLDEN_OUT", HERE), name + ".npz")      # (override: dry runs that must not touch the committed fixtures)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

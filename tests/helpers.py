@@ -45,7 +45,7 @@ def replay(case, i_frame, p_frame, device="cpu"):
 
 
 # ---- full-size cases (tests/golden/make_golden_full.py): inputs are regenerated, not stored -------------------------
-FULL_CASES = ("x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_i")
+FULL_CASES = ("x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_ip")
 FULL_SAMPLE = {"x_hat_bl": (4, 1), "x_hat_el": (8, 1), "feature_el": (32, 4), "feature_bl": (16, 4), "mv_hat": (8, 1),
                "warp_frame": (8, 1), "x_bl": (8, 1)}
 

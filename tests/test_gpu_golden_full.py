@@ -2,7 +2,7 @@
 
     x2_1080p_ipp    BASELINE configs[1]: EL 1152x1920 / BL 576x960, I + first P + steady P
     x1_5_1080p_ip   the non-integer ratio at full size: EL 1152x1920 / BL 768x1280, I + first P
-    x2_2160p_i      BASELINE configs[3]'s shape: EL 2176x3840 / BL 1088x1920, the I-frame
+    x2_2160p_ip     BASELINE configs[3]'s shape: EL 2176x3840 / BL 1088x1920, I + first P
 
 Bars (BASELINE.json north_star): |d bpp| <= 1e-5 and |d PSNR| <= 1e-4 dB per layer per frame, in both conv precisions.
 The fixtures also hold the reference's QUANTISED LATENTS, which makes the comparison exact where a plain replay cannot
@@ -85,7 +85,7 @@ def _decode_from_reference_symbols(z, m, t, inet, pnet, dpb):
             "mv_hat": mv_hat.to_nchw(), "warp_frame": warp_frame.to_nchw()}
 
 
-@pytest.mark.parametrize("case", ["x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_i"])
+@pytest.mark.parametrize("case", ["x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_ip"])
 def test_full_size_frames_match_reference(case, precision):
     from lssvc_amd import IntraSS, LSSVC_extend
     from lssvc_amd.preprocess import psnr
