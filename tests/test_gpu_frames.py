@@ -180,9 +180,10 @@ def test_dataset_picture_sizes_vs_oracle(ph, pw, scale, precision):
     EL 384x576 / BL 256x384 (ratio 1.5) and EL 256x512 / BL 128x256 -- map widths of 14, 9 and 8 sixty-fourths, which none of
     the other shapes has. I + P + P against the CPU oracle at the north-star bars.
     Seed: 7, 8 and 9 were run for every shape in both precisions (18 runs); 17 pass, and seed 7 at 416x240 / ratio 1.5 in
-    the f32 mode misses the base-layer bit count of the I-frame by 18.49 bits -- exactly -log2(Phi(-0.5 / 0.11)), ONE symbol
-    whose sigma sits at the 0.11 floor rounded the other way at a tie (y - mu within the fp32 noise of k + 1/2; the two
-    precisions agree on y to 3e-6 on that frame, tools/debug_precision_diff.py). At 256x384 pixels that one tie is 1.9e-4 bpp,
+    the f32 mode misses the base-layer bit count of the I-frame by 18.49 bits = log2 of the likelihood ratio of symbols 0 and
+    1 at sigma = 0.11 (18.48): ONE symbol whose sigma sits at the floor rounded the other way at a tie, y - mu within the fp32
+    noise of k + 1/2 (the two precisions agree on y to 3e-6 at this size, tools/debug_precision_diff.py 256 384 7 0.55; the
+    f16x3 mode passes that very seed). At 256x384 pixels that one tie is 1.9e-4 bpp,
     beyond the bar by construction; which seed ties is a property of the summation order, not of a kernel, and ties are what
     tests/test_gpu_golden_full.py handles with the reference's own symbols. This test uses seed 8."""
     from lssvc_amd.preprocess import interlayer_padding
