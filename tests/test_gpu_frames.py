@@ -173,12 +173,13 @@ def test_frames_384x640_vs_oracle(precision):
     _gpu_gop_against_oracle(3, 384, 640, 3, 0.55, want_kernels=want)
 
 
-@pytest.mark.parametrize("ph,pw,scale,frames", [(480, 832, 2.0, 3), (240, 416, 1.5, 3), (240, 416, 2.0, 3), (720, 1280, 1.5, 2)])
+@pytest.mark.parametrize("ph,pw,scale,frames", [(480, 832, 2.0, 2), (240, 416, 1.5, 3), (240, 416, 2.0, 3), (720, 1280, 1.5, 2)])
 def test_dataset_picture_sizes_vs_oracle(ph, pw, scale, frames, precision):
     """The picture sizes of the reference's own test set below 720p (HEVC class C 832x480 and class D 416x240,
     recommend_test_config.json) at both of its ratios, padded as test.py pads them (common.py:48-86): EL 512x896 / BL 256x448,
     EL 384x576 / BL 256x384 (ratio 1.5) and EL 256x512 / BL 128x256 -- map widths of 14, 9 and 8 sixty-fourths, which none of
-    the other shapes has -- I + P + P, and class E 1280x720 at ratio 1.5 (EL 768x1344 / BL 512x896: 21 sixty-fourths), I + P,
+    the other shapes has -- and class E 1280x720 at ratio 1.5 (EL 768x1344 / BL 512x896: 21 sixty-fourths); I + P + P at
+    416x240, I + P at the larger sizes (the oracle's seconds bound the suite),
     against the CPU oracle at the north-star bars.
     Seed: 7, 8 and 9 were run for every shape in both precisions (18 runs); 17 pass, and seed 7 at 416x240 / ratio 1.5 in
     the f32 mode misses the base-layer bit count of the I-frame by 18.49 bits = log2 of the likelihood ratio of symbols 0 and
