@@ -352,6 +352,33 @@ int lssvc_engine_pframe(void *engine, const float *x_bl, const float *x_el, cons
 /* which: 0 intra, 1 first-P, 2 steady-P -> launches, streams, arena bytes, weight bytes, H, W */
 int lssvc_engine_plan_info(void *engine, int32_t which, int64_t *out6);
 
+/* write_stream = 1 through the engine (SURVEY 8b's lssvc_pframe_symbols / lssvc_pframe_decode): the ENCODER and the DECODER
+ * half of a frame as separate plans (plan_compiler.py: compile_iframe_stream / compile_pframe_stream), replacing
+ * IntraSS.compress / decompress (src/models/IntraSS.py:304-336, priors.py:422-452) and LSSVC_extend.compress / decompress
+ * (src/models/LSSVC_net_extend.py:24-136, dmc_net_extend.py:55-146). Such a plan also holds the host coder's steps (staging
+ * copies of the int16 planes, rANS calls, the CDF tables update() built) and is replayed eagerly. A layer "file" is the byte
+ * image the reference writes to disk (src/utils/stream_helper.py:61-99): I-frame = big-endian u32 height, width, len_y,
+ * len_z + the y and z strings; P-frame = u32 len + one string -- the bytes are those of the Python path's .bin files.
+ * Any path may be NULL (an encoder-only or decoder-only process loads its half). */
+int lssvc_engine_load_stream(void *engine, const char *iframe_enc_plan, const char *iframe_dec_plan, const char *first_p_enc_plan,
+                             const char *first_p_dec_plan, const char *steady_p_enc_plan, const char *steady_p_dec_plan);
+/* *_len receives the file size (also when the buffer is too small, which is an error). Outputs: the reconstruction the decoder
+ * will produce from these bytes (bit-identical), i.e. the DPB of the next frame */
+int lssvc_engine_encode_iframe(void *engine, const float *x_bl, const float *x_el, uint8_t *bl_file, int64_t bl_cap, int64_t *bl_len,
+                               uint8_t *el_file, int64_t el_cap, int64_t *el_len, float *x_hat_bl, float *x_hat_el, float *feature_el,
+                               void *stream);
+int lssvc_engine_decode_iframe(void *engine, const uint8_t *bl_file, int64_t bl_len, const uint8_t *el_file, int64_t el_len,
+                               float *x_hat_bl, float *x_hat_el, float *feature_el, void *stream);
+/* ref_feature_bl NULL selects the first-P plans. recon_bl comes back clamped to [0, 1], as the reference's base-layer decoder
+ * returns it (dmc_net_extend.py:138); the caller clamps recon_el before handing it back (test.py:249-250) */
+int lssvc_engine_encode_pframe(void *engine, const float *x_bl, const float *x_el, const float *ref_frame_bl, const float *ref_frame_el,
+                               const float *ref_feature_bl, const float *ref_feature_el, uint8_t *bl_file, int64_t bl_cap, int64_t *bl_len,
+                               uint8_t *el_file, int64_t el_cap, int64_t *el_len, float *recon_bl, float *feature_bl, float *recon_el,
+                               float *feature_el, void *stream);
+int lssvc_engine_decode_pframe(void *engine, const uint8_t *bl_file, int64_t bl_len, const uint8_t *el_file, int64_t el_len,
+                               const float *ref_frame_bl, const float *ref_frame_el, const float *ref_feature_bl, const float *ref_feature_el,
+                               float *recon_bl, float *feature_bl, float *recon_el, float *feature_el, void *stream);
+
 /* Runtime tuning switches (each also reads an environment variable at first use):
  *   "f16x3_persist"            1/0   use the persistent warp-specialised 3x3 kernel (LSSVC_F16X3_PERSIST)
  *   "f16x3_persist_min_tiles"  n     ... for convs with at least n output tiles (LSSVC_F16X3_PERSIST_MIN_TILES, 256)

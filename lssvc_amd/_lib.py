@@ -120,6 +120,11 @@ SIGNATURES = {
     "lssvc_engine_iframe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_engine_pframe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.POINTER(C.c_double)] + [C.c_void_p] * 7),
     "lssvc_engine_plan_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "lssvc_engine_load_stream": (C.c_int, [C.c_void_p] + [C.c_char_p] * 6),
+    "lssvc_engine_encode_iframe": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)] + [C.c_void_p] * 4),
+    "lssvc_engine_decode_iframe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_void_p] * 4),
+    "lssvc_engine_encode_pframe": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)] + [C.c_void_p] * 5),
+    "lssvc_engine_decode_pframe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_void_p] * 9),
     "lssvc_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
     "lssvc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "lssvc_last_error": (C.c_char_p, []),

@@ -11,6 +11,14 @@
 // hipStreamBeginCapture; a frame after that is: copy the caller's inputs into the plan's input buffers, hipGraphLaunch, copy
 // the outputs and the bit counters out (the graph itself only ever sees the engine's own memory, so it is captured once).
 // Results are bit-identical to the Python path: same kernels, same arguments, same order.
+//
+// write_stream = 1 plans (compile_iframe_stream / compile_pframe_stream) are the encoder or the decoder half of a frame
+// (IntraSS.compress / decompress, src/models/IntraSS.py:304-336 with priors.py:422-452; LSSVC_extend.compress / decompress,
+// src/models/LSSVC_net_extend.py:24-136 with dmc_net_extend.py:55-146). Besides launches they hold the HOST steps the front
+// end performed between them -- int16 plane copies to / from a pinned staging buffer, rANS coder calls with the CDF tables
+// stored in the file -- which the runtime performs in place, in order, on the main stream; such a plan is replayed eagerly
+// every frame (a decoder waits for the host a dozen times per frame: there is no graph to capture). The layer files the
+// encoder entry points return are byte for byte what the Python path writes (src/utils/stream_helper.py:61-99).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,13 +70,21 @@ struct Launch {
 enum Fn {
     FN_WAIT, FN_CONV2D, FN_CONV1X1_DW, FN_FFN, FN_DWCONV, FN_RESIZE, FN_WARP, FN_POOL, FN_SOFTMAX2, FN_ADD, FN_COPY, FN_LRELU,
     FN_OFFSET_DIVERSITY, FN_NCHW_TO_NHWC, FN_NHWC_TO_NCHW, FN_LAPLACE_QUANT_BITS, FN_FOUR_PART_STEP, FN_LAPLACE_BITS,
-    FN_FACTORIZED, FN_GAUSSIAN, FN_BOTTLENECK, FN_FILL_ZERO, FN_CLAMP, FN_COUNT
+    FN_FACTORIZED, FN_GAUSSIAN, FN_BOTTLENECK, FN_FILL_ZERO, FN_CLAMP, FN_EXPORT_I16, FN_IMPORT_I16,
+    FN_H_D2H, FN_H_H2D, FN_H_ENCODE, FN_H_FLUSH, FN_H_SET_STREAM, FN_H_DECODE, FN_H_DECODE_CH, FN_COUNT
 };
 const char *const kFnNames[FN_COUNT] = {
     "__wait__", "lssvc_conv2d", "lssvc_conv1x1_dw3x3_f16x3", "lssvc_ffn_f16x3", "lssvc_dwconv3x3", "lssvc_resize_bilinear",
     "lssvc_flow_warp", "lssvc_pool2x2", "lssvc_softmax2_blend", "lssvc_add", "lssvc_copy", "lssvc_lrelu", "lssvc_offset_diversity",
     "lssvc_nchw_to_nhwc", "lssvc_nhwc_to_nchw", "lssvc_laplace_quant_bits", "lssvc_four_part_step", "lssvc_laplace_bits",
-    "lssvc_factorized_quant_bits", "lssvc_gaussian_conditional", "lssvc_entropy_bottleneck", "lssvc_fill_zero", "lssvc_clamp_inplace"};
+    "lssvc_factorized_quant_bits", "lssvc_gaussian_conditional", "lssvc_entropy_bottleneck", "lssvc_fill_zero", "lssvc_clamp_inplace",
+    "lssvc_export_symbols_i16", "lssvc_import_symbols_i16",
+    "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__"};
+
+struct Table {                           // one entropy_coder.Tables: quantised CDF rows + used lengths + symbol offsets
+    std::vector<int32_t> cdfs, sizes, offsets;
+    lssvc_cdf_table c{};
+};
 
 struct Plan {
     std::string kind;
@@ -83,8 +99,24 @@ struct Plan {
     hipGraphExec_t exec = nullptr;
     int runs = 0;
     int bits_region = -1;
+    // write_stream = 1 plans
+    bool has_host_steps = false;
+    std::vector<Table> tables;
+    int stage_region = -1, flag_region = -1;
+    int16_t *stage_host = nullptr;       // pinned mirror of the staging region
+    int32_t *flag_host = nullptr;
+    std::vector<void *> encoders, decoders;
+    std::vector<std::pair<const uint8_t *, int64_t>> in_strings;
+    std::vector<std::vector<uint8_t>> out_strings;
+    std::vector<int16_t> channel_idx;
 
     ~Plan() {
+        for (void *e : encoders)
+            if (e) lssvc_rans_encoder_free(e);
+        for (void *d : decoders)
+            if (d) lssvc_rans_decoder_free(d);
+        if (stage_host) (void)hipHostFree(stage_host);
+        if (flag_host) (void)hipHostFree(flag_host);
         if (exec) (void)hipGraphExecDestroy(exec);
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto s : side) (void)hipStreamDestroy(s);
@@ -135,7 +167,8 @@ int load_plan(const char *path, Plan &p) {
     const uint32_t n_regions = r.get<uint32_t>(), n_launches = r.get<uint32_t>();
     p.n_streams = r.get<uint32_t>();
     const uint32_t n_meta = r.get<uint32_t>();
-    r.get<uint32_t>();
+    const uint32_t n_tables = r.get<uint32_t>();
+    LSSVC_CHECK(r.ok && n_tables <= 64, "engine: corrupt plan (table count)");
     p.scale = r.get<double>();
     p.H = r.get<int32_t>();
     p.W = r.get<int32_t>();
@@ -196,6 +229,26 @@ int load_plan(const char *path, Plan &p) {
         for (int k = 0; k < FN_COUNT; ++k)
             if (l.fn == kFnNames[k]) l.id = k;
         LSSVC_CHECK(l.id >= 0, "engine: plan uses %s, which this runtime does not replay", l.fn.c_str());
+        if (l.id >= FN_H_D2H) {
+            p.has_host_steps = true;
+            for (auto &a : l.args) LSSVC_CHECK(a.tag == TAG_I64, "engine: corrupt plan (host step argument)");
+        }
+    }
+    p.tables.resize(n_tables);
+    for (auto &t : p.tables) {
+        const uint32_t rows = r.get<uint32_t>(), stride = r.get<uint32_t>();
+        LSSVC_CHECK(r.ok && rows > 0 && rows <= 4096 && stride > 0 && stride <= 65538, "engine: corrupt plan (table shape)");
+        t.cdfs.resize((size_t)rows * stride);
+        t.sizes.resize(rows);
+        t.offsets.resize(rows);
+        r.bytes(t.cdfs.data(), t.cdfs.size() * 4);
+        r.bytes(t.sizes.data(), rows * 4);
+        r.bytes(t.offsets.data(), rows * 4);
+        t.c.cdfs = t.cdfs.data();
+        t.c.n_cdfs = (int32_t)rows;
+        t.c.stride = (int32_t)stride;
+        t.c.sizes = t.sizes.data();
+        t.c.offsets = t.offsets.data();
     }
     LSSVC_CHECK(r.ok, "engine: truncated plan file %s", path);
     // ---- regions: allocate, upload the weights (payloads follow the launch list, 256-byte aligned, in region order)
@@ -214,6 +267,13 @@ int load_plan(const char *path, Plan &p) {
     }
     p.bits_region = p.region_index("bits", REGION_SCRATCH);
     LSSVC_CHECK(p.bits_region >= 0, "engine: plan has no bit-counter region");
+    if (p.has_host_steps) {
+        p.stage_region = p.region_index("stage_dev", REGION_SCRATCH);
+        p.flag_region = p.region_index("stage_flag", REGION_SCRATCH);
+        LSSVC_CHECK(p.stage_region >= 0 && p.flag_region >= 0, "engine: a plan with host steps needs the staging regions");
+        LSSVC_HIP(hipHostMalloc((void **)&p.stage_host, p.regions[p.stage_region].nbytes, hipHostMallocDefault));
+        LSSVC_HIP(hipHostMalloc((void **)&p.flag_host, sizeof(int32_t), hipHostMallocDefault));
+    }
     for (uint32_t s = 1; s < p.n_streams; ++s) {
         hipStream_t st;
         LSSVC_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -241,6 +301,80 @@ int bind(Plan &p) {
             }
         }
     return 0;
+}
+
+// One host step of a write_stream = 1 plan (entropy_coder.py / hip_ops.SymbolStage, as recorded): plane offsets are int16
+// element offsets into the staging region and its pinned mirror.
+int host_step(Plan &p, const Launch &l, hipStream_t main) {
+    auto A = [&](size_t i) { return l.args[i].i; };
+    const int64_t cap = (int64_t)(p.regions[p.stage_region].nbytes / 2);
+    int16_t *dev = static_cast<int16_t *>(p.regions[p.stage_region].ptr);
+    auto in_stage = [&](int64_t off, int64_t n) { return off >= 0 && n >= 0 && off + n <= cap; };
+    auto coder = [&](std::vector<void *> &v, int64_t id, bool enc) -> void * {
+        if (id < 0 || id >= 16) return nullptr;
+        if ((size_t)id >= v.size()) v.resize(id + 1, nullptr);
+        if (!v[id]) v[id] = enc ? lssvc_rans_encoder_new() : lssvc_rans_decoder_new();
+        return v[id];
+    };
+    auto table = [&](int64_t id) -> const lssvc_cdf_table * { return id >= 0 && (size_t)id < p.tables.size() ? &p.tables[id].c : nullptr; };
+    switch (l.id) {
+    case FN_H_D2H: {                                     // SymbolStage.download: planes [lo, hi) + the overflow flag, then wait
+        LSSVC_CHECK(l.args.size() == 2 && in_stage(A(0), A(1) - A(0)), "engine: corrupt plan (d2h step)");
+        LSSVC_HIP(hipMemcpyAsync(p.stage_host + A(0), dev + A(0), 2 * (size_t)(A(1) - A(0)), hipMemcpyDeviceToHost, main));
+        LSSVC_HIP(hipMemcpyAsync(p.flag_host, p.regions[p.flag_region].ptr, sizeof(int32_t), hipMemcpyDeviceToHost, main));
+        LSSVC_HIP(hipStreamSynchronize(main));
+        LSSVC_CHECK(*p.flag_host == 0, "engine: a quantised latent does not fit the 16-bit symbol planes");
+        return 0;
+    }
+    case FN_H_H2D:                                       // SymbolStage.upload
+        LSSVC_CHECK(l.args.size() == 2 && in_stage(A(0), A(1)), "engine: corrupt plan (h2d step)");
+        LSSVC_HIP(hipMemcpyAsync(dev + A(0), p.stage_host + A(0), 2 * (size_t)A(1), hipMemcpyHostToDevice, main));
+        return 0;
+    case FN_H_ENCODE: {                                  // RansEncoder.encode_with_indexes(symbols, indexes, tables)
+        LSSVC_CHECK(l.args.size() == 5 && in_stage(A(1), A(3)) && in_stage(A(2), A(3)) && table(A(4)), "engine: corrupt plan (encode step)");
+        void *e = coder(p.encoders, A(0), true);
+        LSSVC_CHECK(e != nullptr, "engine: corrupt plan (encoder id)");
+        return lssvc_rans_encode_with_indexes_i16(e, p.stage_host + A(1), p.stage_host + A(2), A(3), table(A(4)));
+    }
+    case FN_H_FLUSH: {                                   // RansEncoder.flush -> string A(1) of the frame
+        LSSVC_CHECK(l.args.size() == 2 && A(1) >= 0 && A(1) < 8, "engine: corrupt plan (flush step)");
+        void *e = coder(p.encoders, A(0), true);
+        LSSVC_CHECK(e != nullptr, "engine: corrupt plan (encoder id)");
+        const int64_t n = lssvc_rans_encoder_flush(e);
+        LSSVC_CHECK(n >= 0, "engine: rANS flush failed");
+        if ((size_t)A(1) >= p.out_strings.size()) p.out_strings.resize(A(1) + 1);
+        const uint8_t *b = lssvc_rans_encoder_bytes(e);
+        p.out_strings[A(1)].assign(b, b + n);
+        lssvc_rans_encoder_reset(e);
+        return 0;
+    }
+    case FN_H_SET_STREAM: {                              // RansDecoder.set_stream(string A(1) of the layer files)
+        LSSVC_CHECK(l.args.size() == 2 && A(1) >= 0 && (size_t)A(1) < p.in_strings.size(), "engine: this plan reads string %lld, %zu were given",
+                    (long long)A(1), p.in_strings.size());
+        void *d = coder(p.decoders, A(0), false);
+        LSSVC_CHECK(d != nullptr, "engine: corrupt plan (decoder id)");
+        return lssvc_rans_decoder_set_stream(d, p.in_strings[A(1)].first, p.in_strings[A(1)].second);
+    }
+    case FN_H_DECODE: {                                  // RansDecoder.decode_stream(staged index plane) -> staged symbol plane
+        LSSVC_CHECK(l.args.size() == 5 && in_stage(A(1), A(2)) && in_stage(A(4), A(2)) && table(A(3)), "engine: corrupt plan (decode step)");
+        void *d = coder(p.decoders, A(0), false);
+        LSSVC_CHECK(d != nullptr, "engine: corrupt plan (decoder id)");
+        LSSVC_HIP(hipStreamSynchronize(main));           // (earlier uploads out of the pinned buffer have left it)
+        return lssvc_rans_decode_stream_i16(d, p.stage_host + A(1), A(2), table(A(3)), p.stage_host + A(4));
+    }
+    case FN_H_DECODE_CH: {                               // ... with index = channel number, NCHW order (factorised tables)
+        LSSVC_CHECK(l.args.size() == 5 && A(1) > 0 && A(1) <= 4096 && A(2) > 0 && in_stage(A(4), A(1) * A(2)) && table(A(3)),
+                    "engine: corrupt plan (decode step)");
+        void *d = coder(p.decoders, A(0), false);
+        LSSVC_CHECK(d != nullptr, "engine: corrupt plan (decoder id)");
+        p.channel_idx.resize((size_t)(A(1) * A(2)));
+        for (int64_t c = 0; c < A(1); ++c)
+            for (int64_t i = 0; i < A(2); ++i) p.channel_idx[(size_t)(c * A(2) + i)] = (int16_t)c;
+        LSSVC_HIP(hipStreamSynchronize(main));
+        return lssvc_rans_decode_stream_i16(d, p.channel_idx.data(), A(1) * A(2), table(A(3)), p.stage_host + A(4));
+    }
+    default: return fail("engine: no host step for %s", l.fn.c_str());
+    }
 }
 
 int replay(Plan &p, hipStream_t main) {
@@ -292,7 +426,20 @@ int replay(Plan &p, hipStream_t main) {
         case FN_BOTTLENECK: rc = lssvc_entropy_bottleneck(V(0), (const float *)P(1), V(2), V(3), (double *)P(4), P(5), st); break;
         case FN_FILL_ZERO: rc = lssvc_fill_zero(P(0), l.args[1].i, st); break;
         case FN_CLAMP: rc = lssvc_clamp_inplace((float *)P(0), l.args[1].i, F(2), F(3), st); break;
-        default: return fail("engine: no replay for %s", l.fn.c_str());
+        case FN_EXPORT_I16:
+            rc = lssvc_export_symbols_i16(V(0), V(1), l.args[2].tag == TAG_I32ARRAY ? reinterpret_cast<const int32_t *>(l.args[2].blob.data()) : nullptr,
+                                          F(3), F(4), F(5), I(6), (int16_t *)P(7), (int16_t *)P(8), (int32_t *)P(9), st);
+            break;
+        case FN_IMPORT_I16:
+            rc = lssvc_import_symbols_i16((const int16_t *)P(0), V(1), (const float *)P(2),
+                                          l.args[3].tag == TAG_I32ARRAY ? reinterpret_cast<const int32_t *>(l.args[3].blob.data()) : nullptr, V(4), st);
+            break;
+        default:
+            if (l.id >= FN_H_D2H) {
+                rc = host_step(p, l, main);
+                break;
+            }
+            return fail("engine: no replay for %s", l.fn.c_str());
         }
         if (rc) return rc;
     }
@@ -303,8 +450,10 @@ struct Engine {
     int device = 0;
     hipStream_t own = nullptr;           // frames run here when the caller passes stream NULL (the null stream cannot be captured)
     std::unique_ptr<Plan> intra, first_p, steady_p;
+    std::unique_ptr<Plan> i_enc, i_dec, p1_enc, p1_dec, p_enc, p_dec;      // write_stream = 1 halves
     ~Engine() {
         intra.reset(), first_p.reset(), steady_p.reset();
+        i_enc.reset(), i_dec.reset(), p1_enc.reset(), p1_dec.reset(), p_enc.reset(), p_dec.reset();
         if (own) (void)hipStreamDestroy(own);
     }
     hipStream_t stream(void *s) const { return s ? (hipStream_t)s : own; }
@@ -322,6 +471,7 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
         LSSVC_CHECK(kv.second != nullptr, "engine: input %s is required by this plan", kv.first);
         LSSVC_HIP(hipMemcpyAsync(p.regions[i].ptr, kv.second, p.regions[i].nbytes, hipMemcpyDefault, st));
     }
+    LSSVC_CHECK(!p.has_host_steps, "engine: a '%s' plan runs through the encode / decode entry points", p.kind.c_str());
     if (p.runs == 0 || std::getenv("LSSVC_ENGINE_EAGER")) {
         if (int e = replay(p, st)) return e;
     } else {
@@ -350,7 +500,77 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
     return 0;
 }
 
+// Run the encoder or decoder half of a frame: inputs in, eager replay with its host steps, outputs out; the strings the
+// decoder reads are in p.in_strings, the strings the encoder wrote come back in p.out_strings.
+int run_stream_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &ins,
+                    const std::vector<std::pair<const char *, void *>> &outs, hipStream_t st) {
+    LSSVC_CHECK(p.has_host_steps, "engine: a '%s' plan has no coder steps", p.kind.c_str());
+    for (auto &kv : ins) {
+        const int i = p.region_index(kv.first, REGION_INPUT);
+        if (i < 0) {
+            LSSVC_CHECK(kv.second == nullptr, "engine: this plan takes no input named %s", kv.first);
+            continue;
+        }
+        LSSVC_CHECK(kv.second != nullptr, "engine: input %s is required by this plan", kv.first);
+        LSSVC_HIP(hipMemcpyAsync(p.regions[i].ptr, kv.second, p.regions[i].nbytes, hipMemcpyDefault, st));
+    }
+    p.out_strings.clear();
+    for (void *e : p.encoders)
+        if (e) lssvc_rans_encoder_reset(e);
+    if (int e = replay(p, st)) return e;
+    ++p.runs;
+    for (auto &kv : outs) {
+        if (!kv.second) continue;
+        const int i = p.region_index(kv.first, REGION_OUTPUT);
+        LSSVC_CHECK(i >= 0, "engine: this plan has no output named %s", kv.first);
+        LSSVC_HIP(hipMemcpyAsync(kv.second, p.regions[i].ptr, p.regions[i].nbytes, hipMemcpyDefault, st));
+    }
+    LSSVC_HIP(hipStreamSynchronize(st));
+    return 0;
+}
 
+// ---- layer files (src/utils/stream_helper.py:61-99; lssvc_amd/bitstream.py): big-endian u32 headers
+void put_be32(uint8_t *d, uint64_t v) {
+    d[0] = (uint8_t)(v >> 24), d[1] = (uint8_t)(v >> 16), d[2] = (uint8_t)(v >> 8), d[3] = (uint8_t)v;
+}
+uint32_t get_be32(const uint8_t *d) { return ((uint32_t)d[0] << 24) | ((uint32_t)d[1] << 16) | ((uint32_t)d[2] << 8) | d[3]; }
+
+// I-frame layer file = (height, width, len_y, len_z) + y string + z string
+int write_i_file(uint8_t *dst, int64_t cap, int64_t *len, int64_t height, int64_t width, const std::vector<uint8_t> &y, const std::vector<uint8_t> &z) {
+    const int64_t need = 16 + (int64_t)y.size() + (int64_t)z.size();
+    *len = need;
+    LSSVC_CHECK(dst && cap >= need, "engine: the layer file needs %lld bytes, the buffer holds %lld", (long long)need, (long long)cap);
+    put_be32(dst, (uint64_t)height), put_be32(dst + 4, (uint64_t)width), put_be32(dst + 8, y.size()), put_be32(dst + 12, z.size());
+    memcpy(dst + 16, y.data(), y.size());
+    memcpy(dst + 16 + y.size(), z.data(), z.size());
+    return 0;
+}
+// P-frame layer file = (len) + one rANS string
+int write_p_file(uint8_t *dst, int64_t cap, int64_t *len, const std::vector<uint8_t> &s) {
+    const int64_t need = 4 + (int64_t)s.size();
+    *len = need;
+    LSSVC_CHECK(dst && cap >= need, "engine: the layer file needs %lld bytes, the buffer holds %lld", (long long)need, (long long)cap);
+    put_be32(dst, s.size());
+    memcpy(dst + 4, s.data(), s.size());
+    return 0;
+}
+int read_i_file(const uint8_t *f, int64_t n, int64_t want_h, int64_t want_w, std::vector<std::pair<const uint8_t *, int64_t>> &strings) {
+    LSSVC_CHECK(f && n >= 16, "engine: truncated I-frame stream");
+    const int64_t h = get_be32(f), w = get_be32(f + 4), ly = get_be32(f + 8), lz = get_be32(f + 12);
+    LSSVC_CHECK(16 + ly + lz <= n, "engine: truncated I-frame stream");
+    LSSVC_CHECK(h == want_h && w == want_w, "engine: the stream codes a %lldx%lld picture, the loaded plan was compiled for %lldx%lld",
+                (long long)h, (long long)w, (long long)want_h, (long long)want_w);
+    strings.emplace_back(f + 16, ly);
+    strings.emplace_back(f + 16 + ly, lz);
+    return 0;
+}
+int read_p_file(const uint8_t *f, int64_t n, std::vector<std::pair<const uint8_t *, int64_t>> &strings) {
+    LSSVC_CHECK(f && n >= 4, "engine: truncated P-frame stream");
+    const int64_t len = get_be32(f);
+    LSSVC_CHECK(4 + len <= n, "engine: truncated P-frame stream");
+    strings.emplace_back(f + 4, len);
+    return 0;
+}
 
 }  // namespace
 
@@ -397,7 +617,8 @@ extern "C" int lssvc_engine_load_inter(void *h, const char *first_p_plan, const 
 extern "C" int lssvc_engine_set_scale(void *h, float scale, int32_t H, int32_t W) {
     LSSVC_CHECK(h, "engine_set_scale: bad arguments");
     Engine *e = static_cast<Engine *>(h);
-    for (Plan *p : {e->intra.get(), e->first_p.get(), e->steady_p.get()})
+    for (Plan *p : {e->intra.get(), e->first_p.get(), e->steady_p.get(), e->i_enc.get(), e->i_dec.get(), e->p1_enc.get(), e->p1_dec.get(),
+                    e->p_enc.get(), e->p_dec.get()})
         if (p)
             LSSVC_CHECK(std::fabs(p->scale - (double)scale) < 1e-9 && p->H == H && p->W == W,
                         "engine_set_scale: the loaded '%s' plan was compiled for scale %g, %dx%d (asked for %g, %dx%d)", p->kind.c_str(),
@@ -454,4 +675,81 @@ extern "C" int lssvc_engine_plan_info(void *h, int32_t which, int64_t *out6) {
     out6[4] = p->H;
     out6[5] = p->W;
     return 0;
+}
+
+// ---- write_stream = 1 ------------------------------------------------------------------------------------------------
+extern "C" int lssvc_engine_load_stream(void *h, const char *iframe_enc, const char *iframe_dec, const char *first_p_enc, const char *first_p_dec,
+                                        const char *steady_p_enc, const char *steady_p_dec) {
+    LSSVC_CHECK(h, "engine_load_stream: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    LSSVC_HIP(hipSetDevice(e->device));
+    struct { std::unique_ptr<Plan> *slot; const char *path, *kind; } todo[6] = {
+        {&e->i_enc, iframe_enc, "iframe_enc"}, {&e->i_dec, iframe_dec, "iframe_dec"}, {&e->p1_enc, first_p_enc, "pframe_first_enc"},
+        {&e->p1_dec, first_p_dec, "pframe_first_dec"}, {&e->p_enc, steady_p_enc, "pframe_enc"}, {&e->p_dec, steady_p_dec, "pframe_dec"}};
+    for (auto &t : todo)
+        if (t.path)
+            if (int rc = load_into(*t.slot, t.path, t.kind, nullptr)) return rc;
+    return 0;
+}
+
+extern "C" int lssvc_engine_encode_iframe(void *h, const float *x_bl, const float *x_el, uint8_t *bl_file, int64_t bl_cap, int64_t *bl_len,
+                                          uint8_t *el_file, int64_t el_cap, int64_t *el_len, float *x_hat_bl, float *x_hat_el,
+                                          float *feature_el, void *stream) {
+    LSSVC_CHECK(h && bl_len && el_len, "engine_encode_iframe: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    Plan *p = e->i_enc.get();
+    LSSVC_CHECK(p != nullptr, "engine_encode_iframe: no I-frame encoder plan loaded");
+    if (int rc = run_stream_plan(*p, {{"x_bl", x_bl}, {"x_el", x_el}}, {{"x_hat_bl", x_hat_bl}, {"x_hat_el", x_hat_el}, {"feature_el", feature_el}},
+                                 e->stream(stream)))
+        return rc;
+    LSSVC_CHECK(p->out_strings.size() == 4, "engine_encode_iframe: the plan produced %zu strings, not y and z of two layers", p->out_strings.size());
+    if (int rc = write_i_file(bl_file, bl_cap, bl_len, p->meta_value("pic_height_bl", 0), p->meta_value("pic_width_bl", 0), p->out_strings[0], p->out_strings[1]))
+        return rc;
+    return write_i_file(el_file, el_cap, el_len, p->meta_value("pic_height_el", 0), p->meta_value("pic_width_el", 0), p->out_strings[2], p->out_strings[3]);
+}
+
+extern "C" int lssvc_engine_decode_iframe(void *h, const uint8_t *bl_file, int64_t bl_len, const uint8_t *el_file, int64_t el_len, float *x_hat_bl,
+                                          float *x_hat_el, float *feature_el, void *stream) {
+    LSSVC_CHECK(h, "engine_decode_iframe: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    Plan *p = e->i_dec.get();
+    LSSVC_CHECK(p != nullptr, "engine_decode_iframe: no I-frame decoder plan loaded");
+    p->in_strings.clear();
+    if (int rc = read_i_file(bl_file, bl_len, p->meta_value("pic_height_bl", 0), p->meta_value("pic_width_bl", 0), p->in_strings)) return rc;
+    if (int rc = read_i_file(el_file, el_len, p->meta_value("pic_height_el", 0), p->meta_value("pic_width_el", 0), p->in_strings)) return rc;
+    return run_stream_plan(*p, {}, {{"x_hat_bl", x_hat_bl}, {"x_hat_el", x_hat_el}, {"feature_el", feature_el}}, e->stream(stream));
+}
+
+extern "C" int lssvc_engine_encode_pframe(void *h, const float *x_bl, const float *x_el, const float *ref_frame_bl, const float *ref_frame_el,
+                                          const float *ref_feature_bl, const float *ref_feature_el, uint8_t *bl_file, int64_t bl_cap,
+                                          int64_t *bl_len, uint8_t *el_file, int64_t el_cap, int64_t *el_len, float *recon_bl, float *feature_bl,
+                                          float *recon_el, float *feature_el, void *stream) {
+    LSSVC_CHECK(h && bl_len && el_len, "engine_encode_pframe: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    Plan *p = ref_feature_bl ? e->p_enc.get() : e->p1_enc.get();
+    LSSVC_CHECK(p != nullptr, "engine_encode_pframe: no %s encoder plan loaded", ref_feature_bl ? "steady-P" : "first-P");
+    if (int rc = run_stream_plan(*p, {{"x_bl", x_bl}, {"x_el", x_el}, {"ref_frame_bl", ref_frame_bl}, {"ref_frame_el", ref_frame_el},
+                                      {"ref_feature_bl", ref_feature_bl}, {"ref_feature_el", ref_feature_el}},
+                                 {{"recon_bl", recon_bl}, {"feature_bl", feature_bl}, {"recon_el", recon_el}, {"feature_el", feature_el}},
+                                 e->stream(stream)))
+        return rc;
+    LSSVC_CHECK(p->out_strings.size() == 2, "engine_encode_pframe: the plan produced %zu strings, not one per layer", p->out_strings.size());
+    if (int rc = write_p_file(bl_file, bl_cap, bl_len, p->out_strings[0])) return rc;
+    return write_p_file(el_file, el_cap, el_len, p->out_strings[1]);
+}
+
+extern "C" int lssvc_engine_decode_pframe(void *h, const uint8_t *bl_file, int64_t bl_len, const uint8_t *el_file, int64_t el_len,
+                                          const float *ref_frame_bl, const float *ref_frame_el, const float *ref_feature_bl,
+                                          const float *ref_feature_el, float *recon_bl, float *feature_bl, float *recon_el, float *feature_el,
+                                          void *stream) {
+    LSSVC_CHECK(h, "engine_decode_pframe: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    Plan *p = ref_feature_bl ? e->p_dec.get() : e->p1_dec.get();
+    LSSVC_CHECK(p != nullptr, "engine_decode_pframe: no %s decoder plan loaded", ref_feature_bl ? "steady-P" : "first-P");
+    p->in_strings.clear();
+    if (int rc = read_p_file(bl_file, bl_len, p->in_strings)) return rc;
+    if (int rc = read_p_file(el_file, el_len, p->in_strings)) return rc;
+    return run_stream_plan(*p, {{"ref_frame_bl", ref_frame_bl}, {"ref_frame_el", ref_frame_el}, {"ref_feature_bl", ref_feature_bl},
+                                {"ref_feature_el", ref_feature_el}},
+                           {{"recon_bl", recon_bl}, {"feature_bl", feature_bl}, {"recon_el", recon_el}, {"feature_el", feature_el}}, e->stream(stream));
 }

@@ -468,5 +468,5 @@ class IntraSS(_HostModel):
 
     def _dev_medians(self, which):
         if which not in self._medians:
-            self._medians[which] = torch.from_numpy(self._tables[which][1]).to(self.device)
+            self._medians[which] = self.W._dev(torch.from_numpy(self._tables[which][1]))      # (registered: plan_compiler stores it with the weights)
         return self._medians[which]

@@ -27,6 +27,9 @@ from . import _lib
 from . import hip_ops as ops
 
 MAGIC = b"LSSVCPL1"
+# host steps of the write_stream = 1 plans, stored in the launch list where the front end performed them (names start with "__")
+HOST_D2H, HOST_H2D, HOST_ENCODE, HOST_FLUSH, HOST_SET_STREAM, HOST_DECODE, HOST_DECODE_CH = (
+    "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__")
 REGION_ARENA, REGION_WEIGHTS, REGION_SCRATCH, REGION_INPUT, REGION_OUTPUT = range(5)
 TAG_NULL, TAG_PTR, TAG_STRUCT, TAG_F32, TAG_I32, TAG_I64, TAG_I32ARRAY, TAG_STREAM = range(8)
 FN_WAIT = "__wait__"
@@ -101,6 +104,18 @@ class Recorder:
         self.launches = []
         self.streams = {}
         self._orig = {}
+        self.tables = []          # entropy_coder.Tables objects of the host steps, in first-use order
+        self._table_ids = {}
+
+    def host(self, name, *ints):
+        """A host step between launches (write_stream = 1 plans): performed by the runtime on the main stream, in order."""
+        self.launches.append((name, 0, [(TAG_I64, int(v)) for v in ints]))
+
+    def table_id(self, tables):
+        if id(tables) not in self._table_ids:
+            self._table_ids[id(tables)] = len(self.tables)
+            self.tables.append(tables)
+        return self._table_ids[id(tables)]
 
     # ---- pointers ------------------------------------------------------------------------------------------------
     def _resolve(self, p):
@@ -133,7 +148,9 @@ class Recorder:
         enc, stream = [], 0
         last_ptr = max(i for i, t in enumerate(argtypes) if t is C.c_void_p)
         for i, (a, t) in enumerate(zip(args, argtypes)):
-            if t is C.c_void_p:
+            if t is C.c_void_p and isinstance(a, C.Array):     # a small host int32 array handed to a `const int32_t *` (chunk_of_mask)
+                enc.append((TAG_I32ARRAY, [int(x) for x in a]))
+            elif t is C.c_void_p:
                 v = a.value if isinstance(a, C.c_void_p) else a
                 if i == last_ptr:                              # every launching entry point ends with `void *stream`
                     stream = self._stream(v)
@@ -199,7 +216,7 @@ class Recorder:
             return b + b"\0" * (48 - len(b))
         out = bytearray()
         out += MAGIC
-        out += struct.pack("<5I", len(self.regions), len(self.launches), max(len(self.streams), 1), len(meta), 0)
+        out += struct.pack("<5I", len(self.regions), len(self.launches), max(len(self.streams), 1), len(meta), len(self.tables))
         out += struct.pack("<d2i", float(scale), int(shape_hr[0]), int(shape_hr[1]))
         out += s48(kind)
         for name, v in meta:
@@ -227,6 +244,8 @@ class Recorder:
                     out += struct.pack("<q", a[1])
                 elif tag == TAG_I32ARRAY:
                     out += struct.pack("<I", len(a[1])) + struct.pack("<%di" % len(a[1]), *a[1])
+        for t in self.tables:                                   # CDF tables of the host coder: rows, stride, cdfs, sizes, offsets (int32)
+            out += struct.pack("<2I", t.cdfs.shape[0], t.cdfs.shape[1]) + t.cdfs.tobytes() + t.sizes.tobytes() + t.offsets.tobytes()
         with open(path, "wb") as f:
             f.write(out)
             for r in self.regions:                              # weight payloads, in region order, 256-byte aligned
@@ -234,10 +253,106 @@ class Recorder:
                     pad = -f.tell() % 256
                     f.write(b"\0" * pad)
                     f.write(r["data"].contiguous().cpu().numpy().tobytes())
-        return {"launches": len(self.launches), "regions": len(self.regions), "arena_bytes": self.arena.peak, "streams": len(self.streams)}
+        return {"launches": len(self.launches), "regions": len(self.regions), "arena_bytes": self.arena.peak, "streams": len(self.streams),
+                "host_steps": sum(1 for n, _, _ in self.launches if n.startswith("__") and n != FN_WAIT), "tables": len(self.tables)}
 
 
-def _record(model, body_inputs, run, outputs, path, kind, arena_gib, meta=()):
+class StreamHooks:
+    """While a write_stream = 1 pass is recorded: every step the front end performs on the HOST between launches -- staging
+    copies of the int16 planes (hip_ops.SymbolStage), the rANS coder calls (entropy_coder) -- is written into the launch
+    list at the point where it happened, with stage offsets instead of addresses, table ids instead of objects and the
+    coders numbered in creation order (= the order of the strings in the layer files)."""
+
+    def __init__(self, rec, stage):
+        self.rec, self.stage = rec, stage
+        self.n_enc = self.n_dec = self.n_out = 0
+        self._saved = []
+
+    def _off(self, a):
+        """element offset of a numpy int16 view inside the stage's pinned buffer, or None"""
+        base = self.stage.host.data_ptr()
+        p = a.ctypes.data
+        if a.dtype.name == "int16" and base <= p and p + 2 * a.size <= base + 2 * self.stage.capacity:
+            return (p - base) // 2
+        return None
+
+    def _patch(self, cls, name, fn):
+        self._saved.append((cls, name, cls.__dict__[name]))
+        setattr(cls, name, fn)
+
+    def __enter__(self):
+        from . import entropy_coder as ec
+        hooks, rec = self, self.rec
+        st_cls, enc_cls, dec_cls = ops.SymbolStage, ec.RansEncoder, ec.RansDecoder
+        o_begin, o_down, o_up = st_cls.begin, st_cls.download, st_cls.upload
+        o_einit, o_eenc, o_eflush = enc_cls.__init__, enc_cls.encode_with_indexes, enc_cls.flush
+        o_dinit, o_dset, o_ddec = dec_cls.__init__, dec_cls.set_stream, dec_cls.decode_stream
+
+        def begin(st, capacity):
+            assert st is hooks.stage and capacity <= st.capacity, "the stage must not grow while a plan is recorded"
+            r = o_begin(st, capacity)
+            _lib.check(_lib.lib.lssvc_fill_zero(C.c_void_p(st.flag.data_ptr()), 4, ops.stream_ptr()))     # the recorded form of flag.zero_()
+            return r
+
+        def download(st, lo, hi):
+            if not (lo >= st._down[0] and hi <= st._down[1]):
+                rec.host(HOST_D2H, lo, hi)
+            return o_down(st, lo, hi)
+
+        def upload(st, ref):
+            rec.host(HOST_H2D, ref.off, ref.n)
+            return o_up(st, ref)
+
+        def einit(enc):
+            o_einit(enc)
+            enc._plan_id = hooks.n_enc
+            hooks.n_enc += 1
+
+        def eenc(enc, symbols, indexes, tables):
+            so, io = hooks._off(symbols), hooks._off(indexes)
+            assert so is not None and io is not None, "stream plans code from the staged int16 planes only"
+            rec.host(HOST_ENCODE, enc._plan_id, so, io, symbols.size, rec.table_id(tables))
+            return o_eenc(enc, symbols, indexes, tables)
+
+        def eflush(enc):
+            rec.host(HOST_FLUSH, enc._plan_id, hooks.n_out)
+            hooks.n_out += 1
+            return o_eflush(enc)
+
+        def dinit(dec):
+            o_dinit(dec)
+            dec._plan_id = hooks.n_dec
+            hooks.n_dec += 1
+
+        def dset(dec, data):
+            rec.host(HOST_SET_STREAM, dec._plan_id, dec._plan_id)        # string k of the layer files feeds decoder k
+            return o_dset(dec, data)
+
+        def ddec(dec, indexes, tables, out=None):
+            oo = hooks._off(out) if out is not None else None
+            assert oo is not None, "stream plans decode into the staged int16 planes only"
+            io = hooks._off(indexes)
+            if io is not None:
+                rec.host(HOST_DECODE, dec._plan_id, io, indexes.size, rec.table_id(tables), oo)
+            else:                                                       # the channel-number plane of a factorised table (intra._channel_indexes)
+                c = int(indexes[-1]) + 1
+                assert indexes.size % c == 0 and int(indexes[0]) == 0
+                rec.host(HOST_DECODE_CH, dec._plan_id, c, indexes.size // c, rec.table_id(tables), oo)
+            return o_ddec(dec, indexes, tables, out=out)
+
+        for cls, name, fn in ((st_cls, "begin", begin), (st_cls, "download", download), (st_cls, "upload", upload),
+                              (enc_cls, "__init__", einit), (enc_cls, "encode_with_indexes", eenc), (enc_cls, "flush", eflush),
+                              (dec_cls, "__init__", dinit), (dec_cls, "set_stream", dset), (dec_cls, "decode_stream", ddec)):
+            self._patch(cls, name, fn)
+        return self
+
+    def __exit__(self, *exc):
+        for cls, name, fn in reversed(self._saved):
+            setattr(cls, name, fn)
+        return False
+
+
+def _record(model, body_inputs, run, outputs, path, kind, arena_gib, meta=(), stream_mode=False):
     """Run `run()` (which must issue the frame through `model` from the NCHW tensors in body_inputs and write the NCHW
     results into the tensors in `outputs`) once eagerly to warm everything up, then once under the recorder."""
     device = model.device
@@ -247,9 +362,16 @@ def _record(model, body_inputs, run, outputs, path, kind, arena_gib, meta=()):
     scratch = {"bits": model.slots.vals}
     for i, ws in enumerate(list(model.slots._ws.values()) + list(model.slots._free)):
         scratch["reduce_ws%d" % i] = ws
+    if stream_mode:                                         # the int16 staging buffer of the symbol / index planes and its overflow flag
+        scratch["stage_dev"] = model.stage.dev
+        scratch["stage_flag"] = model.stage.flag
     rec = Recorder(device, int(arena_gib * 2 ** 30), [model.W], scratch, body_inputs, outputs)
     with rec:
-        run()
+        if stream_mode:
+            with StreamHooks(rec, model.stage):
+                run()
+        else:
+            run()
     torch.cuda.synchronize(device)
     info = rec.save(path, kind, model.scale_factor, model.shape_hr, meta)
     return info
@@ -302,3 +424,127 @@ def compile_pframe(pnet, x_bl, x_el, dpb, path, arena_gib=None):
     info = _record(pnet, ins, run, outs, path, "pframe_first" if first else "pframe", arena_gib,
                    meta=(("ref_feature_el_channels", ins["ref_feature_el"].shape[1]),))
     return info, outs
+
+
+# ---- write_stream = 1: encoder and decoder plans (GPU launches + the host coder's steps between them) ------------------------
+def _nchw_out(t, dst, clamp=False):
+    _lib.check(_lib.lib.lssvc_nhwc_to_nchw(t.ref, C.c_void_p(dst.data_ptr()), ops.stream_ptr()))
+    if clamp:
+        _lib.check(_lib.lib.lssvc_clamp_inplace(C.c_void_p(dst.data_ptr()), dst.numel(), 0.0, 1.0, ops.stream_ptr()))
+
+
+def compile_iframe_stream(inet, x_bl, x_el, path_enc, path_dec, arena_gib=None):
+    """The two write_stream = 1 plans of an I-frame: IntraSS.encode_decode with bin paths, split into its encoder half
+    (IntraNoAR.compress + IntraSS.compress, priors.py:422-437, IntraSS.py:304-314 -> the y and z strings of both layers)
+    and its decoder half (decompress, priors.py:439-452, IntraSS.py:316-336). inet.update() must have been called.
+    Returns (info_enc, info_dec, strings): the four rANS strings the recorded encoder pass produced."""
+    from .hip_ops import T
+    from .entropy_coder import SymbolSink, SymbolSource
+    from . import bitstream
+    assert inet._tables is not None, "call update() first"
+    H, W = inet.shape_hr
+    h, w = x_bl.shape[2], x_bl.shape[3]
+    arena_gib = arena_gib if arena_gib is not None else max(0.25, 8.0 * H * W / (1152.0 * 1920.0))
+    dev = inet.device
+    mk = lambda: {"x_hat_bl": torch.empty(1, 3, h, w, device=dev), "x_hat_el": torch.empty(1, 3, H, W, device=dev),
+                  "feature_el": torch.empty(1, 64, H, W, device=dev)}
+    ins = {"x_bl": x_bl.contiguous(), "x_el": x_el.contiguous()}
+    meta = (("pic_height_bl", h), ("pic_width_bl", w), ("pic_height_el", H), ("pic_width_el", W))
+    strings = []
+
+    def finish(outs, x_hat_bl, x_hat, feature):
+        _nchw_out(x_hat_bl, outs["x_hat_bl"])
+        _nchw_out(x_hat, outs["x_hat_el"])
+        _nchw_out(feature, outs["feature_el"])
+
+    outs_e = mk()
+
+    def run_enc():
+        del strings[:]
+        st = inet._begin_layer()
+        sinks = (SymbolSink(st), SymbolSink(st))
+        x_hat_bl, y_hat_bl = inet._bl_codec(T.from_nchw(ins["x_bl"]), sinks=sinks)
+        strings.extend([sinks[0].flush(), sinks[1].flush()])
+        st = inet._begin_layer()
+        sinks = (SymbolSink(st), SymbolSink(st))
+        feature, x_hat = inet._el_codec(T.from_nchw(ins["x_el"]), x_hat_bl, y_hat_bl, sinks=sinks)
+        strings.extend([sinks[0].flush(), sinks[1].flush()])
+        finish(outs_e, x_hat_bl, x_hat, feature)
+
+    info_e = _record(inet, ins, run_enc, outs_e, path_enc, "iframe_enc", arena_gib, meta, stream_mode=True)
+    coded = list(strings)
+    outs_d = mk()
+
+    def run_dec():
+        st = inet._begin_layer()
+        x_hat_bl, y_hat_bl = inet._bl_codec(None, sources=(SymbolSource(coded[0], st), SymbolSource(coded[1], st)),
+                                            lat_hw=bitstream.get_downsampled_shape(h, w, 64))
+        st = inet._begin_layer()
+        feature, x_hat = inet._el_codec(None, x_hat_bl, y_hat_bl, sources=(SymbolSource(coded[2], st), SymbolSource(coded[3], st)),
+                                        lat_hw=bitstream.get_downsampled_shape(H, W, 64))
+        finish(outs_d, x_hat_bl, x_hat, feature)
+
+    info_d = _record(inet, {}, run_dec, outs_d, path_dec, "iframe_dec", arena_gib, meta, stream_mode=True)
+    for k in outs_e:
+        assert torch.equal(outs_e[k], outs_d[k]), "decoder plan does not reproduce the encoder's %s" % k
+    return info_e, info_d, coded
+
+
+def compile_pframe_stream(pnet, x_bl, x_el, dpb, path_enc, path_dec, arena_gib=None):
+    """The two write_stream = 1 plans of a P-frame (LSSVC_extend.encode_decode_extend, LSSVC_net_extend.py:138-191, with
+    DMCExtend's, dmc_net_extend.py:148-173): encoder half (compress: one rANS string per layer) and decoder half (decompress).
+    The DPB decides first-P / steady-P as in compile_pframe. Outputs of both: the next DPB -- recon_bl (clamped to [0, 1], as
+    the reference's base-layer decoder returns it, dmc_net_extend.py:138), feature_bl, recon_el, feature_el."""
+    from .hip_ops import T
+    from .entropy_coder import SymbolSink, SymbolSource
+    assert pnet._tables is not None, "call update() first"
+    H, W = pnet.shape_hr
+    h, w = x_bl.shape[2], x_bl.shape[3]
+    arena_gib = arena_gib if arena_gib is not None else max(0.5, 26.0 * H * W / (1152.0 * 1920.0))
+    dev = pnet.device
+    refs = {"ref_frame_bl": dpb["ref_frame_bl"].contiguous(), "ref_frame_el": dpb["ref_frame_el"].contiguous(),
+            "ref_feature_el": dpb["ref_feature_el"].contiguous()}
+    if dpb["ref_feature_bl"] is not None:
+        refs["ref_feature_bl"] = dpb["ref_feature_bl"].contiguous()
+    ins = dict(refs, x_bl=x_bl.contiguous(), x_el=x_el.contiguous())
+    mk = lambda: {"recon_bl": torch.empty(1, 3, h, w, device=dev), "feature_bl": torch.empty(1, 64, h, w, device=dev),
+                  "recon_el": torch.empty(1, 3, H, W, device=dev), "feature_el": torch.empty(1, 48, H, W, device=dev)}
+    first = dpb["ref_feature_bl"] is None
+    meta = (("ref_feature_el_channels", refs["ref_feature_el"].shape[1]),)
+    strings = []
+
+    def nhwc(d, k):
+        return T.from_nchw(d[k]) if k in d else None
+
+    def finish(outs, bl, recon_el, feature):
+        _nchw_out(bl["recon"], outs["recon_bl"], clamp=True)
+        _nchw_out(bl["feature"], outs["feature_bl"])
+        _nchw_out(recon_el, outs["recon_el"])
+        _nchw_out(feature, outs["feature_el"])
+
+    outs_e = mk()
+
+    def run_enc():
+        del strings[:]
+        sink = SymbolSink(pnet._begin_layer())
+        bl = pnet._bl_codec(nhwc(ins, "x_bl"), nhwc(ins, "ref_frame_bl"), nhwc(ins, "ref_feature_bl"), sink=sink)
+        strings.append(sink.flush())
+        sink = SymbolSink(pnet._begin_layer())
+        feature, recon_el, _, _ = pnet._el_codec(nhwc(ins, "x_el"), bl, nhwc(ins, "ref_frame_el"), nhwc(ins, "ref_feature_el"), sink=sink)
+        strings.append(sink.flush())
+        finish(outs_e, bl, recon_el, feature)
+
+    info_e = _record(pnet, ins, run_enc, outs_e, path_enc, "pframe_first_enc" if first else "pframe_enc", arena_gib, meta, stream_mode=True)
+    coded = list(strings)
+    outs_d = mk()
+
+    def run_dec():
+        bl = pnet._bl_codec(None, nhwc(refs, "ref_frame_bl"), nhwc(refs, "ref_feature_bl"), source=SymbolSource(coded[0], pnet._begin_layer()))
+        feature, recon_el, _, _ = pnet._el_codec(None, bl, nhwc(refs, "ref_frame_el"), nhwc(refs, "ref_feature_el"),
+                                                 source=SymbolSource(coded[1], pnet._begin_layer()))
+        finish(outs_d, bl, recon_el, feature)
+
+    info_d = _record(pnet, refs, run_dec, outs_d, path_dec, "pframe_first_dec" if first else "pframe_dec", arena_gib, meta, stream_mode=True)
+    for k in outs_e:
+        assert torch.equal(outs_e[k], outs_d[k]), "decoder plan does not reproduce the encoder's %s" % k
+    return info_e, info_d, coded

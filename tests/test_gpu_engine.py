@@ -102,3 +102,95 @@ def test_c_program_codes_a_gop_through_compiled_plans(tmp_path):
             p_el = psnr(x_el[t].cpu(), got[1].clamp(0, 1))
             assert abs(p_el - z["f%d_psnr" % t][1]) <= 1e-4
     assert pos == raw.size
+
+
+def test_c_programs_write_and_read_real_bitstreams(tmp_path):
+    """write_stream = 1 through the engine: encoder and decoder plans compiled by the front end
+    (plan_compiler.compile_iframe_stream / compile_pframe_stream), then tests/engine_stream_demo.c -- plain C -- runs TWICE as
+    separate processes: `enc` codes I + P + P + P + P into the reference's layer files, `dec` (a fresh process that is given only
+    the decoder plans and those files) reconstructs them. The files must be byte for byte what the Python path writes for the
+    same frames, and encoder-side, decoder-side and Python reconstructions must be identical bit for bit."""
+    from lssvc_amd import IntraSS, LSSVC_extend, plan_compiler
+    from lssvc_amd.synth import synth_state_dict
+    z, m = load_case("x2_128_ipp")
+    H, W, h, w = m["H"], m["W"], m["h"], m["w"]
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", m["seed"], m["gain"])).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", m["seed"], m["gain"]))
+    pnet.to(DEV).eval()
+    order = [0, 1, 2, 1, 2]
+    x_el = [(torch.from_numpy(z["x_el_u8"][t:t + 1]).float() / 255.0).to(DEV) for t in order]
+    x_bl = [torch.from_numpy(z["x_bl"][t:t + 1]).to(DEV) for t in order]
+    for net in (inet, pnet):
+        net.set_scale_information(m["scale"], (H, W), (0, 0, 0, 0))
+        net.update(force=True)
+
+    # ---- the Python path with real bitstreams: expected files and reconstructions, and the DPBs the plans are compiled from
+    py = tmp_path / "py"
+    py.mkdir()
+    want, dpbs, dpb = [], [], None
+    for t in range(len(order)):
+        pb, pe = str(py / ("%d_BL.bin" % t)), str(py / ("%d_EL.bin" % t))
+        if t == 0:
+            r = inet.encode_decode(x_bl[t], x_el[t], pb, pe, h, w, H, W)
+            dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+        else:
+            r = pnet.encode_decode(x_bl[t], x_el[t], dpb, pb, pe, W, H, w, h)
+            dpb = r["dpb"]
+        want.append([v.contiguous().clone().cpu() for v in (dpb["ref_frame_bl"], dpb["ref_frame_el"], dpb["ref_feature_el"])]
+                    + ([dpb["ref_feature_bl"].contiguous().clone().cpu()] if t else []))
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        dpbs.append({k: (None if v is None else v.contiguous().clone()) for k, v in dpb.items()})
+
+    # ---- compile the six halves
+    d = tmp_path / "eng"
+    d.mkdir()
+    ie, idc, s_i = plan_compiler.compile_iframe_stream(inet, x_bl[0], x_el[0], str(d / "i_enc.plan"), str(d / "i_dec.plan"))
+    e1, d1, s_1 = plan_compiler.compile_pframe_stream(pnet, x_bl[1], x_el[1], dpbs[0], str(d / "p1_enc.plan"), str(d / "p1_dec.plan"))
+    e2, d2, s_2 = plan_compiler.compile_pframe_stream(pnet, x_bl[2], x_el[2], dpbs[1], str(d / "p_enc.plan"), str(d / "p_dec.plan"))
+    print("stream plans:", ie, idc, e1, d1, e2, d2)
+    assert ie["host_steps"] >= 8 and d2["host_steps"] >= 20 and e2["tables"] >= 3
+    assert len(s_i) == 4 and len(s_1) == 2 and len(s_2) == 2
+
+    # ---- the C program: encoder process, then decoder process
+    case, exe = str(tmp_path / "case.bin"), str(tmp_path / "engine_stream_demo")
+    with open(case, "wb") as f:
+        f.write(struct.pack("<5if", len(order), H, W, h, w, m["scale"]))
+        for t in range(len(order)):
+            f.write(x_bl[t].cpu().contiguous().numpy().tobytes())
+            f.write(x_el[t].cpu().contiguous().numpy().tobytes())
+    libdir = os.path.join(ROOT, "lssvc_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "engine_stream_demo.c"),
+                           "-L", libdir, "-llssvc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    for role in ("enc", "dec"):
+        res = subprocess.run([exe, role, str(d), case], capture_output=True, text=True, env=env, timeout=600)
+        print(res.stdout, res.stderr)
+        assert res.returncode == 0, res.stderr
+
+    # ---- compare: files, then tensors
+    for t in range(len(order)):
+        for tag in ("BL", "EL"):
+            a = open(str(py / ("%d_%s.bin" % (t, tag))), "rb").read()
+            b = open(str(d / ("%d_%s.bin" % (t, tag))), "rb").read()
+            assert a == b, (t, tag, len(a), len(b))
+    outs = {}
+    for role in ("enc", "dec"):
+        raw = np.fromfile(str(d / (role + ".out")), dtype=np.float32)
+        pos, frames = 0, []
+        for t in range(len(order)):
+            shapes = [(1, 3, h, w), (1, 3, H, W), (1, 64 if t == 0 else 48, H, W)] + ([(1, 64, h, w)] if t else [])
+            got = []
+            for sh in shapes:
+                n = int(np.prod(sh))
+                got.append(torch.from_numpy(raw[pos:pos + n].reshape(sh).copy()))
+                pos += n
+            frames.append(got)
+        assert pos == raw.size
+        outs[role] = frames
+    for t in range(len(order)):
+        for k, (e, dd, x) in enumerate(zip(outs["enc"][t], outs["dec"][t], want[t])):
+            assert torch.equal(e, dd), (t, k, "encoder-side and decoder-side reconstructions differ")
+            assert torch.equal(dd, x), (t, k, (dd - x).abs().max().item())
