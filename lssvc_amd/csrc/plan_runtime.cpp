@@ -71,7 +71,7 @@ enum Fn {
     FN_WAIT, FN_CONV2D, FN_CONV1X1_DW, FN_FFN, FN_DWCONV, FN_RESIZE, FN_WARP, FN_POOL, FN_SOFTMAX2, FN_ADD, FN_COPY, FN_LRELU,
     FN_OFFSET_DIVERSITY, FN_NCHW_TO_NHWC, FN_NHWC_TO_NCHW, FN_LAPLACE_QUANT_BITS, FN_FOUR_PART_STEP, FN_LAPLACE_BITS,
     FN_FACTORIZED, FN_GAUSSIAN, FN_BOTTLENECK, FN_FILL_ZERO, FN_CLAMP, FN_EXPORT_I16, FN_IMPORT_I16,
-    FN_H_D2H, FN_H_H2D, FN_H_ENCODE, FN_H_FLUSH, FN_H_SET_STREAM, FN_H_DECODE, FN_H_DECODE_CH, FN_COUNT
+    FN_H_D2H, FN_H_H2D, FN_H_ENCODE, FN_H_FLUSH, FN_H_SET_STREAM, FN_H_DECODE, FN_H_DECODE_CH, FN_H_D2H_ASYNC, FN_H_D2H_WAIT, FN_COUNT
 };
 const char *const kFnNames[FN_COUNT] = {
     "__wait__", "lssvc_conv2d", "lssvc_conv1x1_dw3x3_f16x3", "lssvc_ffn_f16x3", "lssvc_dwconv3x3", "lssvc_resize_bilinear",
@@ -79,7 +79,7 @@ const char *const kFnNames[FN_COUNT] = {
     "lssvc_nchw_to_nhwc", "lssvc_nhwc_to_nchw", "lssvc_laplace_quant_bits", "lssvc_four_part_step", "lssvc_laplace_bits",
     "lssvc_factorized_quant_bits", "lssvc_gaussian_conditional", "lssvc_entropy_bottleneck", "lssvc_fill_zero", "lssvc_clamp_inplace",
     "lssvc_export_symbols_i16", "lssvc_import_symbols_i16",
-    "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__"};
+    "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__", "__d2h_async__", "__d2h_wait__"};
 
 struct Table {                           // one entropy_coder.Tables: quantised CDF rows + used lengths + symbol offsets
     std::vector<int32_t> cdfs, sizes, offsets;
@@ -105,6 +105,7 @@ struct Plan {
     int stage_region = -1, flag_region = -1;
     int16_t *stage_host = nullptr;       // pinned mirror of the staging region
     int32_t *flag_host = nullptr;
+    hipEvent_t staged = nullptr;         // behind the asynchronous plane copy of SymbolStage.prefetch
     std::vector<void *> encoders, decoders;
     std::vector<std::pair<const uint8_t *, int64_t>> in_strings;
     std::vector<std::vector<uint8_t>> out_strings;
@@ -117,6 +118,7 @@ struct Plan {
             if (d) lssvc_rans_decoder_free(d);
         if (stage_host) (void)hipHostFree(stage_host);
         if (flag_host) (void)hipHostFree(flag_host);
+        if (staged) (void)hipEventDestroy(staged);
         if (exec) (void)hipGraphExecDestroy(exec);
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto s : side) (void)hipStreamDestroy(s);
@@ -273,6 +275,7 @@ int load_plan(const char *path, Plan &p) {
         LSSVC_CHECK(p.stage_region >= 0 && p.flag_region >= 0, "engine: a plan with host steps needs the staging regions");
         LSSVC_HIP(hipHostMalloc((void **)&p.stage_host, p.regions[p.stage_region].nbytes, hipHostMallocDefault));
         LSSVC_HIP(hipHostMalloc((void **)&p.flag_host, sizeof(int32_t), hipHostMallocDefault));
+        LSSVC_HIP(hipEventCreateWithFlags(&p.staged, hipEventDisableTiming));
     }
     for (uint32_t s = 1; s < p.n_streams; ++s) {
         hipStream_t st;
@@ -326,6 +329,16 @@ int host_step(Plan &p, const Launch &l, hipStream_t main) {
         LSSVC_CHECK(*p.flag_host == 0, "engine: a quantised latent does not fit the 16-bit symbol planes");
         return 0;
     }
+    case FN_H_D2H_ASYNC:                                 // SymbolStage.prefetch: the same copy, not waited for; the kernels that follow overlap the host coder
+        LSSVC_CHECK(l.args.size() == 2 && in_stage(A(0), A(1) - A(0)), "engine: corrupt plan (d2h step)");
+        LSSVC_HIP(hipMemcpyAsync(p.stage_host + A(0), dev + A(0), 2 * (size_t)(A(1) - A(0)), hipMemcpyDeviceToHost, main));
+        LSSVC_HIP(hipMemcpyAsync(p.flag_host, p.regions[p.flag_region].ptr, sizeof(int32_t), hipMemcpyDeviceToHost, main));
+        LSSVC_HIP(hipEventRecord(p.staged, main));
+        return 0;
+    case FN_H_D2H_WAIT:                                  // ... SymbolStage.download of a prefetched range: wait for that copy only
+        LSSVC_HIP(hipEventSynchronize(p.staged));
+        LSSVC_CHECK(*p.flag_host == 0, "engine: a quantised latent does not fit the 16-bit symbol planes");
+        return 0;
     case FN_H_H2D:                                       // SymbolStage.upload
         LSSVC_CHECK(l.args.size() == 2 && in_stage(A(0), A(1)), "engine: corrupt plan (h2d step)");
         LSSVC_HIP(hipMemcpyAsync(dev + A(0), p.stage_host + A(0), 2 * (size_t)A(1), hipMemcpyHostToDevice, main));

@@ -717,6 +717,7 @@ class SymbolStage:
             self.host_np = self.host.numpy()
         self.used = 0
         self._down = (0, 0)
+        self._pre = None
         self.flag.zero_()
         return self
 
@@ -736,15 +737,30 @@ class SymbolStage:
     def numpy(self, ref):
         return self.host_np[ref.off:ref.off + ref.n]
 
+    def prefetch(self):
+        """Encoder side, called right after a layer's LAST plane has been exported: put the copy of everything staged so far
+        on the stream NOW, with an event behind it. The kernels the codec issues after this point (the layer's synthesis
+        transform and reconstruction network: a third of a P-frame) then run while the host codes the planes, instead of
+        the host waiting for them before it starts."""
+        if self.used == 0:
+            return
+        self.host[0:self.used].copy_(self.dev[0:self.used], non_blocking=True)
+        self.flag_host.copy_(self.flag, non_blocking=True)
+        self.done.record()
+        self._pre = (0, self.used)
+
     def download(self, lo, hi):
         """dev[lo:hi] -> pinned host, asynchronously on the current stream; returns after the copy has landed."""
         if lo >= self._down[0] and hi <= self._down[1]:
             return                                                              # a sink sharing the stage already brought it down
-        self._down = (lo, hi)
-        t0 = _prof_start(self.device)
-        self.host[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
-        self.flag_host.copy_(self.flag, non_blocking=True)
-        self.done.record()
+        t0 = _prof_start(self.device if self._pre is None else None)
+        if self._pre is not None and lo >= self._pre[0] and hi <= self._pre[1]:
+            self._down = self._pre                                              # prefetch(): only its event is waited for
+        else:
+            self._down = (lo, hi)
+            self.host[lo:hi].copy_(self.dev[lo:hi], non_blocking=True)
+            self.flag_host.copy_(self.flag, non_blocking=True)
+            self.done.record()
         self.done.synchronize()
         if t0 is not None:
             _prof("d2h_s", t0)

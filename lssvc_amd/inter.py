@@ -156,6 +156,7 @@ class LSSVC_extend(_HostModel):
             self._tap("bl_y", y_q)
             if sink:
                 self._push(sink, y_q, scales, tb["laplace"], LAPLACE_IDX)
+                self._prefetch(sink)                  # the layer's last plane: its copy goes ahead of the synthesis / reconstruction kernels
         else:
             y_hat = self._pull_laplace(source, scales, means)
 
@@ -410,6 +411,8 @@ class LSSVC_extend(_HostModel):
         params = B.depth_conv_block(W, "prior_fusion_net.prior_fusion_conv.1",
                                     B.depth_conv_block(W, "prior_fusion_net.prior_fusion_conv.0", fused))
         y_q, y_hat, scales_hat = self._four_part_prior(y, params, sink=sink, source=source)
+        if sink is not None:
+            self._prefetch(sink)                      # (as in _bl_codec)
         if not decoding:
             ops.laplace_bits(y_q, scales_hat, S, 4)
             self._tap("el_y", y_q)

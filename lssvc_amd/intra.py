@@ -216,6 +216,11 @@ class _HostModel:
         """Encoder: hand the symbols of `q` (table index from `sigma`, or the channel number) to a sink."""
         sink.push(*ops.export_symbols(q, sigma, idx_params, chunk_of_mask, stage=getattr(sink, "stage", None)), tables)
 
+    def _prefetch(self, sink):
+        """Encoder, after a layer's last _push: start the planes' trip to the host now (SymbolStage.prefetch)."""
+        if getattr(sink, "stage", None) is self.stage:
+            self.stage.prefetch()
+
     def _pull(self, source, tables, out, sigma=None, idx_params=None, mean=None, channel_add=None, chunk_of_mask=None):
         """Decoder: out = decoded symbols (+ mean / per-channel medians); the table index plane comes from `sigma`
         (GaussianConditional / GaussianEncoder.build_indexes) or is the channel number (factorised tables)."""
@@ -307,6 +312,7 @@ class IntraSS(_HostModel):
             self._tap("bl_y", y_q)
             if sinks:
                 self._push(sinks[0], y_q, scales, T_["gauss"], GAUSS_IDX)
+                self._prefetch(sinks[0])              # the layer's last plane: its copy goes ahead of the synthesis kernels
         else:
             y_hat = T.empty(scales.H, scales.W, scales.C, self.device)
             self._pull(sources[0], T_["gauss"], y_hat, sigma=scales, idx_params=GAUSS_IDX, mean=means)
@@ -367,6 +373,7 @@ class IntraSS(_HostModel):
             self._tap("el_y", y_q)
             if sinks:
                 self._push(sinks[0], y_q, scales, T_["gauss"], GAUSS_IDX)
+                self._prefetch(sinks[0])              # the layer's last plane: its copy goes ahead of the synthesis kernels
         else:
             y_hat = T.empty(scales.H, scales.W, scales.C, self.device)
             self._pull(sources[0], T_["gauss"], y_hat, sigma=scales, idx_params=GAUSS_IDX, mean=means)

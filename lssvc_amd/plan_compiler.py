@@ -28,8 +28,8 @@ from . import hip_ops as ops
 
 MAGIC = b"LSSVCPL1"
 # host steps of the write_stream = 1 plans, stored in the launch list where the front end performed them (names start with "__")
-HOST_D2H, HOST_H2D, HOST_ENCODE, HOST_FLUSH, HOST_SET_STREAM, HOST_DECODE, HOST_DECODE_CH = (
-    "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__")
+HOST_D2H, HOST_H2D, HOST_ENCODE, HOST_FLUSH, HOST_SET_STREAM, HOST_DECODE, HOST_DECODE_CH, HOST_D2H_ASYNC, HOST_D2H_WAIT = (
+    "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__", "__d2h_async__", "__d2h_wait__")
 REGION_ARENA, REGION_WEIGHTS, REGION_SCRATCH, REGION_INPUT, REGION_OUTPUT = range(5)
 TAG_NULL, TAG_PTR, TAG_STRUCT, TAG_F32, TAG_I32, TAG_I64, TAG_I32ARRAY, TAG_STREAM = range(8)
 FN_WAIT = "__wait__"
@@ -284,7 +284,7 @@ class StreamHooks:
         from . import entropy_coder as ec
         hooks, rec = self, self.rec
         st_cls, enc_cls, dec_cls = ops.SymbolStage, ec.RansEncoder, ec.RansDecoder
-        o_begin, o_down, o_up = st_cls.begin, st_cls.download, st_cls.upload
+        o_begin, o_down, o_up, o_pre = st_cls.begin, st_cls.download, st_cls.upload, st_cls.prefetch
         o_einit, o_eenc, o_eflush = enc_cls.__init__, enc_cls.encode_with_indexes, enc_cls.flush
         o_dinit, o_dset, o_ddec = dec_cls.__init__, dec_cls.set_stream, dec_cls.decode_stream
 
@@ -294,9 +294,17 @@ class StreamHooks:
             _lib.check(_lib.lib.lssvc_fill_zero(C.c_void_p(st.flag.data_ptr()), 4, ops.stream_ptr()))     # the recorded form of flag.zero_()
             return r
 
+        def prefetch(st):
+            if st.used:
+                rec.host(HOST_D2H_ASYNC, 0, st.used)
+            return o_pre(st)
+
         def download(st, lo, hi):
             if not (lo >= st._down[0] and hi <= st._down[1]):
-                rec.host(HOST_D2H, lo, hi)
+                if st._pre is not None and lo >= st._pre[0] and hi <= st._pre[1]:
+                    rec.host(HOST_D2H_WAIT)                               # the copy is on the stream already (prefetch)
+                else:
+                    rec.host(HOST_D2H, lo, hi)
             return o_down(st, lo, hi)
 
         def upload(st, ref):
@@ -340,7 +348,7 @@ class StreamHooks:
                 rec.host(HOST_DECODE_CH, dec._plan_id, c, indexes.size // c, rec.table_id(tables), oo)
             return o_ddec(dec, indexes, tables, out=out)
 
-        for cls, name, fn in ((st_cls, "begin", begin), (st_cls, "download", download), (st_cls, "upload", upload),
+        for cls, name, fn in ((st_cls, "begin", begin), (st_cls, "download", download), (st_cls, "upload", upload), (st_cls, "prefetch", prefetch),
                               (enc_cls, "__init__", einit), (enc_cls, "encode_with_indexes", eenc), (enc_cls, "flush", eflush),
                               (dec_cls, "__init__", dinit), (dec_cls, "set_stream", dset), (dec_cls, "decode_stream", ddec)):
             self._patch(cls, name, fn)
