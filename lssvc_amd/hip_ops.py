@@ -742,7 +742,7 @@ class SymbolStage:
         on the stream NOW, with an event behind it. The kernels the codec issues after this point (the layer's synthesis
         transform and reconstruction network: a third of a P-frame) then run while the host codes the planes, instead of
         the host waiting for them before it starts."""
-        if self.used == 0:
+        if self.used == 0 or STREAM_PROF is not None:        # (a profiled pass books GPU, copy and coder time separately: no overlap)
             return
         self.host[0:self.used].copy_(self.dev[0:self.used], non_blocking=True)
         self.flag_host.copy_(self.flag, non_blocking=True)
@@ -753,7 +753,7 @@ class SymbolStage:
         """dev[lo:hi] -> pinned host, asynchronously on the current stream; returns after the copy has landed."""
         if lo >= self._down[0] and hi <= self._down[1]:
             return                                                              # a sink sharing the stage already brought it down
-        t0 = _prof_start(self.device if self._pre is None else None)
+        t0 = _prof_start(self.device)
         if self._pre is not None and lo >= self._pre[0] and hi <= self._pre[1]:
             self._down = self._pre                                              # prefetch(): only its event is waited for
         else:
