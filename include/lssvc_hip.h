@@ -349,7 +349,8 @@ int lssvc_engine_iframe(void *engine, const float *x_bl, const float *x_el, doub
 int lssvc_engine_pframe(void *engine, const float *x_bl, const float *x_el, const float *ref_frame_bl, const float *ref_frame_el,
                         const float *ref_feature_bl, const float *ref_feature_el, double bits[2], float *recon_bl, float *feature_bl,
                         float *recon_el, float *feature_el, float *mv_hat, float *warp_frame, void *stream);
-/* which: 0 intra, 1 first-P, 2 steady-P -> launches, streams, arena bytes, weight bytes, H, W */
+/* which: 0 intra, 1 first-P, 2 steady-P; 3 / 4 I-frame encoder / decoder, 5 / 6 first-P, 7 / 8 steady-P (write_stream = 1 plans)
+ * -> launches (host steps included), streams, arena bytes, weight bytes, H, W */
 int lssvc_engine_plan_info(void *engine, int32_t which, int64_t *out6);
 
 /* write_stream = 1 through the engine (SURVEY 8b's lssvc_pframe_symbols / lssvc_pframe_decode): the ENCODER and the DECODER

@@ -674,7 +674,10 @@ extern "C" int lssvc_engine_pframe(void *h, const float *x_bl, const float *x_el
 extern "C" int lssvc_engine_plan_info(void *h, int32_t which, int64_t *out6) {
     LSSVC_CHECK(h && out6, "engine_plan_info: bad arguments");
     Engine *e = static_cast<Engine *>(h);
-    Plan *p = which == 0 ? e->intra.get() : (which == 1 ? e->first_p.get() : e->steady_p.get());
+    Plan *const all[9] = {e->intra.get(), e->first_p.get(), e->steady_p.get(), e->i_enc.get(), e->i_dec.get(), e->p1_enc.get(),
+                          e->p1_dec.get(), e->p_enc.get(), e->p_dec.get()};
+    LSSVC_CHECK(which >= 0 && which < 9, "engine_plan_info: plan index %d", which);
+    Plan *p = all[which];
     LSSVC_CHECK(p != nullptr, "engine_plan_info: plan %d is not loaded", which);
     uint64_t arena = 0, weights = 0;
     for (auto &g : p->regions) {
