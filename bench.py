@@ -483,12 +483,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device("cuda", local)
+    # Rehearsal of the multi-rank flow on a box with ONE GPU (never a measurement: the ranks share the card):
+    # LSSVC_BENCH_REHEARSAL=1 puts every rank on cuda:0 and runs the collectives over gloo on host tensors.
+    rehearsal = os.environ.get("LSSVC_BENCH_REHEARSAL", "0") == "1"
+    device = torch.device("cuda", 0 if rehearsal else local)
     torch.cuda.set_device(device)
+    coll_device = torch.device("cpu") if rehearsal else device
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (got world=%d, --gpus=%d)" % (world, args.gpus)
 
     from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
@@ -501,9 +508,9 @@ def main():
     # the deployment path (harness under torchrun): rank 0 alone has the checkpoints and broadcasts them over RCCL, ~245 MB
     # once; with one rank this is a plain local load
     t0 = time.time()
-    sds = broadcast_state_dicts(["intra_ss", "lssvc_extend"], dist, device, loader=lambda name: synth_state_dict(name, 0, GAIN))
+    sds = broadcast_state_dicts(["intra_ss", "lssvc_extend"], dist, coll_device, loader=lambda name: synth_state_dict(name, 0, GAIN))
     if rank == 0 and world > 1:
-        log("checkpoints broadcast from rank 0 over RCCL in %.2f s" % (time.time() - t0))
+        log("checkpoints broadcast from rank 0 over %s in %.2f s" % ("gloo (rehearsal)" if rehearsal else "RCCL", time.time() - t0))
     inet = IntraSS.from_state_dict(sds["intra_ss"]).to(device).eval()
     pnet = LSSVC_extend()
     pnet.load_dict(sds["lssvc_extend"])
@@ -558,7 +565,7 @@ def main():
             sync_all()
             dt_incl = time.time() - t1
     if dist is not None:
-        t = torch.tensor([dt, dt_incl if dt_incl is not None else 0.0], dtype=torch.float64, device=device)
+        t = torch.tensor([dt, dt_incl if dt_incl is not None else 0.0], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t[0].item()
         dt_incl = t[1].item() if dt_incl is not None else None
@@ -574,7 +581,8 @@ def main():
                                    "%d-frame GOP per GPU per step, write_stream=0; inputs resident in HBM for `value`, "
                                    "per-frame H2D + pre-processing included in `h2d_inclusive`" % args.frames,
                        "frames_per_step_per_gpu": args.frames, "weights": "seeded synthetic (lssvc_amd.synth, gain %.2f)" % GAIN,
-                       "parallelism": "gop-shard x%d (no data-path collective; weights broadcast once from rank 0 over RCCL)" % world if world > 1
+                       "parallelism": ("gop-shard x%d (no data-path collective; weights broadcast once from rank 0 over RCCL)" % world
+                                       + (" -- REHEARSAL: all ranks on one GPU, gloo; not a measurement" if rehearsal else "")) if world > 1
                        else "gop-shard x1",
                        "launch": ("eager (ctypes per kernel)" if args.no_graph else "hipGraph frame plans (I / first-P / steady-P)")
                                  + (", independent chains of a frame as parallel branches (side streams)" if hip_ops.MULTI_STREAM else ", single stream")},
