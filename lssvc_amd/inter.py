@@ -523,6 +523,33 @@ class LSSVC_extend(_HostModel):
                 "encoder_side": {"ref_frame_bl": bl_e["recon"].to_nchw(), "ref_feature_bl": bl_e["feature"].to_nchw(),
                                  "ref_frame_el": recon_e.to_nchw(), "ref_feature_el": feature_e.to_nchw()}}
 
+    def encode(self, x_bl, x_el, dpb, output_path_bl, output_path_el):
+        """Encoder only: the compress half of encode_decode_extend (DMCExtend.compress dmc_net_extend.py:55-104 +
+        LSSVC_extend.compress LSSVC_net_extend.py:24-86) -- writes the two layer files and returns {"dpb": ...} built from the
+        encoder-side reconstruction, which is bit for bit what decode() makes of those files, so an encoder process never has
+        to decode: 55 instead of 104 ms per 1080p P-frame. ref_frame_bl comes back clamped, as the decoder returns it
+        (dmc_net_extend.py:138)."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        nhwc = lambda t: None if t is None else T.from_nchw(t)
+        xb, xe = nhwc(x_bl), nhwc(x_el)
+        ref_bl, ref_el = nhwc(dpb["ref_frame_bl"]), nhwc(dpb["ref_frame_el"])
+        feat_bl, feat_el = nhwc(dpb["ref_feature_bl"]), nhwc(dpb["ref_feature_el"])
+        ins = {"x_bl": xb, "x_el": xe, "ref_frame_bl": ref_bl, "ref_frame_el": ref_el, "ref_feature_bl": feat_bl, "ref_feature_el": feat_el}
+        self._with_range_audit(("p",) + tuple(None if v is None else (1, v.C, v.H, v.W) for v in ins.values()),
+                               lambda: self._frame_body(ins))
+        sink = SymbolSink(self._begin_layer())
+        bl = self._bl_codec(xb, ref_bl, feat_bl, sink=sink)
+        bitstream.encode_p(sink.flush(), output_path_bl)
+        sink = SymbolSink(self._begin_layer())
+        feature, recon_el, mv_hat, warp_frame = self._el_codec(xe, bl, ref_el, feat_el, sink=sink)
+        bitstream.encode_p(sink.flush(), output_path_el)
+        return {"dpb": {"ref_frame_bl": bl["recon"].to_nchw(copy=True).clamp_(0, 1), "ref_feature_bl": bl["feature"].to_nchw(),
+                        "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()},
+                "bit_bl": bitstream.filesize(output_path_bl) * 8, "bit_el": bitstream.filesize(output_path_el) * 8,
+                "mv_hat": mv_hat.to_nchw(), "warp_frame": warp_frame.to_nchw()}
+
     def decode(self, dpb, input_path_bl, input_path_el):
         """Decoder only: reconstruct a P-frame from its two layer files and the previous frame's DPB (the decode half
         of encode_decode_extend = DMCExtend.decompress dmc_net_extend.py:106-146 + LSSVC_extend.decompress

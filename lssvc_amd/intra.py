@@ -446,6 +446,27 @@ class IntraSS(_HostModel):
                 "bit_bl_estimate": (est[0] + est[1]) / (-math.log(2)), "bit_el_estimate": (est[2] + est[3]) / (-math.log(2)),
                 "encoder_side": {"x_hat_bl": x_hat_bl_e.to_nchw(), "x_hat_el": x_hat_e.to_nchw(), "feature_el": feature_e.to_nchw()}}
 
+    def encode(self, x_bl, x_el, bin_path_bl, bin_path_el, pic_height_bl, pic_width_bl, pic_height_el, pic_width_el):
+        """Encoder only: the compress half of encode_decode above (IntraNoAR.compress priors.py:422-437 + IntraSS.compress
+        IntraSS.py:304-314) -- writes the two layer files and returns the encoder-side reconstruction, which is bit for bit
+        what decode() makes of those files (tests/test_gpu_stream.py), so an encoder process never has to decode. The host
+        coder runs while the GPU is still busy with the synthesis transforms (SymbolStage.prefetch)."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        xb, xe = T.from_nchw(x_bl), T.from_nchw(x_el)
+        self._with_range_audit(("i", tuple(x_bl.shape), tuple(x_el.shape)), lambda: self._frame_body({"x_bl": xb, "x_el": xe}))
+        st = self._begin_layer()
+        sinks = (SymbolSink(st), SymbolSink(st))
+        x_hat_bl, y_hat_bl = self._bl_codec(xb, sinks=sinks)
+        bitstream.encode_i(pic_height_bl, pic_width_bl, sinks[0].flush(), sinks[1].flush(), bin_path_bl)
+        st = self._begin_layer()
+        sinks = (SymbolSink(st), SymbolSink(st))
+        feature, x_hat = self._el_codec(xe, x_hat_bl, y_hat_bl, sinks=sinks)
+        bitstream.encode_i(pic_height_el, pic_width_el, sinks[0].flush(), sinks[1].flush(), bin_path_el)
+        return {"bit_bl": bitstream.filesize(bin_path_bl) * 8, "bit_el": bitstream.filesize(bin_path_el) * 8,
+                "x_hat_bl": x_hat_bl.to_nchw(), "x_hat_el": x_hat.to_nchw(), "feature_el": feature.to_nchw()}
+
     def decode(self, bin_path_bl, bin_path_el):
         """Decoder only: reconstruct an I-frame from its two layer files (the decode half of encode_decode above =
         IntraNoAR.decompress priors.py:439-452 + IntraSS.decompress IntraSS.py:316-336). Needs set_scale_information()

@@ -223,3 +223,36 @@ def test_fresh_decoder_reconstructs_gop_from_files_only(tmp_path):
         f.write(data[:len(data) // 2])
     with pytest.raises(ValueError):                                # the framing notices a truncated stream
         dec_p.decode(dpb, str(tmp_path / "bl_1.bin"), cut)
+
+
+def test_encoder_only_writes_the_same_files_and_keeps_the_decoders_dpb(tmp_path):
+    """encode() -- the compress half alone -- must write byte for byte the files encode_decode() writes and hand back the DPB
+    the decoder will arrive at (so an encoder process can go on to the next frame without decoding), over an I + P + P GOP
+    in which every frame is coded from the encode()-side DPB."""
+    H = W = 128
+    frames = 3
+    inet, pnet = _nets(11, 0.6)
+    x_bl, x_el = _clip(frames, H, W, 11)
+    for net in (inet, pnet):
+        net.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+    dpb_a = dpb_b = None
+    for t in range(frames):
+        fa = [str(tmp_path / ("a_%s_%d.bin" % (g, t))) for g in ("bl", "el")]
+        fb = [str(tmp_path / ("b_%s_%d.bin" % (g, t))) for g in ("bl", "el")]
+        if t == 0:
+            ra = inet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], fa[0], fa[1], H // 2, W // 2, H, W)
+            rb = inet.encode(x_bl[t:t + 1], x_el[t:t + 1], fb[0], fb[1], H // 2, W // 2, H, W)
+            dpb_a = {"ref_frame_bl": ra["x_hat_bl"], "ref_frame_el": ra["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": ra["feature_el"]}
+            dpb_b = {"ref_frame_bl": rb["x_hat_bl"], "ref_frame_el": rb["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": rb["feature_el"]}
+        else:
+            ra = pnet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], dpb_a, fa[0], fa[1], W, H, W // 2, H // 2)
+            rb = pnet.encode(x_bl[t:t + 1], x_el[t:t + 1], dpb_b, fb[0], fb[1])
+            dpb_a, dpb_b = ra["dpb"], rb["dpb"]
+        assert (ra["bit_bl"], ra["bit_el"]) == (rb["bit_bl"], rb["bit_el"])
+        for a, b in zip(fa, fb):
+            assert open(a, "rb").read() == open(b, "rb").read(), (t, a)
+        for d in (dpb_a, dpb_b):
+            d["ref_frame_bl"].clamp_(0, 1)
+            d["ref_frame_el"].clamp_(0, 1)
+        for k in dpb_a:
+            assert (dpb_a[k] is None and dpb_b[k] is None) or torch.equal(dpb_a[k], dpb_b[k]), (t, k)
