@@ -17,6 +17,7 @@
 // 147 KB for C = 64, hidden = 256, i.e. one workgroup per CU), persistent over flat 32-pixel groups; no barrier
 // after the staging. Every product is the 3-term split of the f16x3 mode (lo*hi + hi*lo + hi*hi, fp32 accumulate).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_f16x3_kernel.h"
@@ -119,15 +120,18 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
     // prefetch registers: the next group's inputs in flight while the current one is in the matrix pipe
     float4 nx[CF][RPW];                             // o1 (no leading conv) or ident (leading conv), accumulator layout
     float4 nt[PRE ? SA_MAX : 1][RPW][2];            // leading conv input, B-fragment layout (8 channels per lane)
-    auto load_group = [&](int grp) {
+    // what = 1: the accumulator-layout operand (o1 / ident), 2: the leading conv's input, 3: both
+    auto load_group = [&](int grp, int what) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             int q = (grp * RPW + r) * 16 + li;
             if (q >= npix) q = 0;
             const V &src = PRE ? p.ident : p.x;
+            if (what & 1) {
 #pragma unroll
-            for (int f = 0; f < CF; ++f) nx[f][r] = *reinterpret_cast<const float4 *>(src.p + (size_t)q * src.ld + f * 16 + 4 * lg);
-            if (PRE) {
+                for (int f = 0; f < CF; ++f) nx[f][r] = *reinterpret_cast<const float4 *>(src.p + (size_t)q * src.ld + f * 16 + 4 * lg);
+            }
+            if (PRE && (what & 2)) {
 #pragma unroll
                 for (int s = 0; s < SA_MAX; ++s) {
                     const int c0 = 32 * s + 8 * lg;
@@ -139,7 +143,12 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
             }
         }
     };
-    if (wave_id < ngroups) load_group(wave_id);
+    // With a leading conv only ITS input is prefetched a group ahead; `ident` is requested at the head of the group it belongs
+    // to and first needed after the leading conv's MFMAs. (Both a group ahead = 64 registers of loads in flight across the
+    // hidden loop: the CF = 4 instantiation then spills, and a spill reload's s_waitcnt vmcnt(0) -- loads return in order --
+    // waits for the whole prefetch at once, which is worse than not prefetching.)
+    constexpr int AHEAD = PRE ? 2 : 3;
+    if (wave_id < ngroups) load_group(wave_id, AHEAD);
 
     for (int grp = wave_id; grp < ngroups; grp += wave_stride) {
         int pix[RPW];
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
             const int q = (grp * RPW + r) * 16 + li;
             pix[r] = q < npix ? q : -1;
         }
+        if (PRE) load_group(grp, 1);
         // ---- o1 in accumulator layout: o1[f][r][j] = channel 16f + 4g + j of pixel pix[r]
         f32x4 o1[CF][RPW];
         if (PRE) {
@@ -165,15 +175,10 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
                     split8(v, th[s][r], tl[s][r]);
                 }
             }
-            f32x4 ident[CF][RPW];
 #pragma unroll
             for (int f = 0; f < CF; ++f)
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    ident[f][r] = f32x4{nx[f][r].x, nx[f][r].y, nx[f][r].z, nx[f][r].w};
-                    o1[f][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            if (grp + wave_stride < ngroups) load_group(grp + wave_stride);
+                for (int r = 0; r < RPW; ++r) o1[f][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < SA_MAX; ++s) {
                 if (s < p.sa) {
@@ -191,14 +196,13 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
             for (int f = 0; f < CF; ++f) {
                 const f32x4 b = *reinterpret_cast<const f32x4 *>(bps + f * 16 + 4 * lg);
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) o1[f][r] = (o1[f][r] * p.pre_u + b) + ident[f][r];
+                for (int r = 0; r < RPW; ++r) o1[f][r] = (o1[f][r] * p.pre_u + b) + f32x4{nx[f][r].x, nx[f][r].y, nx[f][r].z, nx[f][r].w};   // ident: first use of this group's load
             }
         } else {
 #pragma unroll
             for (int f = 0; f < CF; ++f)
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) o1[f][r] = f32x4{nx[f][r].x, nx[f][r].y, nx[f][r].z, nx[f][r].w};
-            if (grp + wave_stride < ngroups) load_group(grp + wave_stride);
         }
 
         // ---- B fragments of the C -> hidden GEMM straight from o1 (K order permuted on the host to match)
@@ -222,6 +226,15 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
 #pragma unroll
             for (int r = 0; r < RPW; ++r) oacc[f][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // The next group's inputs are requested HERE, with the whole hidden loop ahead to hide them. Requested earlier (as soon
+        // as their registers were free, before the leading conv) they were waited for at once: this instantiation spills a few
+        // registers around that stage, a spill reload is a vector-memory load, loads return in order, so the reload's
+        // s_waitcnt vmcnt(0) also waited for the sixteen prefetch loads issued just before it.
+        // (unconditional -- past the end it re-reads group 0 -- and fenced: as a conditional block the compiler moved it above the
+        // arithmetic that consumes this group's older loads, whose waits then had to assume the worst and drained it as well)
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(grp + wave_stride < ngroups ? grp + wave_stride : 0, AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < T; ++t) {
             // hidden channels 32t .. 32t+31 = two accumulator fragments
             f32x4 hacc[2][RPW];
@@ -240,6 +253,16 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
                 }
                 mfma3<2, RPW>(hacc, ah, al, bh[s], bl[s]);
             }
+            // W2's fragments are requested BEFORE the activation / split arithmetic (which does not depend on them): their LDS
+            // round trip then hides behind ~110 VALU instructions instead of stalling the MFMAs that follow
+            f16x8 ah[CF], al[CF];
+#pragma unroll
+            for (int m = 0; m < CF; ++m) {
+                const int o = (t * CF + m) * 512 + a_off;
+                ah[m] = *reinterpret_cast<const f16x8 *>(w2h + o);
+                al[m] = *reinterpret_cast<const f16x8 *>(w2l + o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f16x8 hh[RPW], hl[RPW];
             {
                 const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b1s + (2 * t) * 16 + 4 * lg);
@@ -251,38 +274,47 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_f16x3_kernel(const FfnP p)
                     split8(v, hh[r], hl[r]);
                 }
             }
-            f16x8 ah[CF], al[CF];
-#pragma unroll
-            for (int m = 0; m < CF; ++m) {
-                const int o = (t * CF + m) * 512 + a_off;
-                ah[m] = *reinterpret_cast<const f16x8 *>(w2h + o);
-                al[m] = *reinterpret_cast<const f16x8 *>(w2l + o);
-            }
             mfma3<CF, RPW>(oacc, ah, al, hh, hl);
         }
 
-        // ---- out = o1 + lrelu(W2 h + b2)
+        // ---- out = o1 + lrelu(W2 h + b2) (+ skip)
+        // Loads and stores share the vmcnt counter: a wait for a load issued AFTER a store also waits for that store to be
+        // acknowledged. Written as one loop (load skip, compute, store per fragment) every store of a group waited for
+        // the one before it -- a full memory round trip each, eight per group -- whether or not there was a skip operand at
+        // all (the wait sits at the join of the two paths). Hence two straight-line variants, chosen wave-uniformly: no skip
+        // operand = no load and no wait between the stores; with one, all its loads are issued before the first store.
+        auto finish = [&](auto has_skip) {
+            constexpr bool SK = decltype(has_skip)::value;
+            float4 sk[SK ? CF : 1][SK ? RPW : 1];
+            if constexpr (SK) {
 #pragma unroll
-        for (int f = 0; f < CF; ++f) {
-            if (f * 16 + 4 * lg >= C) continue;
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
+                for (int f = 0; f < CF; ++f)
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                if (pix[r] < 0) continue;
-                float4 o;
-                float v[4];
-                float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.skip.p) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)pix[r] * p.skip.ld + f * 16 + 4 * lg);
-                const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = oacc[f][r][j] * p.u2 + b[j];
-                    v[j] = (o1[f][r][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
-                }
-                o = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4 *>(p.out.p + (size_t)pix[r] * p.out.ld + f * 16 + 4 * lg) = o;
+                    for (int r = 0; r < RPW; ++r) {
+                        const bool ok = f * 16 + 4 * lg < C && pix[r] >= 0;
+                        sk[f][r] = *reinterpret_cast<const float4 *>(p.skip.p + (ok ? (size_t)pix[r] * p.skip.ld + f * 16 + 4 * lg : (size_t)0));
+                    }
             }
-        }
+#pragma unroll
+            for (int f = 0; f < CF; ++f) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    float v[4];
+                    float skv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (SK) skv[0] = sk[f][r].x, skv[1] = sk[f][r].y, skv[2] = sk[f][r].z, skv[3] = sk[f][r].w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = oacc[f][r][j] * p.u2 + b[j];
+                        v[j] = (o1[f][r][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
+                    }
+                    if (f * 16 + 4 * lg < C && pix[r] >= 0)
+                        *reinterpret_cast<float4 *>(p.out.p + (size_t)pix[r] * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        };
+        if (p.skip.p) finish(std::true_type{});
+        else finish(std::false_type{});
     }
 }
 
@@ -467,21 +499,34 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
             __syncthreads();                                 // slice g consumed by everyone; slice g+1 has landed
             ++g;
         }
+        // (two straight-line variants, as in ffn_f16x3_kernel: no wait between the stores)
+        auto finish = [&](auto has_skip) {
+            constexpr bool SK = decltype(has_skip)::value;
+            float4 sk[SK ? CF : 1];
+            if constexpr (SK) {
 #pragma unroll
-        for (int f = 0; f < CF; ++f) {
-            if (f * 16 + 4 * lg >= C || !live) continue;
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
-            float v[4];
-            float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.skip.p) sk = *reinterpret_cast<const float4 *>(p.skip.p + (size_t)q * p.skip.ld + f * 16 + 4 * lg);
-            const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = oacc[f][0][j] * p.u2 + b[j];
-                v[j] = (o1[f][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
+                for (int f = 0; f < CF; ++f) {
+                    const bool ok = f * 16 + 4 * lg < C && live;
+                    sk[f] = *reinterpret_cast<const float4 *>(p.skip.p + (ok ? (size_t)q * p.skip.ld + f * 16 + 4 * lg : (size_t)0));
+                }
             }
-            *reinterpret_cast<float4 *>(p.out.p + (size_t)q * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+#pragma unroll
+            for (int f = 0; f < CF; ++f) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(b2s + f * 16 + 4 * lg);
+                float v[4];
+                float skv[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (SK) skv[0] = sk[f].x, skv[1] = sk[f].y, skv[2] = sk[f].z, skv[3] = sk[f].w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = oacc[f][0][j] * p.u2 + b[j];
+                    v[j] = (o1[f][j] + (a > 0.f ? a : a * p.slope)) + skv[j];
+                }
+                if (f * 16 + 4 * lg < C && live)
+                    *reinterpret_cast<float4 *>(p.out.p + (size_t)q * p.out.ld + f * 16 + 4 * lg) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        };
+        if (p.skip.p) finish(std::true_type{});
+        else finish(std::false_type{});
     }
 }
 
