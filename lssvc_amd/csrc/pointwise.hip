@@ -110,11 +110,14 @@ __global__ void dwconv3x3_b2_kernel(V in, const float *__restrict__ w, const flo
 #pragma unroll
     for (int t = 0; t < 9; ++t) k[t] = *reinterpret_cast<const float4 *>(w + t * in.C + c);
     const float4 bv = *reinterpret_cast<const float4 *>(bias + c);
+    // all four results first, then the stores back to back: with compute + store per output inside its own bounds check the
+    // compiler repeated the (already satisfied) load waits in every block, down to vmcnt(0) -- which, after the first store,
+    // waits for THAT STORE: four store round trips in a row per thread
+    float4 res[2][2];
 #pragma unroll
     for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox) {
-            if (y0 + oy >= in.H || x0 + ox >= in.W) continue;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -129,8 +132,15 @@ __global__ void dwconv3x3_b2_kernel(V in, const float *__restrict__ w, const flo
                     acc.w = fmaf(p.w, q.w, acc.w);
                 }
             acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
-            *reinterpret_cast<float4 *>(out.p + ((size_t)(y0 + oy) * out.W + x0 + ox) * out.ld + c) = acc;
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w));      // (or the compiler sinks the arithmetic back into the store's block)
+            res[oy][ox] = acc;
         }
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+            if (y0 + oy < in.H && x0 + ox < in.W)
+                *reinterpret_cast<float4 *>(out.p + ((size_t)(y0 + oy) * out.W + x0 + ox) * out.ld + c) = res[oy][ox];
 }
 
 // ------------------------------------------------------------------------------------------------
