@@ -438,13 +438,20 @@ class LSSVC_extend(_HostModel):
         return feature, recon_el, mv_hat, warp_frame
 
     # ---------------------------------------------------------------------------------------------
-    def _frame_body(self, t):
+    def _fork_el_head(self, x_el, ref_el, feat_el):
+        """-> (fk, pre): the frame's Fork with branch 0 already issued -- what the EL needs from the inputs and the DPB alone
+        (encoder: motion estimation + reference pyramid; decoder, x_el None: the reference pyramid), beside the whole BL codec."""
         fk = ops.Fork(self.device)
         pre = {}
         if fk.enabled:
-            with fk.branch(0):    # EL motion estimation + reference pyramid: inputs and DPB only, beside the whole BL codec
-                pre["mv"] = B.spynet(self.W, "optic_flow", t["x_el"], t["ref_frame_el"])
-                pre["ref_pyr"] = self._ref_pyramid(t["ref_frame_el"], t["ref_feature_el"])
+            with fk.branch(0):
+                if x_el is not None:
+                    pre["mv"] = B.spynet(self.W, "optic_flow", x_el, ref_el)
+                pre["ref_pyr"] = self._ref_pyramid(ref_el, feat_el)
+        return fk, pre
+
+    def _frame_body(self, t):
+        fk, pre = self._fork_el_head(t["x_el"], t["ref_frame_el"], t["ref_feature_el"])
         bl = self._bl_codec(t["x_bl"], t["ref_frame_bl"], t["ref_feature_bl"], fk=fk)
         feature, recon_el, mv_hat, warp_frame = self._el_codec(t["x_el"], bl, t["ref_frame_el"], t["ref_feature_el"], fk=fk, pre=pre)
         fk.close()
@@ -495,23 +502,34 @@ class LSSVC_extend(_HostModel):
                                lambda: self._frame_body(ins))                # first frame of a type only (hip_ops.RangeAudit)
         sync = lambda: torch.cuda.synchronize(self.device)
         # ---- base layer ----
+        # (every codec call below issues its independent chains as parallel branches, as the estimate-mode frame does: a
+        # ops.Fork per call, closed -- all branches joined -- before the call's results are used)
         sync(); t0 = time.time()
         sink = SymbolSink(self._begin_layer())
-        bl_e = self._bl_codec(xb, ref_bl, feat_bl, sink=sink)
+        fk = ops.Fork(self.device)
+        bl_e = self._bl_codec(xb, ref_bl, feat_bl, sink=sink, fk=fk)
+        fk.close()
         bitstream.encode_p(sink.flush(), output_path_bl)
         bit_bl = bitstream.filesize(output_path_bl) * 8
         sync(); t1 = time.time()
-        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(output_path_bl), self._begin_layer()))
+        fk = ops.Fork(self.device)
+        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(output_path_bl), self._begin_layer()), fk=fk)
+        fk.close()
         recon_bl = bl["recon"].to_nchw(copy=True).clamp_(0, 1)                         # dmc_net_extend.py:138
         sync(); t2 = time.time()
         # ---- enhancement layer ----
         sink = SymbolSink(self._begin_layer())
-        feature_e, recon_e, mv_hat, warp_frame = self._el_codec(xe, bl, ref_el, feat_el, sink=sink)
+        fk, pre = self._fork_el_head(xe, ref_el, feat_el)
+        feature_e, recon_e, mv_hat, warp_frame = self._el_codec(xe, bl, ref_el, feat_el, sink=sink, fk=fk, pre=pre)
+        fk.close()
         bitstream.encode_p(sink.flush(), output_path_el)
         bit_el = bitstream.filesize(output_path_el) * 8
         est = self.slots.fetch()
         sync(); t3 = time.time()
-        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(output_path_el), self._begin_layer()))
+        fk, pre = self._fork_el_head(None, ref_el, feat_el)
+        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(output_path_el), self._begin_layer()),
+                                                 fk=fk, pre=pre)
+        fk.close()
         sync(); t4 = time.time()
         out_dpb = {"ref_frame_bl": recon_bl, "ref_feature_bl": bl["feature"].to_nchw(),
                    "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()}
@@ -539,11 +557,13 @@ class LSSVC_extend(_HostModel):
         ins = {"x_bl": xb, "x_el": xe, "ref_frame_bl": ref_bl, "ref_frame_el": ref_el, "ref_feature_bl": feat_bl, "ref_feature_el": feat_el}
         self._with_range_audit(("p",) + tuple(None if v is None else (1, v.C, v.H, v.W) for v in ins.values()),
                                lambda: self._frame_body(ins))
+        fk, pre = self._fork_el_head(xe, ref_el, feat_el)         # EL motion estimation + reference pyramid run beside the BL codec
         sink = SymbolSink(self._begin_layer())
-        bl = self._bl_codec(xb, ref_bl, feat_bl, sink=sink)
+        bl = self._bl_codec(xb, ref_bl, feat_bl, sink=sink, fk=fk)
         bitstream.encode_p(sink.flush(), output_path_bl)
         sink = SymbolSink(self._begin_layer())
-        feature, recon_el, mv_hat, warp_frame = self._el_codec(xe, bl, ref_el, feat_el, sink=sink)
+        feature, recon_el, mv_hat, warp_frame = self._el_codec(xe, bl, ref_el, feat_el, sink=sink, fk=fk, pre=pre)
+        fk.close()
         bitstream.encode_p(sink.flush(), output_path_el)
         return {"dpb": {"ref_frame_bl": bl["recon"].to_nchw(copy=True).clamp_(0, 1), "ref_feature_bl": bl["feature"].to_nchw(),
                         "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()},
@@ -560,9 +580,13 @@ class LSSVC_extend(_HostModel):
         nhwc = lambda t: None if t is None else T.from_nchw(t)
         ref_bl, ref_el = nhwc(dpb["ref_frame_bl"]), nhwc(dpb["ref_frame_el"])
         feat_bl, feat_el = nhwc(dpb["ref_feature_bl"]), nhwc(dpb["ref_feature_el"])
-        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(input_path_bl), self._begin_layer()))
+        fk, pre = self._fork_el_head(None, ref_el, feat_el)       # the EL reference pyramid runs beside the BL decoder; while the host
+        #                                                           decodes a plane, the side streams keep the GPU busy
+        bl = self._bl_codec(None, ref_bl, feat_bl, source=SymbolSource(bitstream.decode_p(input_path_bl), self._begin_layer()), fk=fk)
         recon_bl = bl["recon"].to_nchw(copy=True).clamp_(0, 1)                         # dmc_net_extend.py:138
-        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(input_path_el), self._begin_layer()))
+        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(bitstream.decode_p(input_path_el), self._begin_layer()),
+                                                 fk=fk, pre=pre)
+        fk.close()
         return {"dpb": {"ref_frame_bl": recon_bl, "ref_feature_bl": bl["feature"].to_nchw(remember=True),
                         "ref_frame_el": recon_el.to_nchw(remember=True), "ref_feature_el": feature.to_nchw(remember=True)}}
 

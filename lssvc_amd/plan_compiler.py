@@ -534,11 +534,14 @@ def compile_pframe_stream(pnet, x_bl, x_el, dpb, path_enc, path_dec, arena_gib=N
 
     def run_enc():
         del strings[:]
+        xe, ref_el, feat_el = nhwc(ins, "x_el"), nhwc(ins, "ref_frame_el"), nhwc(ins, "ref_feature_el")
+        fk, pre = pnet._fork_el_head(xe, ref_el, feat_el)           # as LSSVC_extend.encode: side-stream branches are part of the plan
         sink = SymbolSink(pnet._begin_layer())
-        bl = pnet._bl_codec(nhwc(ins, "x_bl"), nhwc(ins, "ref_frame_bl"), nhwc(ins, "ref_feature_bl"), sink=sink)
+        bl = pnet._bl_codec(nhwc(ins, "x_bl"), nhwc(ins, "ref_frame_bl"), nhwc(ins, "ref_feature_bl"), sink=sink, fk=fk)
         strings.append(sink.flush())
         sink = SymbolSink(pnet._begin_layer())
-        feature, recon_el, _, _ = pnet._el_codec(nhwc(ins, "x_el"), bl, nhwc(ins, "ref_frame_el"), nhwc(ins, "ref_feature_el"), sink=sink)
+        feature, recon_el, _, _ = pnet._el_codec(xe, bl, ref_el, feat_el, sink=sink, fk=fk, pre=pre)
+        fk.close()
         strings.append(sink.flush())
         finish(outs_e, bl, recon_el, feature)
 
@@ -547,9 +550,11 @@ def compile_pframe_stream(pnet, x_bl, x_el, dpb, path_enc, path_dec, arena_gib=N
     outs_d = mk()
 
     def run_dec():
-        bl = pnet._bl_codec(None, nhwc(refs, "ref_frame_bl"), nhwc(refs, "ref_feature_bl"), source=SymbolSource(coded[0], pnet._begin_layer()))
-        feature, recon_el, _, _ = pnet._el_codec(None, bl, nhwc(refs, "ref_frame_el"), nhwc(refs, "ref_feature_el"),
-                                                 source=SymbolSource(coded[1], pnet._begin_layer()))
+        ref_el, feat_el = nhwc(refs, "ref_frame_el"), nhwc(refs, "ref_feature_el")
+        fk, pre = pnet._fork_el_head(None, ref_el, feat_el)         # as LSSVC_extend.decode
+        bl = pnet._bl_codec(None, nhwc(refs, "ref_frame_bl"), nhwc(refs, "ref_feature_bl"), source=SymbolSource(coded[0], pnet._begin_layer()), fk=fk)
+        feature, recon_el, _, _ = pnet._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(coded[1], pnet._begin_layer()), fk=fk, pre=pre)
+        fk.close()
         finish(outs_d, bl, recon_el, feature)
 
     info_d = _record(pnet, refs, run_dec, outs_d, path_dec, "pframe_first_dec" if first else "pframe_dec", arena_gib, meta, stream_mode=True)
