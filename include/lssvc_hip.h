@@ -167,6 +167,9 @@ int lssvc_add(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, v
 int lssvc_copy(const lssvc_view *in, const lssvc_view *out, void *stream);
 /* out = lrelu(in, slope) (the stand-alone nn.LeakyReLU between blocks, e.g. dmc_net.py:178). */
 int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float slope, void *stream);
+/* out = F.pad(in, (left, right, top, bottom), value 0), negative entries cropping; right / bottom follow from out's size
+ * (get_depadded_feature: IntraSS.py:124-135, LSSVC_net.py:271-282). Writes every element of `out`. */
+int lssvc_pad_crop(const lssvc_view *in, const lssvc_view *out, int32_t left, int32_t top, void *stream);
 /* Zero `nbytes` of device memory / clamp n floats in place (what torch.zeros and the caller's `clamp_(0, 1)` of the
  * reconstructions, test.py:249-250, are for a caller without PyTorch; compiled frame plans record these as launches). */
 int lssvc_fill_zero(void *ptr, int64_t nbytes, void *stream);
@@ -352,6 +355,11 @@ int lssvc_engine_pframe(void *engine, const float *x_bl, const float *x_el, cons
 /* which: 0 intra, 1 first-P, 2 steady-P; 3 / 4 I-frame encoder / decoder, 5 / 6 first-P, 7 / 8 steady-P (write_stream = 1 plans)
  * -> launches (host steps included), streams, arena bytes, weight bytes, H, W */
 int lssvc_engine_plan_info(void *engine, int32_t which, int64_t *out6);
+/* One named integer of a plan's header: "pad_left" / "pad_right" / "pad_top" / "pad_bottom" (the inter-layer padding the plan
+ * was compiled for: set_scale_information's pad_size, IntraSS.py:229-232), "f32_layers_n" / "f32_layers_crc" (the conv layers
+ * the fp16 range audit moved to the exact fp32 kernel), "pic_height_bl" ... (stream plans). lssvc_engine_set_scale refuses a
+ * set of plans that disagree on the padding or, within one model, on the fp32 layers. Unknown name = error. */
+int lssvc_engine_plan_meta(void *engine, int32_t which, const char *name, int64_t *out);
 
 /* write_stream = 1 through the engine (SURVEY 8b's lssvc_pframe_symbols / lssvc_pframe_decode): the ENCODER and the DECODER
  * half of a frame as separate plans (plan_compiler.py: compile_iframe_stream / compile_pframe_stream), replacing

@@ -75,6 +75,7 @@ SIGNATURES = {
     "lssvc_add": (C.c_int, [VP, VP, VP, C.c_void_p]),
     "lssvc_copy": (C.c_int, [VP, VP, C.c_void_p]),
     "lssvc_lrelu": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
+    "lssvc_pad_crop": (C.c_int, [VP, VP, C.c_int32, C.c_int32, C.c_void_p]),
     "lssvc_absmax": (C.c_int, [VP, C.c_void_p, C.c_void_p]),
     "lssvc_fill_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "lssvc_clamp_inplace": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
@@ -120,6 +121,7 @@ SIGNATURES = {
     "lssvc_engine_iframe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_engine_pframe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.POINTER(C.c_double)] + [C.c_void_p] * 7),
     "lssvc_engine_plan_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "lssvc_engine_plan_meta": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_int64)]),
     "lssvc_engine_load_stream": (C.c_int, [C.c_void_p] + [C.c_char_p] * 6),
     "lssvc_engine_encode_iframe": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)] + [C.c_void_p] * 4),
     "lssvc_engine_decode_iframe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64] + [C.c_void_p] * 4),

@@ -70,7 +70,7 @@ struct Launch {
 enum Fn {
     FN_WAIT, FN_CONV2D, FN_CONV1X1_DW, FN_FFN, FN_DWCONV, FN_RESIZE, FN_WARP, FN_POOL, FN_SOFTMAX2, FN_ADD, FN_COPY, FN_LRELU,
     FN_OFFSET_DIVERSITY, FN_NCHW_TO_NHWC, FN_NHWC_TO_NCHW, FN_LAPLACE_QUANT_BITS, FN_FOUR_PART_STEP, FN_LAPLACE_BITS,
-    FN_FACTORIZED, FN_GAUSSIAN, FN_BOTTLENECK, FN_FILL_ZERO, FN_CLAMP, FN_EXPORT_I16, FN_IMPORT_I16,
+    FN_FACTORIZED, FN_GAUSSIAN, FN_BOTTLENECK, FN_FILL_ZERO, FN_CLAMP, FN_EXPORT_I16, FN_IMPORT_I16, FN_PAD_CROP,
     FN_H_D2H, FN_H_H2D, FN_H_ENCODE, FN_H_FLUSH, FN_H_SET_STREAM, FN_H_DECODE, FN_H_DECODE_CH, FN_H_D2H_ASYNC, FN_H_D2H_WAIT, FN_COUNT
 };
 const char *const kFnNames[FN_COUNT] = {
@@ -78,7 +78,7 @@ const char *const kFnNames[FN_COUNT] = {
     "lssvc_flow_warp", "lssvc_pool2x2", "lssvc_softmax2_blend", "lssvc_add", "lssvc_copy", "lssvc_lrelu", "lssvc_offset_diversity",
     "lssvc_nchw_to_nhwc", "lssvc_nhwc_to_nchw", "lssvc_laplace_quant_bits", "lssvc_four_part_step", "lssvc_laplace_bits",
     "lssvc_factorized_quant_bits", "lssvc_gaussian_conditional", "lssvc_entropy_bottleneck", "lssvc_fill_zero", "lssvc_clamp_inplace",
-    "lssvc_export_symbols_i16", "lssvc_import_symbols_i16",
+    "lssvc_export_symbols_i16", "lssvc_import_symbols_i16", "lssvc_pad_crop",
     "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__", "__d2h_async__", "__d2h_wait__"};
 
 struct Table {                           // one entropy_coder.Tables: quantised CDF rows + used lengths + symbol offsets
@@ -447,6 +447,7 @@ int replay(Plan &p, hipStream_t main) {
             rc = lssvc_import_symbols_i16((const int16_t *)P(0), V(1), (const float *)P(2),
                                           l.args[3].tag == TAG_I32ARRAY ? reinterpret_cast<const int32_t *>(l.args[3].blob.data()) : nullptr, V(4), st);
             break;
+        case FN_PAD_CROP: rc = lssvc_pad_crop(V(0), V(1), I(2), I(3), st); break;
         default:
             if (l.id >= FN_H_D2H) {
                 rc = host_step(p, l, main);
@@ -630,13 +631,51 @@ extern "C" int lssvc_engine_load_inter(void *h, const char *first_p_plan, const 
 extern "C" int lssvc_engine_set_scale(void *h, float scale, int32_t H, int32_t W) {
     LSSVC_CHECK(h, "engine_set_scale: bad arguments");
     Engine *e = static_cast<Engine *>(h);
-    for (Plan *p : {e->intra.get(), e->first_p.get(), e->steady_p.get(), e->i_enc.get(), e->i_dec.get(), e->p1_enc.get(), e->p1_dec.get(),
-                    e->p_enc.get(), e->p_dec.get()})
-        if (p)
-            LSSVC_CHECK(std::fabs(p->scale - (double)scale) < 1e-9 && p->H == H && p->W == W,
-                        "engine_set_scale: the loaded '%s' plan was compiled for scale %g, %dx%d (asked for %g, %dx%d)", p->kind.c_str(),
-                        p->scale, p->H, p->W, (double)scale, H, W);
+    Plan *const all[9] = {e->intra.get(), e->first_p.get(), e->steady_p.get(), e->i_enc.get(), e->i_dec.get(), e->p1_enc.get(), e->p1_dec.get(),
+                          e->p_enc.get(), e->p_dec.get()};
+    const Plan *first = nullptr;
+    for (Plan *p : all) {
+        if (!p) continue;
+        LSSVC_CHECK(std::fabs(p->scale - (double)scale) < 1e-9 && p->H == H && p->W == W,
+                    "engine_set_scale: the loaded '%s' plan was compiled for scale %g, %dx%d (asked for %g, %dx%d)", p->kind.c_str(),
+                    p->scale, p->H, p->W, (double)scale, H, W);
+        // the inter-layer padding (set_scale_information's pad_size) is baked into a plan's launches: every plan of one
+        // session must have been compiled for the same one
+        if (!first) first = p;
+        for (const char *k : {"pad_left", "pad_right", "pad_top", "pad_bottom"})
+            LSSVC_CHECK(p->meta_value(k, 0) == first->meta_value(k, 0), "engine_set_scale: plans '%s' and '%s' were compiled for different %s (%lld vs %lld)",
+                        first->kind.c_str(), p->kind.c_str(), k, (long long)first->meta_value(k, 0), (long long)p->meta_value(k, 0));
+    }
+    // encoder and decoder of one model must run the same kernels (the fp16 range audit may have moved layers to the exact
+    // fp32 kernel while the plans were compiled; a mismatch would give streams the other side cannot decode)
+    Plan *const groups[2][6] = {{e->i_enc.get(), e->i_dec.get(), e->intra.get(), nullptr, nullptr, nullptr},
+                                {e->p1_enc.get(), e->p1_dec.get(), e->p_enc.get(), e->p_dec.get(), e->first_p.get(), e->steady_p.get()}};
+    for (auto &g : groups) {
+        const Plan *ref = nullptr;
+        for (Plan *p : g) {
+            if (!p) continue;
+            if (!ref) ref = p;
+            LSSVC_CHECK(p->meta_value("f32_layers_crc", 0) == ref->meta_value("f32_layers_crc", 0) &&
+                            p->meta_value("f32_layers_n", 0) == ref->meta_value("f32_layers_n", 0),
+                        "engine_set_scale: plans '%s' and '%s' were compiled with different sets of fp32-fallback layers (range audit): "
+                        "recompile them from one model", ref->kind.c_str(), p->kind.c_str());
+        }
+    }
     return 0;
+}
+
+extern "C" int lssvc_engine_plan_meta(void *h, int32_t which, const char *name, int64_t *out) {
+    LSSVC_CHECK(h && name && out, "engine_plan_meta: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    Plan *const all[9] = {e->intra.get(), e->first_p.get(), e->steady_p.get(), e->i_enc.get(), e->i_dec.get(), e->p1_enc.get(),
+                          e->p1_dec.get(), e->p_enc.get(), e->p_dec.get()};
+    LSSVC_CHECK(which >= 0 && which < 9 && all[which], "engine_plan_meta: plan %d is not loaded", which);
+    for (auto &m : all[which]->meta)
+        if (m.first == name) {
+            *out = m.second;
+            return 0;
+        }
+    return fail("engine_plan_meta: plan %d has no entry '%s'", which, name);
 }
 
 extern "C" int lssvc_engine_iframe(void *h, const float *x_bl, const float *x_el, double bits[2], float *x_hat_bl, float *x_hat_el,

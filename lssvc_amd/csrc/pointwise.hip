@@ -558,6 +558,29 @@ extern "C" int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float sl
     return binary(in, nullptr, out, 2, slope, stream, "lrelu");
 }
 
+// F.pad(x, (left, right, top, bottom), value 0) with negative entries cropping, as ONE launch that writes every element of
+// `out` (source pixel (y - top, x - left) where it exists, zero elsewhere): get_depadded_feature, IntraSS.py:124-135.
+__global__ void pad_crop_kernel(V in, V out, int left, int top, int cg, long long total, int vec) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)cg;
+    const int c = (int)(idx - pix * (unsigned)cg) * 4;
+    const int y = (int)(pix / (unsigned)out.W), x = (int)(pix - (unsigned)y * (unsigned)out.W);
+    const int sy = y - top, sx = x - left;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sy >= 0 && sy < in.H && sx >= 0 && sx < in.W) r = ld4(in, (size_t)sy * in.W + sx, c, vec);
+    st4(out, (size_t)pix, c, vec, r);
+}
+extern "C" int lssvc_pad_crop(const lssvc_view *in, const lssvc_view *out, int32_t left, int32_t top, void *stream) {
+    LSSVC_CHECK(view_ok(in) && view_ok(out) && in->C == out->C, "pad_crop: bad views");
+    const Items it = items_of(out);
+    const int vec = vec4_ok(in) && vec4_ok(out);
+    LSSVC_ITEMS_OK(it.total, "pad_crop");
+    hipLaunchKernelGGL(pad_crop_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(out), (int)left, (int)top,
+                       it.cg, it.total, vec);
+    return launch_status("pad_crop");
+}
+
 // ---- range audit: max |x| of a view (NaN / Inf count as +Inf) ------------------------------------------------------------
 // Non-negative floats order like their bit patterns, so the grid reduces with one integer atomicMax per wave: no workspace,
 // no fp64, order-independent. The caller zeroes *out_max (or keeps accumulating the maximum over several views into it).

@@ -557,19 +557,15 @@ def copy(a, out):
 
 def pad_crop(x, pad):
     """F.pad(x, (left, right, top, bottom), value=0) of an NHWC view, negative entries cropping: the reference's
-    get_depadded_feature (IntraSS.py:124-135, LSSVC_net.py:271-282). Pure data movement (a strided device copy); all
-    zeros in `pad` returns x itself."""
+    get_depadded_feature (IntraSS.py:124-135, LSSVC_net.py:271-282). Pure data movement (lssvc_pad_crop); all zeros in
+    `pad` returns x itself."""
     l, r, t, b = (int(v) for v in pad)
     if l == r == t == b == 0:
         return x
     H, W = x.H + t + b, x.W + l + r
     assert H > 0 and W > 0, "pad_size %s leaves nothing of a %dx%d map" % (pad, x.H, x.W)
-    out = T.zeros(H, W, x.C, x.device)
-    y0, y1, x0, x1 = max(0, -t), min(x.H, H - t), max(0, -l), min(x.W, W - l)      # source rectangle that survives
-    if y1 > y0 and x1 > x0:
-        src = x.buf.view(-1).as_strided((x.H, x.W, x.C), (x.W * x.ld, x.ld, 1), x.off)
-        dst = out.buf.view(H, W, x.C)
-        dst[y0 + t:y1 + t, x0 + l:x1 + l].copy_(src[y0:y1, x0:x1])
+    out = T.empty(H, W, x.C, x.device)
+    check(lib.lssvc_pad_crop(x.ref, out.ref, l, t, stream_ptr()))      # a library launch: compiled frame plans record it
     return out
 
 

@@ -365,8 +365,14 @@ def _record(model, body_inputs, run, outputs, path, kind, arena_gib, meta=(), st
     results into the tensors in `outputs`) once eagerly to warm everything up, then once under the recorder."""
     device = model.device
     assert not model.graph_mode, "compile plans from a model in eager mode"
-    run()                                                   # weights laid out, LDS granted, range audit done
+    # warm-up THROUGH the fp16 range audit (a frame type this model has not coded yet is audited here, exactly as its first
+    # encode_decode would be): weights laid out, LDS granted, and W.force_f32 final before anything is recorded
+    model._with_range_audit(("plan", kind, model.shape_hr, float(model.scale_factor)), run)
     torch.cuda.synchronize(device)
+    import zlib
+    f32 = sorted(model.W.force_f32)
+    meta = tuple(meta) + tuple(zip(("pad_left", "pad_right", "pad_top", "pad_bottom"), model.pad_size)) + (
+        ("f32_layers_n", len(f32)), ("f32_layers_crc", zlib.crc32("\n".join(f32).encode())))
     scratch = {"bits": model.slots.vals}
     for i, ws in enumerate(list(model.slots._ws.values()) + list(model.slots._free)):
         scratch["reduce_ws%d" % i] = ws

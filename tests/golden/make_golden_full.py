@@ -5,7 +5,10 @@ benchmark's own sizes on seeded synthetic weights and an integer-exact synthetic
 
     x2_1080p_ipp    BASELINE configs[1] shape: EL 1152x1920 / BL 576x960, I + first P + steady P
     x1_5_1080p_ip   EL 1152x1920 / BL 768x1280 (the non-integer ratio at full size), I + first P
-    x2_2160p_ip     BASELINE configs[3] shape: EL 2176x3840 / BL 1088x1920, I + first P (the P-frame: ~40 GB of host memory)
+    x2_2160p_ipp    BASELINE configs[3] shape: EL 2176x3840 / BL 1088x1920, I + first P + steady P (a P-frame: ~40 GB of host memory)
+    x2_1080p_gop32  BASELINE configs[1] in full: the whole 32-frame closed loop of test.py:182-250 at EL 1152x1920 / BL 576x960.
+                    Bits, PSNR, whole-tensor sums and the quantised latents of ALL 32 frames; strided samples only of
+                    frames 0, 1, 2, 15, 31 (the fixture would otherwise be 50 MB)
 
 The frame loop is test.py's (test.py:182-250), exactly as tests/golden/make_golden.py replays it. What is stored per
 frame: bits, PSNR, strided samples and double-precision sums of every tensor the model hands back, and -- so that a
@@ -37,10 +40,12 @@ CASES = {
     # name: (frames, picture H, picture W, scale, gain, seed)
     "x2_1080p_ipp": (3, 1080, 1920, 2.0, 0.55, 0),
     "x1_5_1080p_ip": (2, 1080, 1920, 1.5, 0.55, 1),
-    "x2_2160p_ip": (2, 2160, 3840, 2.0, 0.55, 2),
+    "x2_2160p_ipp": (3, 2160, 3840, 2.0, 0.55, 2),
+    "x2_1080p_gop32": (32, 1080, 1920, 2.0, 0.55, 4),
     "_dev_x2_128_ipp": (3, 120, 128, 2.0, 0.55, 3),       # generator self-check only, not committed
 }
 # (spatial stride, channel stride) of the stored samples
+DENSE_FRAMES = (0, 1, 2, 15, 31)     # frames of a long case whose strided samples are stored
 SAMPLE = {"x_hat_bl": (4, 1), "x_hat_el": (8, 1), "feature_el": (32, 4), "feature_bl": (16, 4), "mv_hat": (8, 1),
           "warp_frame": (8, 1), "x_bl": (8, 1)}
 
@@ -120,7 +125,9 @@ def run_case(name, IntraSS, LSSVC_extend, imresize):
             x_bl = imresize(x_el, sizes=(h, w), kernel="cubic").clamp_(0, 1)                                       # test.py:199
             mine = imresize_bicubic(x_el, (h, w)).clamp_(0, 1)
             assert torch.equal(mine, x_bl), "bicubic restatement differs from the reference's imresize: max %g" % (mine - x_bl).abs().max().item()
-            out["f%d_x_bl" % t] = sample("x_bl", x_bl)
+            dense = frames <= 3 or t in DENSE_FRAMES
+            if dense:
+                out["f%d_x_bl" % t] = sample("x_bl", x_bl)
             out["f%d_x_bl_sha1" % t] = np.array(sha1(x_bl))
             inet.set_scale_information(scale, (H, W), (0, 0, 0, 0))
             pnet.set_scale_information(scale, (H, W), (0, 0, 0, 0))
@@ -151,17 +158,20 @@ def run_case(name, IntraSS, LSSVC_extend, imresize):
                 assert names == ["get_y_bits_probs", "get_y_bits_probs", "get_z_bits_probs", "get_z_bits_probs"] * 2, names
                 for key, (_, v) in zip(("bl_y", "bl_mv_y", "bl_z", "bl_mv_z", "el_y", "el_mv_y", "el_z", "el_mv_z"), rec.bits_args):
                     out["f%d_sym_%s" % (t, key)] = v.reshape(-1).numpy()
-                out["f%d_mv_hat" % t] = sample("mv_hat", r["mv_hat"])
+                if dense:
+                    out["f%d_mv_hat" % t] = sample("mv_hat", r["mv_hat"])
+                    out["f%d_warp_frame" % t] = sample("warp_frame", r["warp_frame"])
+                    out["f%d_feature_bl" % t] = sample("feature_bl", dpb["ref_feature_bl"])
                 out["f%d_mv_hat_sum" % t] = sums(r["mv_hat"])
-                out["f%d_warp_frame" % t] = sample("warp_frame", r["warp_frame"])
-                out["f%d_feature_bl" % t] = sample("feature_bl", dpb["ref_feature_bl"])
+                out["f%d_warp_frame_sum" % t] = sums(r["warp_frame"])
                 out["f%d_feature_bl_sum" % t] = sums(dpb["ref_feature_bl"])
             out["f%d_bits" % t] = np.array([r["bit_bl"], r["bit_el"]], dtype=np.float64)
-            out["f%d_x_hat_bl" % t] = sample("x_hat_bl", dpb["ref_frame_bl"])          # un-clamped, as returned
+            if dense:
+                out["f%d_x_hat_bl" % t] = sample("x_hat_bl", dpb["ref_frame_bl"])      # un-clamped, as returned
+                out["f%d_x_hat_el" % t] = sample("x_hat_el", dpb["ref_frame_el"])
+                out["f%d_feature_el" % t] = sample("feature_el", dpb["ref_feature_el"])
             out["f%d_x_hat_bl_sum" % t] = sums(dpb["ref_frame_bl"])
-            out["f%d_x_hat_el" % t] = sample("x_hat_el", dpb["ref_frame_el"])
             out["f%d_x_hat_el_sum" % t] = sums(dpb["ref_frame_el"])
-            out["f%d_feature_el" % t] = sample("feature_el", dpb["ref_feature_el"])
             out["f%d_feature_el_sum" % t] = sums(dpb["ref_feature_el"])
             dpb["ref_frame_bl"].clamp_(0, 1)                                            # test.py:249-250
             dpb["ref_frame_el"].clamp_(0, 1)
@@ -176,7 +186,7 @@ def run_case(name, IntraSS, LSSVC_extend, imresize):
 
 
 if __name__ == "__main__":
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("LSSVC_GOLDEN_THREADS", "8")))
     IntraSS, LSSVC_extend = import_reference()
     from src.utils.core import imresize  # reference's MATLAB-style bicubic (core.py:364-432)
     for case in (sys.argv[1:] or list(CASES)):

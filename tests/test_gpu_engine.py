@@ -194,3 +194,48 @@ def test_c_programs_write_and_read_real_bitstreams(tmp_path):
         for k, (e, dd, x) in enumerate(zip(outs["enc"][t], outs["dec"][t], want[t])):
             assert torch.equal(e, dd), (t, k, "encoder-side and decoder-side reconstructions differ")
             assert torch.equal(dd, x), (t, k, (dd - x).abs().max().item())
+
+
+def test_plan_with_inter_layer_padding_replays_through_the_engine(tmp_path):
+    """A plan compiled with a NON-ZERO pad_size (set_scale_information's inter-layer padding, get_depadded_feature:
+    IntraSS.py:124-147): the crop / pad of the BL texture and latent is a library launch (lssvc_pad_crop), so the recorder
+    sees it and the engine -- driven here through ctypes, no model object involved in the replay -- returns the Python
+    path's I-frame bit for bit; the header stores the padding the plan was compiled for (lssvc_engine_plan_meta) and the fp32
+    layer set of the range audit. Golden case x2_128_ip_depad holds the Python path itself to the reference."""
+    import ctypes as C
+    from lssvc_amd import IntraSS, plan_compiler, _lib
+    from lssvc_amd.synth import synth_state_dict
+    z, m = load_case("x2_128_ip_depad")
+    assert any(m["pad"])
+    H, W, h, w = m["H"], m["W"], m["h"], m["w"]
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", m["seed"], m["gain"])).to(DEV).eval()
+    inet.set_scale_information(m["scale"], (H, W), m["pad"])
+    x_el = (torch.from_numpy(z["x_el_u8"][0:1]).float() / 255.0).to(DEV)
+    x_bl = torch.from_numpy(z["x_bl"][0:1]).to(DEV)
+    r = inet.encode_decode(x_bl, x_el, None, None, h, w, H, W)
+    path = str(tmp_path / "iframe_pad.plan")
+    info, _ = plan_compiler.compile_iframe(inet, x_bl, x_el, path)
+    lib = _lib.lib
+    eng = lib.lssvc_engine_create(0)
+    assert eng
+    try:
+        _lib.check(lib.lssvc_engine_load_intra(eng, path.encode()))
+        _lib.check(lib.lssvc_engine_set_scale(eng, C.c_float(m["scale"]), H, W))
+        v = C.c_int64()
+        for name, want in zip(("pad_left", "pad_right", "pad_top", "pad_bottom"), m["pad"]):
+            _lib.check(lib.lssvc_engine_plan_meta(eng, 0, name.encode(), C.byref(v)))
+            assert v.value == want, (name, v.value, want)
+        _lib.check(lib.lssvc_engine_plan_meta(eng, 0, b"f32_layers_n", C.byref(v)))
+        assert v.value == 0
+        assert lib.lssvc_engine_plan_meta(eng, 0, b"no_such_entry", C.byref(v)) != 0
+        outs = [torch.empty(1, 3, h, w, device=DEV), torch.empty(1, 3, H, W, device=DEV), torch.empty(1, 64, H, W, device=DEV)]
+        bits = (C.c_double * 2)()
+        for _ in range(3):                                          # eager, capture, replay
+            _lib.check(lib.lssvc_engine_iframe(eng, C.c_void_p(x_bl.data_ptr()), C.c_void_p(x_el.data_ptr()), bits,
+                                               *[C.c_void_p(o.data_ptr()) for o in outs], None))
+            torch.cuda.synchronize()
+            assert (bits[0], bits[1]) == (r["bit_bl"], r["bit_el"])
+            for o, k in zip(outs, ("x_hat_bl", "x_hat_el", "feature_el")):
+                assert torch.equal(o, r[k].contiguous()), k
+    finally:
+        lib.lssvc_engine_destroy(eng)

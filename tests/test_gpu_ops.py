@@ -160,6 +160,19 @@ def test_resize(hip, c, hin, win, hout, wout, scale):
     close(got, want, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("c,H,W,pad", [(3, 9, 11, (1, 2, 3, 4)), (64, 16, 24, (-2, -1, -3, 0)), (96, 8, 8, (2, -3, -1, 5)), (5, 7, 6, (0, 0, -2, -2)),
+                                       (4, 5, 5, (-5, 6, 0, 0))])
+def test_pad_crop_matches_f_pad(hip, c, H, W, pad):
+    """get_depadded_feature (IntraSS.py:124-135): F.pad with zeros, negative entries cropping; the last case crops the whole
+    source away on one side (all zeros)."""
+    x = torch.randn(1, c, H, W, generator=torch.Generator().manual_seed(c))
+    want = F.pad(x, pad, mode="constant", value=0)
+    got = back(hip.pad_crop(nhwc(hip, x), pad))
+    assert got.shape == want.shape and torch.equal(got, want)
+    wide = nhwc(hip, torch.cat([x, x], 1))                       # a channel slice of a wider buffer (ld > C)
+    assert torch.equal(back(hip.pad_crop(wide.slice(c, 2 * c), pad)), want)
+
+
 def _with_option(name, value, fn):
     import ctypes as C
     from lssvc_amd._lib import lib, check

@@ -77,3 +77,26 @@ def test_gather_reduce_and_sharded_loop_over_rccl(rccl_world_of_one):
     # world of one takes the in-process path, where the exception propagates as it is
     with pytest.raises(ValueError):
         shard.run_sharded([1, 2, 3], flaky, dist)
+
+
+def test_bench_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` with no launcher in front, on the ONE card of a test box (LSSVC_BENCH_REHEARSAL=1: both ranks
+    on cuda:0, collectives over gloo): bench.py starts its own two rank processes, rank 0's checkpoints are broadcast, each rank
+    codes its own short GOP through the HIP path, the timing is max-reduced and ONE line comes back with n_gpus 2. A rehearsal of
+    the flow the driver's 8-GPU run takes, not a measurement (the line says so itself)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LSSVC_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "3",
+                        "--no-cpu-baseline", "--no-side-configs", "--no-h2d-pass", "--no-events"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
+    assert line["value"] > 0 and "REHEARSAL" in line["config"]["parallelism"]
+    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 1e-3)) < 1e-2 * line["value"]      # whole-job frames over the max-over-ranks time

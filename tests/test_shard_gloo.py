@@ -181,3 +181,36 @@ def test_a_failing_unit_is_reported_on_every_rank():
     for rank, meta_ok, msg in got:
         assert meta_ok
         assert msg is not None and "rank 1, unit 3" in msg and "sequence ends before frame 7" in msg and "1 of 6" in msg
+
+
+def _run_bench(extra_env, *argv):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, [json.loads(ln) for ln in lines]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in front (how the driver may call it, and what test.py:648-656,685-748 does
+    for itself: one worker process per GPU): bench.py starts the two ranks as child processes before it touches HIP, rank 0's
+    single JSON line comes back on stdout with n_gpus 2, exit code 0. LSSVC_BENCH_DRYRUN=1 leaves the codec out so that this
+    runs on a host without a GPU; the full flow on a GPU is tests/test_gpu_shard.py::test_bench_two_ranks_rehearsal."""
+    p, lines = _run_bench({"LSSVC_BENCH_DRYRUN": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["dry_run"] is True and lines[0]["steps"] == 2
+    assert lines[0]["checkpoint_tensors_broadcast"] == 334
+    assert "starting 2 ranks" in p.stderr
+
+
+def test_bench_reports_a_failed_rank():
+    """A rank that dies takes the launcher's exit code with it: non-zero, no JSON line."""
+    p, lines = _run_bench({"LSSVC_BENCH_DRYRUN": "1", "LSSVC_BENCH_DRYRUN_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert p.returncode != 0
+    assert not lines
