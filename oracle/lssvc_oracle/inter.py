@@ -384,5 +384,7 @@ def inter_forward(sd, x_bl, x_el, dpb, shape_hr, scale, extras=False, pad_size=(
     if extras:
         out.update({"bl": bl, "mv_up": mv_up, "mv": mv, "y": y, "y_q": y_q, "y_hat": y_hat, "scales_hat": scales_hat,
                     "mv_y_q": mv_y_q, "mv_scales": mv_scales, "z_hat": z_hat, "mv_z_hat": mv_z_hat, "ctx": (c1, c2, c3),
-                    "params": params, "pre_round": {"mv_z": mv_z, "mv_y": mv_y - mv_means, "z": z, "y": y_res}})
+                    "params": params, "pre_round": {"mv_z": mv_z, "mv_y": mv_y - mv_means, "z": z, "y": y_res},
+                    "sym": {"bl_y": bl["y_q"], "bl_mv_y": bl["mv_y_q"], "bl_z": bl["z_hat"], "bl_mv_z": bl["mv_z_hat"],
+                            "el_y": y_q, "el_mv_y": mv_y_q, "el_z": z_hat, "el_mv_z": mv_z_hat}})
     return out

@@ -54,7 +54,9 @@ def bl_layer_information(x, p):
     scales, means = g.chunk(2, 1)
     y_hat, y_lik = gaussian_conditional(y, scales, means)
     x_hat = bl_g_s(y_hat, p)
-    return {"bits": bits_from_likelihoods(y_lik, z_lik), "x_hat": x_hat, "y_hat": y_hat, "y": y, "z": z}
+    med = p.sub("entropy_bottleneck")["quantiles"][:, 0, 1].view(1, -1, 1, 1)
+    return {"bits": bits_from_likelihoods(y_lik, z_lik), "x_hat": x_hat, "y_hat": y_hat, "y": y, "z": z,
+            "y_q": torch.round(y - means), "z_q": torch.round(z - med)}      # the integers the coder sees (tests: symbol planes)
 
 
 def texture_resampler(x, p, shape_hr):
@@ -161,6 +163,8 @@ def intra_forward(sd, x_bl, x_el, shape_hr, extras=False, pad_size=(0, 0, 0, 0))
     out = {"bit_bl": bl["bits"].item(), "bit_el": bits_from_likelihoods(y_lik, z_lik).item(),
            "x_hat_bl": x_hat_bl_full, "x_hat_el": x_hat, "feature_el": feature}
     if extras:
+        med = p.sub("entropy_bottleneck")["quantiles"][:, 0, 1].view(1, -1, 1, 1)
         out.update({"y_bl": bl["y"], "z_bl": bl["z"], "y_hat_bl": y_hat_bl, "ctx": (c1, c2, c3), "y": y, "z": z,
-                    "scales": scales, "means": means, "y_hat": y_hat})
+                    "scales": scales, "means": means, "y_hat": y_hat,
+                    "sym": {"bl_y": bl["y_q"], "bl_z": bl["z_q"], "el_y": torch.round(y - means), "el_z": torch.round(z - med)}})
     return out

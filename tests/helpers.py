@@ -113,3 +113,55 @@ def replay_full(name, i_frame, p_frame, device="cpu"):
         dpb["ref_frame_bl"].clamp_(0, 1)
         dpb["ref_frame_el"].clamp_(0, 1)
         yield t, r, raw, dpb, psnr(x_bl, dpb["ref_frame_bl"]), psnr(x_el, dpb["ref_frame_el"]), exact
+
+
+# ---- decoder pass on stored symbols (tests/test_gpu_golden_full.py, the symbol-aware closed loops of tests/test_gpu_frames.py) ----
+class ArraySource:
+    """Decoder-side symbol source (duck type of entropy_coder.SymbolSource) that hands out stored planes instead of
+    decoding a stream."""
+
+    def __init__(self, planes):
+        self.planes = [np.ascontiguousarray(p, dtype=np.int32).reshape(-1) for p in planes]
+
+    def pull(self, indexes, tables):
+        a = self.planes.pop(0)
+        assert a.size == np.asarray(indexes).size, (a.size, np.asarray(indexes).size)
+        return a
+
+
+def _fold(y_q, step):
+    """The C/4-channel plane of spatial-prior step `step` (y_q_w_k, LSSVC_net.py:432-442) of a (C, H, W) symbol array."""
+    from lssvc_amd.inter import CHUNK_OF_MASK
+    c4 = y_q.shape[0] // 4
+    out = np.zeros((c4,) + y_q.shape[1:], dtype=y_q.dtype)
+    for mpos, (r, c) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        ch = CHUNK_OF_MASK[step][mpos]
+        out[:, r::2, c::2] = y_q[ch * c4:(ch + 1) * c4, r::2, c::2]
+    return out
+
+
+def decode_from_symbols(syms, H, W, h, w, t, inet, pnet, dpb):
+    """The DECODER role of the codec functions fed stored symbol planes (the reference's or the oracle's; syms: {"bl_y": ...,
+    "el_mv_z": ...}, channel-major int arrays) for frame t (0 = the I-frame) -> result dict like encode_decode's. No rounding
+    stands between these outputs and the reference's, so they can be compared tightly, and as the next frame's DPB they keep a
+    closed loop aligned with the reference's however a rounding tie fell in the encoder pass."""
+    from lssvc_amd.hip_ops import T
+    m = {"H": H, "W": W, "h": h, "w": w}
+    sym = lambda k: np.asarray(syms[k])
+    if t == 0:
+        x_hat_bl, y_hat_bl = inet._bl_codec(None, sources=(ArraySource([sym("bl_y")]), ArraySource([sym("bl_z")])),
+                                            lat_hw=(m["h"] // 64, m["w"] // 64))
+        feature, x_hat = inet._el_codec(None, x_hat_bl, y_hat_bl, sources=(ArraySource([sym("el_y")]), ArraySource([sym("el_z")])),
+                                        lat_hw=(m["H"] // 64, m["W"] // 64))
+        return {"x_hat_bl": x_hat_bl.to_nchw(), "x_hat_el": x_hat.to_nchw(), "feature_el": feature.to_nchw()}
+    nhwc = lambda v: None if v is None else T.from_nchw(v)
+    ref_bl, ref_el = nhwc(dpb["ref_frame_bl"]), nhwc(dpb["ref_frame_el"])
+    feat_bl, feat_el = nhwc(dpb["ref_feature_bl"]), nhwc(dpb["ref_feature_el"])
+    bl = pnet._bl_codec(None, ref_bl, feat_bl, source=ArraySource([sym("bl_mv_z"), sym("bl_mv_y"), sym("bl_z"), sym("bl_y")]))
+    y = sym("el_y").reshape(128, m["H"] // 16, m["W"] // 16)
+    src = ArraySource([sym("el_mv_z"), sym("el_mv_y"), sym("el_z")] + [_fold(y, s) for s in range(4)])
+    feature, recon_el, mv_hat, warp_frame = pnet._el_codec(None, bl, ref_el, feat_el, source=src)
+    assert not src.planes
+    return {"dpb": {"ref_frame_bl": bl["recon"].to_nchw(), "ref_feature_bl": bl["feature"].to_nchw(),
+                    "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()},
+            "mv_hat": mv_hat.to_nchw(), "warp_frame": warp_frame.to_nchw()}

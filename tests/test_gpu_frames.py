@@ -99,15 +99,17 @@ def _oracle_gop(n, H, W, seed, gain, scale=2.0, bl=None):
         for t in range(n):
             xb, xe = x_bl[t:t + 1], clip[t:t + 1]
             if t == 0:
-                o = intra_forward(sd_i, xb, xe, (H, W))
+                o = intra_forward(sd_i, xb, xe, (H, W), extras=True)
                 do = {"ref_frame_bl": o["x_hat_bl"], "ref_frame_el": o["x_hat_el"], "ref_feature_bl": None,
                       "ref_feature_el": o["feature_el"]}
             else:
-                o = inter_forward(sd_p, xb, xe, do, (H, W), scale)
+                o = inter_forward(sd_p, xb, xe, do, (H, W), scale, extras=True)
                 do = o["dpb"]
             do["ref_frame_bl"].clamp_(0, 1)
             do["ref_frame_el"].clamp_(0, 1)
-            rows.append((float(o["bit_bl"]), float(o["bit_el"]), psnr(xb, do["ref_frame_bl"]), psnr(xe, do["ref_frame_el"])))
+            syms = {k: v.reshape(-1).to(torch.int16).numpy() for k, v in o["sym"].items()}      # the integers the coder would see
+            rows.append((float(o["bit_bl"]), float(o["bit_el"]), psnr(xb, do["ref_frame_bl"]), psnr(xe, do["ref_frame_el"]), syms))
+            del o
     _ORACLE_GOPS[key] = (clip, x_bl, rows)
     return _ORACLE_GOPS[key]
 
@@ -148,13 +150,92 @@ def _gpu_gop_against_oracle(n, H, W, seed, gain, want_kernels=(), scale=2.0, bl=
                 hip_ops.OP_LOG = None
         dg["ref_frame_bl"].clamp_(0, 1)
         dg["ref_frame_el"].clamp_(0, 1)
-        o_bl, o_el, o_pbl, o_pel = rows[t]
+        o_bl, o_el, o_pbl, o_pel = rows[t][:4]
         assert abs(g["bit_bl"] - o_bl) / (h * w) <= 1e-5, (t, g["bit_bl"], o_bl)
         assert abs(g["bit_el"] - o_el) / (H * W) <= 1e-5, (t, g["bit_el"], o_el)
         assert abs(psnr(xe, dg["ref_frame_el"].cpu()) - o_pel) <= 1e-4, t
         assert abs(psnr(xb, dg["ref_frame_bl"].cpu()) - o_pbl) <= 1e-4, t
     for k in want_kernels:
         assert any(s.startswith(k) for s in seen), (k, sorted(seen))
+
+
+TIE_STATS = {}             # precision -> [symbols compared, symbols that differ from the oracle's]
+MAX_FLIPS_PER_PLANE = 4    # of a frame's latent planes (3 k - 150 k symbols each at these sizes); every one must be off by exactly one
+FLIP_BITS = 40.0           # bound on what ONE flipped symbol moves a frame's bit count (likelihoods are floored at 1e-9 = 29.9 bits)
+
+
+def _gpu_gop_symbol_aware(n, H, W, seed, gain, scale=2.0, bl=None):
+    """The closed loop against the oracle with rounding ties told apart from errors (what tests/test_gpu_golden_full.py does
+    against the reference's own symbols; LSSVC_net.py:193, img_entropy_models.py:237 are the round() calls). A differently
+    ordered fp32 sum moves a value that lies within ~3e-7 of k + 1/2 across the tie about once per 10^6 symbols (DESIGN.md
+    section 9); at 256x384 pixels one such symbol is 1.9e-4 bpp, beyond the 1e-5 bar by construction, and from then on a
+    plain closed loop drifts away from the oracle's. So per frame:
+      ENCODER pass (public API, estimate mode) from a DPB aligned with the oracle's: every symbol against the oracle's --
+          at most MAX_FLIPS_PER_PLANE differences per plane, each by exactly one; bits inside 1e-5 bpp + FLIP_BITS per
+          flipped symbol (no flip: the plain bar); PSNR inside 1e-4 dB when nothing flipped.
+      DECODER pass (decoder role of the same codec functions on the ORACLE's symbols): PSNR of both layers inside 1e-4 dB,
+          always; its outputs are the next frame's DPB.
+    Flip counts are accumulated in TIE_STATS (test_tie_rate_report)."""
+    from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
+    from lssvc_amd.synth import synth_state_dict
+    from lssvc_amd.preprocess import psnr
+    from helpers import decode_from_symbols
+    clip, x_bl, rows = _oracle_gop(n, H, W, seed, gain, scale, bl)
+    h, w = x_bl.shape[2:]
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", seed, gain)).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", seed, gain))
+    pnet.to(DEV).eval()
+    inet.update(force=True)                                  # the decoder role reads the bottleneck medians from the tables
+    pnet.update(force=True)
+    stats = TIE_STATS.setdefault(hip_ops.CONV_PRECISION, [0, 0])
+    dg, report = None, []
+    for t in range(n):
+        xb, xe = x_bl[t:t + 1], clip[t:t + 1]
+        net = inet if t == 0 else pnet
+        net.set_scale_information(scale, (H, W), (0, 0, 0, 0))
+        taps = net.taps = {}
+        if t == 0:
+            g = inet.encode_decode(xb.to(DEV), xe.to(DEV), None, None)
+            enc = {"ref_frame_bl": g["x_hat_bl"], "ref_frame_el": g["x_hat_el"]}
+        else:
+            g = pnet.encode_decode(xb.to(DEV), xe.to(DEV), dg)
+            enc = g["dpb"]
+        net.taps = None
+        o_bl, o_el, o_pbl, o_pel, syms = rows[t]
+        assert set(taps) == set(syms), (sorted(taps), sorted(syms))
+        flips = {"bl": 0, "el": 0}
+        for key, want in syms.items():
+            got = taps[key].reshape(-1).numpy()
+            assert got.shape == want.shape, (key, got.shape, want.shape)
+            d = got.astype(np.int32) - want.astype(np.int32)
+            nz = int(np.count_nonzero(d))
+            assert nz <= MAX_FLIPS_PER_PLANE and (nz == 0 or int(np.abs(d).max()) == 1), (t, key, nz, int(np.abs(d).max()))
+            flips[key[:2]] += nz
+            stats[0] += d.size
+            stats[1] += nz
+        assert abs(g["bit_bl"] - o_bl) <= 1e-5 * h * w + FLIP_BITS * flips["bl"], (t, g["bit_bl"], o_bl, flips)
+        assert abs(g["bit_el"] - o_el) <= 1e-5 * H * W + FLIP_BITS * flips["el"], (t, g["bit_el"], o_el, flips)
+        if flips["bl"] == 0:
+            assert abs(psnr(xb, enc["ref_frame_bl"].cpu().clamp(0, 1)) - o_pbl) <= 1e-4, t
+            if flips["el"] == 0:
+                assert abs(psnr(xe, enc["ref_frame_el"].cpu().clamp(0, 1)) - o_pel) <= 1e-4, t
+        del g, enc
+        d = decode_from_symbols(syms, H, W, h, w, t, inet, pnet, dg)
+        dg = d["dpb"] if t else {"ref_frame_bl": d["x_hat_bl"], "ref_frame_el": d["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": d["feature_el"]}
+        dg["ref_frame_bl"].clamp_(0, 1)
+        dg["ref_frame_el"].clamp_(0, 1)
+        assert abs(psnr(xb, dg["ref_frame_bl"].cpu()) - o_pbl) <= 1e-4, t
+        assert abs(psnr(xe, dg["ref_frame_el"].cpu()) - o_pel) <= 1e-4, t
+        if flips["bl"] or flips["el"]:
+            report.append((t, flips["bl"], flips["el"]))
+    print("symbol-aware loop %dx%d seed %d %s: frames with flipped symbols (t, BL, EL) = %s" % (H, W, seed, hip_ops.CONV_PRECISION, report or "none"))
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_gop_drift_symbol_aware(seed, precision):
+    """The 32-frame GOP of test_gop_drift_vs_oracle on three more seeds, with ties handled instead of avoided."""
+    _gpu_gop_symbol_aware(32, 128, 128, seed, 0.55)
 
 
 def test_gop_drift_vs_oracle(precision):
@@ -173,31 +254,44 @@ def test_frames_384x640_vs_oracle(precision):
     _gpu_gop_against_oracle(3, 384, 640, 3, 0.55, want_kernels=want)
 
 
+@pytest.mark.parametrize("seed", [7, 8, 9])
 @pytest.mark.parametrize("ph,pw,scale,frames", [
     (240, 416, 2.0, 3),
     # the oracle's CPU seconds, not the GPU's, make these long (45 - 80 s each on a 16-core host share): --runslow / LSSVC_SLOW=1
     pytest.param(240, 416, 1.5, 3, marks=pytest.mark.slow), pytest.param(480, 832, 2.0, 2, marks=pytest.mark.slow),
     pytest.param(720, 1280, 1.5, 2, marks=pytest.mark.slow)])
-def test_dataset_picture_sizes_vs_oracle(ph, pw, scale, frames, precision):
+def test_dataset_picture_sizes_vs_oracle(ph, pw, scale, frames, seed, precision):
     """The picture sizes of the reference's own test set below 720p (HEVC class C 832x480 and class D 416x240,
     recommend_test_config.json) at both of its ratios, padded as test.py pads them (common.py:48-86): EL 512x896 / BL 256x448,
     EL 384x576 / BL 256x384 (ratio 1.5) and EL 256x512 / BL 128x256 -- map widths of 14, 9 and 8 sixty-fourths, which none of
     the other shapes has -- and class E 1280x720 at ratio 1.5 (EL 768x1344 / BL 512x896: 21 sixty-fourths); I + P + P at
-    416x240, I + P at the larger sizes (the oracle's seconds bound the suite),
-    against the CPU oracle at the north-star bars.
-    Seed: 7, 8 and 9 were run for every shape in both precisions (18 runs); 17 pass, and seed 7 at 416x240 / ratio 1.5 in
-    the f32 mode misses the base-layer bit count of the I-frame by 18.49 bits = log2 of the likelihood ratio of symbols 0 and
-    1 at sigma = 0.11 (18.48): ONE symbol whose sigma sits at the floor rounded the other way at a tie, y - mu within the fp32
-    noise of k + 1/2 (the two precisions agree on y to 3e-6 at this size, tools/debug_precision_diff.py 256 384 7 0.55; the
-    f16x3 mode passes that very seed). At 256x384 pixels that one tie is 1.9e-4 bpp,
-    beyond the bar by construction; which seed ties is a property of the summation order, not of a kernel, and ties are what
-    tests/test_gpu_golden_full.py handles with the reference's own symbols. This test uses seed 8.
-    Run by default: 416x240 at ratio 2; the other three are marked slow (their oracle runs take 45-80 s each of the suite's time)
-    and passed on the GPU in both precisions when they were added (--runslow / LSSVC_SLOW=1 with -m gpu)."""
+    416x240, I + P at the larger sizes (the oracle's seconds bound the suite), against the CPU oracle, seeds 7, 8 and 9, with
+    the symbol-aware comparison (_gpu_gop_symbol_aware): round 3 ran the plain comparison, found that seed 7 at 416x240 /
+    ratio 1.5 in the f32 mode flips ONE base-layer symbol of the I-frame at a tie (18.49 bits = 1.9e-4 bpp at 256x384 pixels)
+    and picked seed 8; a tie is now recognised for what it is on every seed, counted, and the loop carries on from the
+    oracle's symbols. Run by default: 416x240 at ratio 2; the other shapes are marked slow (their oracle runs take 45-80 s each)."""
     from lssvc_amd.preprocess import interlayer_padding
     pad = interlayer_padding(ph, pw, scale)
     (H, W), bl = pad["HR_padded_size"], pad["LR_padded_size"]
-    _gpu_gop_against_oracle(frames, H, W, 8, 0.55, scale=scale, bl=bl)
+    _gpu_gop_symbol_aware(frames, H, W, seed, 0.55, scale=scale, bl=bl)
+
+
+def test_tie_rate_report():
+    """Runs after the symbol-aware loops of this file (pytest keeps file order): symbols compared and symbols that fell on the
+    other side of a rounding tie than the oracle's, per conv precision, as flips per 10^6 symbols; kept in
+    gpurun_out/tie_stats.json (DESIGN.md section 9 quotes it). The fp32 noise floor predicts O(1) per 10^6."""
+    import json
+    import os
+    if not TIE_STATS:
+        pytest.skip("no symbol-aware loop ran in this session")
+    out = {k: {"symbols": v[0], "flipped": v[1], "flips_per_million": round(1e6 * v[1] / max(v[0], 1), 3)} for k, v in TIE_STATS.items()}
+    print("tie statistics:", out)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "tie_stats.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    for k, v in out.items():
+        assert v["flips_per_million"] <= 25.0, (k, v)
 
 
 def test_config1_single_iframe_256(precision):
