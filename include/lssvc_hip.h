@@ -325,6 +325,44 @@ int lssvc_rans_decode_stream_i16(void *dec, const int16_t *indexes, int64_t n, c
 /* cdf_out has n + 1 entries */
 int lssvc_pmf_to_quantized_cdf(const float *pmf, int32_t n, int32_t precision, uint32_t *cdf_out);
 
+/* ---- checkpoint -> kernel layouts, on the host (csrc/weight_prep.cpp) -------------------------------------------------------
+ * What nn.Module.load_state_dict + the first forward do for the reference (src/models/IntraSS.py:190-214,
+ * src/models/LSSVC_net.py:141-149): here a checkpoint is a table of named fp32 tensors exactly as the reference's state dict
+ * holds them (OIHW conv weights, GDN beta / gamma, BitEstimator / EntropyBottleneck parameters; 'module.' prefix already
+ * stripped), and one call turns one layer's tensors into the blobs the kernels consume. The Python front end
+ * (lssvc_amd/weights.py) and the engine (lssvc_engine_load_checkpoint) both go through it. Host memory in, host memory out. */
+typedef struct lssvc_tensor {
+    const char *name;      /* state-dict key, e.g. "res_encoder.conv1.weight" */
+    const float *data;     /* contiguous, row-major */
+    int32_t ndim;          /* <= 4 */
+    int64_t shape[4];
+} lssvc_tensor;
+
+enum {
+    LSSVC_PREP_CONV = 1,            /* <name>.weight [, .bias]           -> [chunk8][ky][kx][m][8] fp32, bias[M_pad]; dims Cout, M_pad, KH, KW */
+    LSSVC_PREP_CONV_F16X3 = 2,      /* <name>.weight                     -> fp16 [hi|lo][chunk16][ky][kx][m][16] of w * 2^e; scalars[0] = 2^-e */
+    LSSVC_PREP_CONVT = 3,           /* ConvTranspose2d, flag = stride    -> as CONV of the equivalent conv; dims[4] = pad, dims[5] = pixel_shuffle */
+    LSSVC_PREP_DWCONV = 4,          /* (C,1,3,3) depthwise               -> [9][C], bias[C] */
+    LSSVC_PREP_GDN = 5,             /* flag 0 = gdn.py / 1 = video_net_component.py -> 1x1 conv of gamma on x^2: fp32 weights, beta as bias, fp16 planes */
+    LSSVC_PREP_VECTOR = 6,          /* tensor <name> as it is, flattened */
+    LSSVC_PREP_BIT_ESTIMATOR = 7,   /* <name>.f1..f4.{h,b,a}             -> [11][C] */
+    LSSVC_PREP_ENTROPY_BOTTLENECK = 8, /* <name>._matrices/_biases/_factors/quantiles -> [59][C] */
+    LSSVC_PREP_FFN_F16X3 = 9        /* ConvFFN <name>.conv.{0,2} [+ leading 1x1 conv <name2>] -> w1, w2 (fp16 planes), b1, b2 [, wp, bp];
+                                       scalars = unscale of w1, w2 [, wp]; dims hidden, C, pre_cin */
+};
+#define LSSVC_PREP_MAX_BLOBS 8
+typedef struct lssvc_prep_spec {
+    int32_t kind;
+    char name[120];
+    char name2[120];
+    int32_t splits[3];     /* CONV / CONV_F16X3: channel counts of the concatenated input segments (sum = Cin) */
+    int32_t n_splits;
+    int32_t flag;          /* CONV*: pixel_shuffle; CONVT: stride; GDN: flavour */
+} lssvc_prep_spec;
+/* blobs == NULL: size query (n_blobs, blob_bytes, dims). Otherwise blobs[i] points at blob_bytes[i] bytes of host memory to fill. */
+int lssvc_prepare_weights(const lssvc_tensor *checkpoint, int32_t n_tensors, const lssvc_prep_spec *spec, int32_t *n_blobs,
+                          int64_t blob_bytes[LSSVC_PREP_MAX_BLOBS], float scalars[4], int32_t dims[8], void *const *blobs);
+
 /* ---- engine: compiled frame plans (csrc/plan_runtime.cpp) ------------------------------------------------
  * Frame-level entry points for a caller without Python or PyTorch (last row). They replace, per frame,
  * IntraSS.encode_decode(bin_path=None) = IntraSS.forward (src/models/IntraSS.py:245-249,137-172) and

@@ -55,6 +55,18 @@ class CdfTable(C.Structure):
                 ("offsets", C.c_void_p)]
 
 
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class PrepSpec(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("name", C.c_char * 120), ("name2", C.c_char * 120), ("splits", C.c_int32 * 3), ("n_splits", C.c_int32),
+                ("flag", C.c_int32)]
+
+
+PREP_CONV, PREP_CONV_F16X3, PREP_CONVT, PREP_DWCONV, PREP_GDN, PREP_VECTOR, PREP_BIT_ESTIMATOR, PREP_ENTROPY_BOTTLENECK, PREP_FFN_F16X3 = range(1, 10)
+PREP_MAX_BLOBS = 8
+
 VP = C.POINTER(View)
 TP = C.POINTER(CdfTable)
 
@@ -113,6 +125,8 @@ SIGNATURES = {
     "lssvc_rans_decode_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, TP, C.c_void_p]),
     "lssvc_rans_decode_stream_i16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, TP, C.c_void_p]),
     "lssvc_pmf_to_quantized_cdf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lssvc_prepare_weights": (C.c_int, [C.POINTER(Tensor), C.c_int32, C.POINTER(PrepSpec), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "lssvc_engine_create": (C.c_void_p, [C.c_int32]),
     "lssvc_engine_destroy": (None, [C.c_void_p]),
     "lssvc_engine_load_intra": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -510,6 +510,7 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return fail("conv2d(f16x3p): bad tile count %lld", ntiles);
     if (p.w16_plane * 2 > 0x7fffffffLL) return fail("conv2d(f16x3p): weight image too large for 32-bit lane offsets");
     long long blocks = cus;                       // one persistent 8-wave workgroup per CU
+    if (const int forced = option_get(OPT_P3_BLOCKS); forced > 0) blocks = forced;      // experiments (tools/p3_scaling.py)
     if (blocks > ntiles) blocks = ntiles;
     if (MF == 4 && !INACT && (p.debug & 256)) {             // diagnostic: in-kernel stamps (tools/p3_stamps.py)
         static LdsGrant grant_s;

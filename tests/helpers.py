@@ -45,7 +45,7 @@ def replay(case, i_frame, p_frame, device="cpu"):
 
 
 # ---- full-size cases (tests/golden/make_golden_full.py): inputs are regenerated, not stored -------------------------
-FULL_CASES = ("x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_ip")
+FULL_CASES = ("x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_ipp", "x2_1080p_gop32")
 FULL_SAMPLE = {"x_hat_bl": (4, 1), "x_hat_el": (8, 1), "feature_el": (32, 4), "feature_bl": (16, 4), "mv_hat": (8, 1),
                "warp_frame": (8, 1), "x_bl": (8, 1)}
 
@@ -90,7 +90,8 @@ def _full_case_inputs(name):
         x_el = torch.nn.functional.pad(clip[t:t + 1].float() / 255.0, pad["P_HR"], mode="constant", value=0)
         x_bl = imresize_bicubic(x_el, (m["h"], m["w"])).clamp_(0, 1)
         exact = exact and hashlib.sha1(x_bl.contiguous().numpy().tobytes()).hexdigest() == str(z["f%d_x_bl_sha1" % t])
-        np.testing.assert_allclose(full_sample("x_bl", x_bl).numpy(), z["f%d_x_bl" % t], atol=1e-6, rtol=0)
+        if ("f%d_x_bl" % t) in z.files:                  # (the 32-frame case keeps samples of five frames; the sha1 of all)
+            np.testing.assert_allclose(full_sample("x_bl", x_bl).numpy(), z["f%d_x_bl" % t], atol=1e-6, rtol=0)
         out.append((x_bl, x_el))
     return out, exact
 

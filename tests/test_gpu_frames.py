@@ -232,9 +232,10 @@ def _gpu_gop_symbol_aware(n, H, W, seed, gain, scale=2.0, bl=None):
     print("symbol-aware loop %dx%d seed %d %s: frames with flipped symbols (t, BL, EL) = %s" % (H, W, seed, hip_ops.CONV_PRECISION, report or "none"))
 
 
-@pytest.mark.parametrize("seed", [7, 8, 9])
+@pytest.mark.parametrize("seed", [7, pytest.param(8, marks=pytest.mark.slow), pytest.param(9, marks=pytest.mark.slow)])
 def test_gop_drift_symbol_aware(seed, precision):
-    """The 32-frame GOP of test_gop_drift_vs_oracle on three more seeds, with ties handled instead of avoided."""
+    """The 32-frame GOP of test_gop_drift_vs_oracle on three more seeds, with ties handled instead of avoided (seeds 8 and 9
+    are marked slow: each is 32 oracle frames of CPU work; profiles/r04_slow_gpu_tests.txt holds their run)."""
     _gpu_gop_symbol_aware(32, 128, 128, seed, 0.55)
 
 

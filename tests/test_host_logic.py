@@ -46,7 +46,7 @@ def _unlayout(wp, cout, splits, kh, kw):
 
 
 def test_conv_layout_roundtrip():
-    from lssvc_amd.weights import layout_conv
+    from weights_torch_ref import layout_conv
     w = torch.randn(51, 3 + 48, 3, 3)
     b = torch.randn(51)
     wp, bp, cout, m_pad = layout_conv(w, b, [3, 48], False)
@@ -55,7 +55,7 @@ def test_conv_layout_roundtrip():
 
 
 def test_pixel_shuffle_permutation():
-    from lssvc_amd.weights import layout_conv
+    from weights_torch_ref import layout_conv
     w = torch.randn(32, 16, 3, 3)
     b = torch.randn(32)
     x = torch.randn(1, 16, 6, 7)
@@ -71,7 +71,7 @@ def test_pixel_shuffle_permutation():
 
 @pytest.mark.parametrize("stride", [1, 2])
 def test_conv_transpose_rewrite(stride):
-    from lssvc_amd.weights import conv_t_as_conv
+    from weights_torch_ref import conv_t_as_conv
     w = torch.randn(10, 6, 3, 3)
     b = torch.randn(6)
     x = torch.randn(1, 10, 5, 7)
@@ -143,7 +143,7 @@ def test_f16x3_layout_reconstructs_weights_and_prescales():
     relative, in the [chunk16][ky][kx][m][16] order, concat segments zero-padded to 16; the prescale keeps the lo plane
     out of fp16's subnormal range for typical weight magnitudes."""
     import math
-    from lssvc_amd.weights import layout_conv_f16x3
+    from weights_torch_ref import layout_conv_f16x3
     g = torch.Generator().manual_seed(3)
     w = torch.randn(40, 24 + 8, 3, 3, generator=g) * 0.02
     planes, unscale = layout_conv_f16x3(w, [24, 8], False)
@@ -162,7 +162,7 @@ def test_f16x3_layout_reconstructs_weights_and_prescales():
 def test_ffn_layout_chained_k_order():
     """layout_ffn_f16x3 puts W1 / W2 in the K order in which ffn_f16x3.hip chains accumulator fragments into B
     operands: K position (pair p, k = 8g + j) <-> channel 16 * (2p + (j >> 2)) + 4g + (j & 3)."""
-    from lssvc_amd.weights import layout_ffn_f16x3, layout_pw_natural_f16x3
+    from weights_torch_ref import layout_ffn_f16x3, layout_pw_natural_f16x3
     g = torch.Generator().manual_seed(4)
     c, hidden = 48, 192
     w1 = torch.randn(hidden, c, 1, 1, generator=g) * 0.05
@@ -184,6 +184,111 @@ def test_ffn_layout_chained_k_order():
     blob, up = layout_pw_natural_f16x3(wp)
     P = ((blob[:blob.numel() // 2].float() + blob[blob.numel() // 2:].float()) * up).reshape(3, 2, 16, 32)
     assert abs(P[2, 1, 5, 3].item() - wp[37, 35, 0, 0].item()) <= 1e-6 and P[:, 1, :, 8:].abs().max() == 0
+
+
+def _store(sd):
+    from lssvc_amd.weights import WeightStore
+    return WeightStore(sd, torch.device("cpu"))            # host-only use of the library's weight preparation (no launch)
+
+
+def test_weight_prep_matches_torch_layouts():
+    """lssvc_prepare_weights (csrc/weight_prep.cpp: what WeightStore and the engine's checkpoint loader both call) against
+    the torch restatement of every layout (tests/weights_torch_ref.py, the implementation rounds 1-3 shipped): the same
+    bytes for convs (plain, concatenated inputs, sub-pixel), their fp16 hi / lo planes and prescale, both ConvTranspose
+    rewrites, depthwise, GDN of both flavours and the FFN images."""
+    import weights_torch_ref as R
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *sh: torch.randn(*sh, generator=g)
+    sd = {"a.weight": rn(51, 3 + 48, 3, 3) * 0.05, "a.bias": rn(51), "s.weight": rn(32, 16, 3, 3), "s.bias": rn(32), "nb.weight": rn(16, 8, 1, 1),
+          "t.weight": rn(10, 6, 3, 3), "t.bias": rn(6), "d.weight": rn(24, 1, 3, 3), "d.bias": rn(24),
+          "f.conv.0.weight": rn(192, 48, 1, 1) * 0.05, "f.conv.0.bias": rn(192), "f.conv.2.weight": rn(48, 192, 1, 1) * 0.05, "f.conv.2.bias": rn(48),
+          "p.weight": rn(48, 40, 1, 1) * 0.05, "p.bias": rn(48),
+          "gi.beta": rn(16).abs() + 0.5, "gi.gamma": rn(16, 16).abs() * 0.1, "gi.beta_reparam.lower_bound.bound": torch.tensor([(1e-6 + 2.0 ** -36) ** 0.5]),
+          "gi.beta_reparam.pedestal": torch.tensor([2.0 ** -36]), "gi.gamma_reparam.lower_bound.bound": torch.tensor([2.0 ** -18]),
+          "gi.gamma_reparam.pedestal": torch.tensor([2.0 ** -36]), "gp.beta": rn(32).abs() + 0.5, "gp.gamma": rn(32, 32) * 0.1}
+    W = _store(sd)
+    for name, splits, ps in (("a", [3, 48], False), ("s", [16], True), ("nb", [8], False)):
+        wp, bp, cout, m_pad, kh, kw = W.conv(name, splits, ps)
+        rw, rb, rc, rm = R.layout_conv(sd[name + ".weight"], sd.get(name + ".bias"), splits, ps)
+        assert (cout, m_pad, kh, kw) == (rc, rm) + tuple(sd[name + ".weight"].shape[2:])
+        assert torch.equal(wp, rw.reshape(-1)) and torch.equal(bp, rb)
+        planes, unscale = W.conv_f16x3(name, splits, ps)
+        rp, ru = R.layout_conv_f16x3(sd[name + ".weight"], splits, ps)
+        assert unscale == ru and torch.equal(planes.view(torch.int16), rp.reshape(-1).view(torch.int16))
+    for stride in (1, 2):
+        wp, bp, cout, m_pad, kh, kw, pad, ps = W.conv_t("t", stride)
+        w2, b2, rpad, rps = R.conv_t_as_conv(sd["t.weight"], sd["t.bias"], stride)
+        rw, rb, rc, rm = R.layout_conv(w2, b2, [w2.shape[1]], False)
+        assert (cout, m_pad, kh, kw, pad, ps) == (rc, rm, w2.shape[2], w2.shape[3], rpad, rps)
+        assert torch.equal(wp, rw.reshape(-1)) and torch.equal(bp, rb)
+    dw, db = W.dwconv("d")
+    assert torch.equal(dw, sd["d.weight"].reshape(24, 9).t().reshape(-1)) and torch.equal(db, sd["d.bias"])
+    for name, flavour in (("gi", "intra"), ("gp", "inter")):
+        wp, bp, cout, m_pad, _, _ = W.gdn(name, flavour)
+        beta, gamma = sd[name + ".beta"], sd[name + ".gamma"]
+        if flavour == "intra":
+            beta = torch.max(beta, sd[name + ".beta_reparam.lower_bound.bound"]) ** 2 - sd[name + ".beta_reparam.pedestal"]
+            gamma = torch.max(gamma, sd[name + ".gamma_reparam.lower_bound.bound"]) ** 2 - sd[name + ".gamma_reparam.pedestal"]
+        else:
+            beta = torch.max(beta, torch.ones_like(beta) * R._BETA_BOUND) ** 2 - R._PEDESTAL
+            gamma = torch.max(gamma, torch.ones_like(gamma) * R._REPARAM_OFFSET) ** 2 - R._PEDESTAL
+        c = gamma.shape[0]
+        rw, rb, _, _ = R.layout_conv(gamma.reshape(c, c, 1, 1), beta, [c], False)
+        rp, ru = R.layout_conv_f16x3(gamma.reshape(c, c, 1, 1), [c], False)
+        planes, unscale = W.gdn_f16x3(name, flavour)
+        assert torch.equal(wp, rw.reshape(-1)) and torch.equal(bp, rb) and unscale == ru
+        assert torch.equal(planes.view(torch.int16), rp.reshape(-1).view(torch.int16))
+    rec = W.ffn_f16x3("f", "p")
+    (a, ua), (b, ub) = R.layout_ffn_f16x3(sd["f.conv.0.weight"], sd["f.conv.2.weight"])
+    blob, up = R.layout_pw_natural_f16x3(sd["p.weight"])
+    assert (rec["u1"], rec["u2"], rec["up"], rec["hidden"], rec["C"], rec["pre_cin"]) == (ua, ub, up, 192, 48, 40)
+    for got, want in ((rec["w1"], a), (rec["w2"], b), (rec["wp"], blob)):
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(rec["b1"], sd["f.conv.0.bias"]) and torch.equal(rec["b2"], sd["f.conv.2.bias"]) and torch.equal(rec["bp"], sd["p.bias"])
+    rec2 = W.ffn_f16x3("f")
+    assert "wp" not in rec2 and torch.equal(rec2["w1"].view(torch.int16), a.view(torch.int16))
+
+
+def test_weight_prep_tables_and_whole_checkpoints():
+    """The BitEstimator / EntropyBottleneck tables (softplus / tanh in double, rounded once: within one ulp of torch's fp32
+    kernels) and every conv of both synthetic checkpoints through the library's preparation, against the torch restatement;
+    a missing tensor and a wrong split are errors, not garbage."""
+    import torch.nn.functional as F2
+    import weights_torch_ref as R
+    from lssvc_amd import _lib
+    from lssvc_amd.synth import synth_state_dict
+    sd = synth_state_dict("lssvc_extend", 3, 0.6)
+    W = _store(sd)
+    be = W.bit_estimator("bit_estimator_z")
+    rows = []
+    for i in (1, 2, 3):
+        rows += [F2.softplus(sd["bit_estimator_z.f%d.h" % i]), sd["bit_estimator_z.f%d.b" % i], torch.tanh(sd["bit_estimator_z.f%d.a" % i])]
+    rows += [F2.softplus(sd["bit_estimator_z.f4.h"]), sd["bit_estimator_z.f4.b"]]
+    want = torch.stack([r.reshape(-1) for r in rows], 0)
+    assert be.shape == want.shape and torch.allclose(be, want, rtol=2e-7, atol=0)
+    assert torch.equal(be[1], want[1])                                                       # the plain rows are copies
+    si = synth_state_dict("intra_ss", 3, 0.6)
+    Wi = _store(si)
+    eb = Wi.entropy_bottleneck("entropy_bottleneck")
+    assert eb.shape == (59, 64) and torch.equal(eb[58], si["entropy_bottleneck.quantiles"][:, 0, 1])
+    m0 = F2.softplus(si["entropy_bottleneck._matrices.0"])
+    assert torch.allclose(eb[0:3], torch.stack([m0[:, j, 0] for j in range(3)]), rtol=2e-7, atol=0)
+    f3 = torch.tanh(si["entropy_bottleneck._factors.3"])
+    assert torch.allclose(eb[55:58], torch.stack([f3[:, j, 0] for j in range(3)]), rtol=2e-7, atol=0)
+    n = 0
+    for store, d in ((W, sd), (Wi, si)):
+        for k, v in d.items():
+            if k.endswith(".weight") and v.dim() == 4 and v.shape[1] > 1 and "deconv" not in k and v.shape[2] == v.shape[3] and n < 400:
+                name = k[:-7]
+                planes, unscale = store.conv_f16x3(name, [v.shape[1]])
+                rp, ru = R.layout_conv_f16x3(v, [v.shape[1]], False)
+                assert unscale == ru and torch.equal(planes.view(torch.int16), rp.reshape(-1).view(torch.int16)), k
+                n += 1
+    assert n > 200
+    with pytest.raises(_lib.LssvcHipError, match="no tensor"):
+        W.conv("no.such.layer", [3])
+    with pytest.raises(_lib.LssvcHipError, match="add up"):
+        W.conv_f16x3(next(k[:-7] for k, v in sd.items() if k.endswith(".weight") and v.dim() == 4), [1, 2])
 
 
 def test_framing_matches_reference_fixture(tmp_path):
