@@ -367,8 +367,9 @@ int lssvc_prepare_weights(const lssvc_tensor *checkpoint, int32_t n_tensors, con
  * Frame-level entry points for a caller without Python or PyTorch (last row). They replace, per frame,
  * IntraSS.encode_decode(bin_path=None) = IntraSS.forward (src/models/IntraSS.py:245-249,137-172) and
  * LSSVC.encode_decode(output_path_el=None) = LSSVC.forward_one_frame (src/models/LSSVC_net.py:172-185,445-528).
- * A plan file holds ONE frame type at ONE size for ONE checkpoint: the prepared weights and the fixed sequence of library
- * launches the Python front end issues for it (lssvc_amd/plan_compiler.py: compile_iframe / compile_pframe). The engine owns
+ * A plan file holds ONE frame type at ONE size: the fixed sequence of library launches the Python front end issues for it
+ * (lssvc_amd/plan_compiler.py: compile_iframe / compile_pframe), with every weight tensor named by the RECIPE that builds it
+ * from a raw checkpoint (lssvc_engine_load_checkpoint); the weights themselves come from the caller. The engine owns
  * the device memory, the side streams and the hipGraph it captures from the sequence (hipStreamBeginCapture inside the
  * library, after one eager pass). All tensors are fp32 NCHW, batch 1, as at the reference's model API; input / output
  * pointers may be device or host memory (hipMemcpyDefault); an output pointer may be NULL if the caller does not want it.
@@ -376,6 +377,14 @@ int lssvc_prepare_weights(const lssvc_tensor *checkpoint, int32_t n_tensors, con
  * (test.py:249-250; lssvc_clamp_inplace) and hand them back with the two features as the next frame's references. */
 void *lssvc_engine_create(int32_t device);
 void lssvc_engine_destroy(void *engine);
+/* The checkpoint of one model (0 = IntraSS, 1 = LSSVC / LSSVC_extend) as a table of named fp32 tensors: what torch.load +
+ * load_state_dict give the reference (IntraSS.py:190-214, LSSVC_net.py:141-149; a leading 'module.' is dropped the same way).
+ * The engine keeps its own copy; plans loaded afterwards take their weights from it (prepared on the device once per layer by
+ * lssvc_prepare_weights and shared between the model's plans), so a plan file holds launches only and is independent of the
+ * checkpoint -- except for what its compilation baked in: the frame size, and the kernel choice of the fp16 range audit
+ * (entry "f32_layers_n" of lssvc_engine_plan_meta; 0 for every checkpoint whose activations stay inside fp16's range). Call
+ * before lssvc_engine_load_intra / _inter / _stream of that model. */
+int lssvc_engine_load_checkpoint(void *engine, int32_t model, const lssvc_tensor *tensors, int32_t n_tensors);
 int lssvc_engine_load_intra(void *engine, const char *iframe_plan_path);
 /* first_p: the plan of the first P-frame after an I-frame (no BL reference feature, 64-channel EL reference feature),
  * steady_p: every later P-frame of the GOP */

@@ -129,6 +129,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "lssvc_engine_create": (C.c_void_p, [C.c_int32]),
     "lssvc_engine_destroy": (None, [C.c_void_p]),
+    "lssvc_engine_load_checkpoint": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Tensor), C.c_int32]),
     "lssvc_engine_load_intra": (C.c_int, [C.c_void_p, C.c_char_p]),
     "lssvc_engine_load_inter": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "lssvc_engine_set_scale": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, C.c_int32]),

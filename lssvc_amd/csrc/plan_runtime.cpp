@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -42,11 +43,39 @@ struct Region {
     int64_t shape[4] = {0, 0, 0, 0};
     std::string name;
     void *ptr = nullptr;
+    // weight regions of "LSSVCPL2" plans: not bytes but the RECIPE that rebuilds them from a raw checkpoint
+    // (lssvc_prepare_weights); their device memory belongs to the engine's cache and is shared between its plans
+    bool has_recipe = false, shared = false;
+    lssvc_prep_spec spec{};
+    int32_t blob = 0;
+    float scalars[4] = {1.f, 1.f, 1.f, 1.f};
 };
 
 struct Fix {
     uint32_t field, region;
     uint64_t offset;
+};
+struct ScalarFix {                       // float at `field` of a struct image = scalars[index] of a recipe region (the 2^-e of its fp16 planes)
+    uint32_t field, region, index;
+};
+
+// a checkpoint handed to the engine (lssvc_engine_load_checkpoint): owned copies of the tensors + the device blobs prepared
+// from them so far, keyed by recipe
+struct Prepared {
+    std::vector<void *> dev;
+    std::vector<int64_t> bytes;
+    float scalars[4];
+};
+struct Checkpoint {
+    std::vector<std::string> names;
+    std::vector<std::vector<float>> data;
+    std::vector<lssvc_tensor> table;
+    std::map<std::string, Prepared> cache;
+    ~Checkpoint() {
+        for (auto &kv : cache)
+            for (void *d : kv.second.dev)
+                if (d) (void)hipFree(d);
+    }
 };
 
 struct Arg {
@@ -57,6 +86,7 @@ struct Arg {
     int64_t i = 0;
     std::vector<unsigned char> blob;     // struct image (pointer fields rebased at load) or an int32 array
     std::vector<Fix> fixes;
+    std::vector<ScalarFix> sfixes;
     void *ptr = nullptr;                 // resolved TAG_PTR
 };
 
@@ -80,6 +110,14 @@ const char *const kFnNames[FN_COUNT] = {
     "lssvc_factorized_quant_bits", "lssvc_gaussian_conditional", "lssvc_entropy_bottleneck", "lssvc_fill_zero", "lssvc_clamp_inplace",
     "lssvc_export_symbols_i16", "lssvc_import_symbols_i16", "lssvc_pad_crop",
     "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__", "__d2h_async__", "__d2h_wait__"};
+
+// argument shapes of every replayed entry point, checked when a plan is loaded (a truncated or mismatched file must be a clean
+// error, not an out-of-bounds pointer): V = lssvc_view image, C / F = conv / ffn descriptor image, P = device pointer or NULL,
+// f / i / l = float / int32 / int64, A = int32 array or NULL, s = the stream slot, w = stream index of a wait
+const char *const kFnArgs[FN_COUNT] = {
+    "w", "Cs", "CPPs", "Fs", "VPPVs", "VVfs", "VVVs", "VVis", "VVVVs", "VVVs", "VVs", "VVfs", "VVVPPVs", "PVs", "VPs", "VVVVVPPs", "VVVAVVVs", "VVPPs",
+    "VPVPPs", "VVVVVPPs", "VPVVPPs", "Pls", "Plffs", "VVAfffiPPPs", "PVPAVs", "VViis",
+    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 struct Table {                           // one entropy_coder.Tables: quantised CDF rows + used lengths + symbol offsets
     std::vector<int32_t> cdfs, sizes, offsets;
@@ -123,7 +161,7 @@ struct Plan {
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto s : side) (void)hipStreamDestroy(s);
         for (auto &r : regions)
-            if (r.ptr) (void)hipFree(r.ptr);
+            if (r.ptr && !r.shared) (void)hipFree(r.ptr);
     }
     int region_index(const char *name, uint32_t kind) const {
         for (size_t i = 0; i < regions.size(); ++i)
@@ -158,15 +196,46 @@ struct Reader {
 
 int bind(Plan &p);
 
-int load_plan(const char *path, Plan &p) {
+// device blobs of one recipe, prepared once per checkpoint
+int prepared_for(Checkpoint &ck, const lssvc_prep_spec &spec, Prepared **out) {
+    std::string key = std::to_string(spec.kind) + "|" + spec.name + "|" + spec.name2 + "|" + std::to_string(spec.flag);
+    for (int i = 0; i < spec.n_splits; ++i) key += "|" + std::to_string(spec.splits[i]);
+    auto it = ck.cache.find(key);
+    if (it == ck.cache.end()) {
+        int32_t nb = 0, dims[8];
+        int64_t bytes[LSSVC_PREP_MAX_BLOBS];
+        Prepared pr{};
+        if (int rc = lssvc_prepare_weights(ck.table.data(), (int32_t)ck.table.size(), &spec, &nb, bytes, pr.scalars, dims, nullptr)) return rc;
+        std::vector<std::vector<unsigned char>> host(nb);
+        void *ptrs[LSSVC_PREP_MAX_BLOBS] = {nullptr};
+        for (int i = 0; i < nb; ++i) {
+            host[i].resize((size_t)(bytes[i] ? bytes[i] : 16));
+            ptrs[i] = host[i].data();
+        }
+        if (int rc = lssvc_prepare_weights(ck.table.data(), (int32_t)ck.table.size(), &spec, &nb, bytes, pr.scalars, dims, ptrs)) return rc;
+        for (int i = 0; i < nb; ++i) {
+            void *d = nullptr;
+            LSSVC_HIP(hipMalloc(&d, bytes[i] ? bytes[i] : 16));
+            pr.dev.push_back(d);
+            pr.bytes.push_back(bytes[i]);
+            LSSVC_HIP(hipMemcpy(d, host[i].data(), bytes[i], hipMemcpyHostToDevice));
+        }
+        it = ck.cache.emplace(key, std::move(pr)).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+int load_plan(const char *path, Plan &p, Checkpoint *ck) {
     FILE *f = fopen(path, "rb");
     LSSVC_CHECK(f != nullptr, "engine: cannot open plan file %s", path);
     std::unique_ptr<FILE, int (*)(FILE *)> closer(f, fclose);
     Reader r{f};
     char magic[8];
     r.bytes(magic, 8);
-    LSSVC_CHECK(r.ok && memcmp(magic, "LSSVCPL1", 8) == 0, "engine: %s is not a frame plan", path);
+    LSSVC_CHECK(r.ok && memcmp(magic, "LSSVCPL2", 8) == 0, "engine: %s is not a frame plan of this format (LSSVCPL2)", path);
     const uint32_t n_regions = r.get<uint32_t>(), n_launches = r.get<uint32_t>();
+    LSSVC_CHECK(r.ok && n_regions <= (1u << 16) && n_launches <= (1u << 20), "engine: corrupt plan (%u regions, %u launches)", n_regions, n_launches);
     p.n_streams = r.get<uint32_t>();
     const uint32_t n_meta = r.get<uint32_t>();
     const uint32_t n_tables = r.get<uint32_t>();
@@ -185,6 +254,20 @@ int load_plan(const char *path, Plan &p) {
         g.nbytes = r.get<uint64_t>();
         for (int k = 0; k < 4; ++k) g.shape[k] = r.get<int64_t>();
         g.name = r.str48();
+        if (g.kind == REGION_WEIGHTS) {
+            g.has_recipe = r.get<uint32_t>() != 0;
+            if (g.has_recipe) {
+                g.spec.kind = r.get<int32_t>();
+                g.blob = r.get<int32_t>();
+                g.spec.n_splits = r.get<int32_t>();
+                for (int k = 0; k < 3; ++k) g.spec.splits[k] = r.get<int32_t>();
+                g.spec.flag = r.get<int32_t>();
+                r.bytes(g.spec.name, sizeof(g.spec.name));
+                r.bytes(g.spec.name2, sizeof(g.spec.name2));
+                g.spec.name[sizeof(g.spec.name) - 1] = g.spec.name2[sizeof(g.spec.name2) - 1] = 0;
+                LSSVC_CHECK(r.ok && g.blob >= 0 && g.blob < LSSVC_PREP_MAX_BLOBS && g.spec.n_splits >= 0 && g.spec.n_splits <= 3, "engine: corrupt plan (weight recipe)");
+            }
+        }
     }
     p.launches.resize(n_launches);
     for (auto &l : p.launches) {
@@ -211,6 +294,15 @@ int load_plan(const char *path, Plan &p) {
                     x.region = r.get<uint32_t>();
                     x.offset = r.get<uint64_t>();
                 }
+                const uint32_t nsfix = r.get<uint32_t>();
+                LSSVC_CHECK(r.ok && nsfix <= 8, "engine: corrupt plan (struct argument)");
+                a.sfixes.resize(nsfix);
+                for (auto &x : a.sfixes) {
+                    x.field = r.get<uint32_t>();
+                    x.region = r.get<uint32_t>();
+                    x.index = r.get<uint32_t>();
+                    LSSVC_CHECK(r.ok && x.index < 4 && x.field + 4 <= len && x.region < n_regions, "engine: corrupt plan (scalar fix)");
+                }
                 break;
             }
             case TAG_F32: a.f = r.get<float>(); break;
@@ -236,6 +328,32 @@ int load_plan(const char *path, Plan &p) {
             for (auto &a : l.args) LSSVC_CHECK(a.tag == TAG_I64, "engine: corrupt plan (host step argument)");
         }
     }
+    for (auto &l : p.launches) {
+        const char *sig = kFnArgs[l.id];
+        if (!sig) continue;                                                   // host steps: int64 arguments, checked above and in host_step
+        LSSVC_CHECK(strlen(sig) == l.args.size(), "engine: corrupt plan (%s with %zu arguments)", l.fn.c_str(), l.args.size());
+        for (size_t i = 0; i < l.args.size(); ++i) {
+            const Arg &a = l.args[i];
+            bool ok = false;
+            switch (sig[i]) {
+            case 'V': ok = a.tag == TAG_STRUCT && a.blob.size() >= sizeof(lssvc_view); break;
+            case 'C': ok = a.tag == TAG_STRUCT && a.blob.size() >= sizeof(lssvc_conv_desc); break;
+            case 'F': ok = a.tag == TAG_STRUCT && a.blob.size() >= sizeof(lssvc_ffn_desc); break;
+            case 'P': ok = a.tag == TAG_PTR || a.tag == TAG_NULL; break;
+            case 'f': ok = a.tag == TAG_F32; break;
+            case 'i': ok = a.tag == TAG_I32; break;
+            case 'l': ok = a.tag == TAG_I64; break;
+            case 'A': ok = a.tag == TAG_NULL || (a.tag == TAG_I32ARRAY && a.blob.size() >= 16); break;
+            case 's': ok = a.tag == TAG_STREAM; break;
+            case 'w': ok = a.tag == TAG_I32 && a.i >= 0 && a.i < (int64_t)p.n_streams; break;
+            }
+            LSSVC_CHECK(ok, "engine: corrupt plan (argument %zu of %s)", i, l.fn.c_str());
+            if (a.tag == TAG_PTR) LSSVC_CHECK(a.region < n_regions && a.offset <= p.regions[a.region].nbytes, "engine: corrupt plan (pointer outside its region in %s)", l.fn.c_str());
+            for (auto &x : a.fixes)
+                LSSVC_CHECK(x.region < n_regions && x.offset <= p.regions[x.region].nbytes && (size_t)x.field + 8 <= a.blob.size(),
+                            "engine: corrupt plan (struct pointer outside its region in %s)", l.fn.c_str());
+        }
+    }
     p.tables.resize(n_tables);
     for (auto &t : p.tables) {
         const uint32_t rows = r.get<uint32_t>(), stride = r.get<uint32_t>();
@@ -256,11 +374,23 @@ int load_plan(const char *path, Plan &p) {
     // ---- regions: allocate, upload the weights (payloads follow the launch list, 256-byte aligned, in region order)
     std::vector<unsigned char> host;
     for (auto &g : p.regions) {
+        if (g.kind == REGION_WEIGHTS && g.has_recipe) {        // rebuilt from the caller's checkpoint, shared between this engine's plans
+            LSSVC_CHECK(ck != nullptr, "engine: %s refers to checkpoint tensors ('%s'): call lssvc_engine_load_checkpoint for this model first", path, g.spec.name);
+            Prepared *pr = nullptr;
+            if (int rc = prepared_for(*ck, g.spec, &pr)) return rc;
+            LSSVC_CHECK((size_t)g.blob < pr->dev.size() && (uint64_t)pr->bytes[g.blob] == g.nbytes,
+                        "engine: layer '%s' of the checkpoint does not have the shape %s was compiled for (%llu bytes expected, %lld prepared)", g.spec.name, path,
+                        (unsigned long long)g.nbytes, (size_t)g.blob < pr->bytes.size() ? (long long)pr->bytes[g.blob] : -1LL);
+            g.ptr = pr->dev[g.blob];
+            g.shared = true;
+            memcpy(g.scalars, pr->scalars, sizeof(g.scalars));
+            continue;
+        }
         LSSVC_HIP(hipMalloc(&g.ptr, g.nbytes ? g.nbytes : 16));
         if (g.kind == REGION_SCRATCH) LSSVC_HIP(hipMemset(g.ptr, 0, g.nbytes));
         if (g.kind == REGION_WEIGHTS) {
             const long pos = ftell(f);
-            fseek(f, (256 - pos % 256) % 256, SEEK_CUR);
+            LSSVC_CHECK(pos >= 0 && fseek(f, (256 - pos % 256) % 256, SEEK_CUR) == 0, "engine: cannot seek in %s", path);
             host.resize(g.nbytes);
             r.bytes(host.data(), g.nbytes);
             LSSVC_CHECK(r.ok, "engine: truncated plan file %s (weights)", path);
@@ -300,6 +430,11 @@ int bind(Plan &p) {
                                 "engine: unbound region %u", x.region);
                     void *q = static_cast<char *>(p.regions[x.region].ptr) + x.offset;
                     memcpy(a.blob.data() + x.field, &q, 8);
+                }
+                for (auto &x : a.sfixes) {
+                    const Region &g = p.regions[x.region];
+                    LSSVC_CHECK(g.has_recipe, "engine: scalar fix on a region without a recipe");
+                    memcpy(a.blob.data() + x.field, &g.scalars[x.index], 4);
                 }
             }
         }
@@ -465,9 +600,11 @@ struct Engine {
     hipStream_t own = nullptr;           // frames run here when the caller passes stream NULL (the null stream cannot be captured)
     std::unique_ptr<Plan> intra, first_p, steady_p;
     std::unique_ptr<Plan> i_enc, i_dec, p1_enc, p1_dec, p_enc, p_dec;      // write_stream = 1 halves
+    std::unique_ptr<Checkpoint> ckpt[2];                                    // [0] IntraSS, [1] LSSVC: raw tensors + prepared device weights
     ~Engine() {
         intra.reset(), first_p.reset(), steady_p.reset();
         i_enc.reset(), i_dec.reset(), p1_enc.reset(), p1_dec.reset(), p_enc.reset(), p_dec.reset();
+        ckpt[0].reset(), ckpt[1].reset();
         if (own) (void)hipStreamDestroy(own);
     }
     hipStream_t stream(void *s) const { return s ? (hipStream_t)s : own; }
@@ -494,7 +631,10 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
             LSSVC_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             const int rc = replay(p, st);
             const hipError_t ce = hipStreamEndCapture(st, &graph);
-            if (rc) return rc;
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
             LSSVC_CHECK(ce == hipSuccess && graph, "engine: hipStreamEndCapture: %s", hipGetErrorString(ce));
             const hipError_t ie = hipGraphInstantiate(&p.exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
@@ -605,11 +745,42 @@ extern "C" void *lssvc_engine_create(int32_t device) {
 
 extern "C" void lssvc_engine_destroy(void *h) { delete static_cast<Engine *>(h); }
 
-static int load_into(std::unique_ptr<Plan> &slot, const char *path, const char *want_a, const char *want_b) {
+static int load_into(Engine *eng, std::unique_ptr<Plan> &slot, const char *path, const char *want_a, const char *want_b) {
     std::unique_ptr<Plan> p(new Plan());
-    if (int e = load_plan(path, *p)) return e;
+    const bool intra_model = want_a[0] == 'i';                  // "iframe*" plans run IntraSS, "pframe*" plans LSSVC
+    if (int e = load_plan(path, *p, eng->ckpt[intra_model ? 0 : 1].get())) return e;
     LSSVC_CHECK(p->kind == want_a || (want_b && p->kind == want_b), "engine: %s holds a '%s' plan", path, p->kind.c_str());
     slot = std::move(p);
+    return 0;
+}
+
+extern "C" int lssvc_engine_load_checkpoint(void *h, int32_t model, const lssvc_tensor *tensors, int32_t n) {
+    LSSVC_CHECK(h && tensors && n > 0 && (model == 0 || model == 1), "engine_load_checkpoint: bad arguments (model 0 = IntraSS, 1 = LSSVC)");
+    Engine *e = static_cast<Engine *>(h);
+    LSSVC_CHECK(!(model == 0 ? (e->intra || e->i_enc || e->i_dec) : (e->first_p || e->steady_p || e->p1_enc || e->p1_dec || e->p_enc || e->p_dec)),
+                "engine_load_checkpoint: plans of this model are already loaded with another checkpoint");
+    LSSVC_HIP(hipSetDevice(e->device));
+    std::unique_ptr<Checkpoint> ck(new Checkpoint());
+    ck->names.reserve(n), ck->data.reserve(n), ck->table.reserve(n);
+    for (int32_t i = 0; i < n; ++i) {
+        const lssvc_tensor &t = tensors[i];
+        LSSVC_CHECK(t.name && t.data && t.ndim >= 0 && t.ndim <= 4, "engine_load_checkpoint: bad tensor %d", i);
+        int64_t numel = 1;
+        for (int d = 0; d < t.ndim; ++d) {
+            LSSVC_CHECK(t.shape[d] >= 0 && t.shape[d] < (1LL << 31), "engine_load_checkpoint: bad shape of '%s'", t.name);
+            numel *= t.shape[d];
+        }
+        const char *nm = strncmp(t.name, "module.", 7) == 0 ? t.name + 7 : t.name;       // IntraSS.py:193-198, LSSVC_net.py:141-149
+        ck->names.emplace_back(nm);
+        ck->data.emplace_back(t.data, t.data + numel);
+    }
+    for (int32_t i = 0; i < n; ++i) {
+        lssvc_tensor t = tensors[i];
+        t.name = ck->names[i].c_str();
+        t.data = ck->data[i].data();
+        ck->table.push_back(t);
+    }
+    e->ckpt[model] = std::move(ck);
     return 0;
 }
 
@@ -617,15 +788,15 @@ extern "C" int lssvc_engine_load_intra(void *h, const char *iframe_plan) {
     LSSVC_CHECK(h && iframe_plan, "engine_load_intra: bad arguments");
     Engine *e = static_cast<Engine *>(h);
     LSSVC_HIP(hipSetDevice(e->device));
-    return load_into(e->intra, iframe_plan, "iframe", nullptr);
+    return load_into(e, e->intra, iframe_plan, "iframe", nullptr);
 }
 
 extern "C" int lssvc_engine_load_inter(void *h, const char *first_p_plan, const char *steady_p_plan) {
     LSSVC_CHECK(h && first_p_plan && steady_p_plan, "engine_load_inter: bad arguments");
     Engine *e = static_cast<Engine *>(h);
     LSSVC_HIP(hipSetDevice(e->device));
-    if (int rc = load_into(e->first_p, first_p_plan, "pframe_first", nullptr)) return rc;
-    return load_into(e->steady_p, steady_p_plan, "pframe", nullptr);
+    if (int rc = load_into(e, e->first_p, first_p_plan, "pframe_first", nullptr)) return rc;
+    return load_into(e, e->steady_p, steady_p_plan, "pframe", nullptr);
 }
 
 extern "C" int lssvc_engine_set_scale(void *h, float scale, int32_t H, int32_t W) {
@@ -743,7 +914,7 @@ extern "C" int lssvc_engine_load_stream(void *h, const char *iframe_enc, const c
         {&e->p1_dec, first_p_dec, "pframe_first_dec"}, {&e->p_enc, steady_p_enc, "pframe_enc"}, {&e->p_dec, steady_p_dec, "pframe_dec"}};
     for (auto &t : todo)
         if (t.path)
-            if (int rc = load_into(*t.slot, t.path, t.kind, nullptr)) return rc;
+            if (int rc = load_into(e, *t.slot, t.path, t.kind, nullptr)) return rc;
     return 0;
 }
 

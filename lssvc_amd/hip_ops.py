@@ -57,8 +57,11 @@ def stream_ptr():
 # and their per-chain order are unchanged, so results are bit-identical to the single-stream order.
 #
 # Memory: PyTorch's caching allocator recycles a freed block for the next allocation on the block's OWN stream, which is
-# only safe if every other stream that touched the block has been joined since. Every buffer touched by a launch inside
-# a branch is therefore kept alive until the Fork is closed (end of the frame body, after all joins).
+# only safe if every other stream that touched the block has been joined since; the plan compiler's arena hands a freed
+# block to whichever stream allocates next. Every buffer touched by a launch inside branch i is therefore kept alive until
+# branch i is JOINED: from then on the joining stream has waited for the branch, and every later allocation is either on
+# that stream or inside a branch context, whose entry waits for that stream again. (Rounds 2-3 kept them to the end of the
+# frame body, which made a P-frame plan's arena 17.6 GB at 1080p.)
 MULTI_STREAM = _os.environ.get("LSSVC_STREAMS", "1") == "1"
 import threading as _threading
 
@@ -86,7 +89,7 @@ class _Branch:
                 PLAN_RECORDER.wait(s.cuda_stream, torch.cuda.current_stream().cuda_stream)
             self.ctx = torch.cuda.stream(s)
             self.ctx.__enter__()
-            _TLS.keep = f.keep
+            _TLS.keep = f.keep.setdefault(self.i, [])
             f.open.add(self.i)
         return self
 
@@ -105,7 +108,7 @@ class Fork:
 
     def __init__(self, device, enabled=None, n=3):
         self.enabled = MULTI_STREAM if enabled is None else bool(enabled)
-        self.keep, self.open = [], set()
+        self.keep, self.open = {}, set()          # keep: branch index -> buffers its launches have touched since its last join
         if self.enabled:
             main = torch.cuda.current_stream(device)
             key = (device.index, n, main.cuda_stream if not torch.cuda.is_current_stream_capturing() else "capture")
@@ -117,11 +120,13 @@ class Fork:
         return _Branch(self, i)
 
     def join(self, i):
+        assert _TLS.keep is None, "join from the forking stream, not from inside a branch"     # (the release below relies on it)
         if self.enabled and i in self.open:
             torch.cuda.current_stream().wait_stream(self.streams[i])
             if PLAN_RECORDER is not None:
                 PLAN_RECORDER.wait(torch.cuda.current_stream().cuda_stream, self.streams[i].cuda_stream)
             self.open.discard(i)
+            self.keep.pop(i, None)                 # the joining stream has waited for the branch: its buffers may be recycled
 
     def close(self):
         for i in sorted(self.open):
@@ -202,7 +207,7 @@ class T:
     def v(self):
         k = _TLS.keep
         if k is not None:
-            k.append(self.buf)              # touched by a side-stream launch: alive until the frame's Fork closes
+            k.append(self.buf)              # touched by a side-stream launch: alive until that branch is joined
         return self._v
 
     @property

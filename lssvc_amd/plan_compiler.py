@@ -26,7 +26,7 @@ import torch
 from . import _lib
 from . import hip_ops as ops
 
-MAGIC = b"LSSVCPL1"
+MAGIC = b"LSSVCPL2"       # 2: weight regions carry the recipe that rebuilds them from a raw checkpoint, structs carry scalar fixes
 # host steps of the write_stream = 1 plans, stored in the launch list where the front end performed them (names start with "__")
 HOST_D2H, HOST_H2D, HOST_ENCODE, HOST_FLUSH, HOST_SET_STREAM, HOST_DECODE, HOST_DECODE_CH, HOST_D2H_ASYNC, HOST_D2H_WAIT = (
     "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__", "__d2h_async__", "__d2h_wait__")
@@ -87,6 +87,11 @@ def _pointer_fields(ctype, base=0):
 
 
 _PTR_FIELDS = {}
+# (float field, pointer field) pairs of the launch descriptors whose float is a by-product of preparing the pointer's weights
+_SCALAR_FIELDS = {"ConvDesc": (("weight16_unscale", "weight16"),),
+                  "FfnDesc": (("pre_unscale", "pre_w16"), ("w1_unscale", "w1_16"), ("w2_unscale", "w2_16"))}
+# (recipe kind, blob index) -> index into the recipe's scalars (include/lssvc_hip.h: lssvc_prepare_weights)
+_SCALAR_OF_BLOB = {(_lib.PREP_CONV_F16X3, 0): 0, (_lib.PREP_GDN, 2): 0, (_lib.PREP_FFN_F16X3, 0): 0, (_lib.PREP_FFN_F16X3, 1): 1, (_lib.PREP_FFN_F16X3, 4): 2}
 
 
 class Recorder:
@@ -122,12 +127,12 @@ class Recorder:
         for i, r in enumerate(self.regions):
             if r["ptr"] <= p < r["ptr"] + max(r["nbytes"], 1):
                 return i, p - r["ptr"]
-        for ws in self.weight_stores:                      # a prepared weight tensor (registered by WeightStore._dev)
+        for ws in self.weight_stores:                      # a prepared weight tensor (registered by WeightStore.prepare / _dev)
             for ptr, (nbytes, host) in ws.regions.items():
                 if ptr <= p < ptr + max(nbytes, 1):
                     if ptr not in self._weight_regions:
                         self.regions.append({"kind": REGION_WEIGHTS, "name": "w%d" % len(self._weight_regions), "ptr": ptr, "nbytes": nbytes,
-                                             "data": host})
+                                             "data": host, "recipe": ws.recipes.get(ptr)})
                         self._weight_regions[ptr] = len(self.regions) - 1
                     return self._weight_regions[ptr], p - ptr
         raise RuntimeError("launch uses device memory at 0x%x that is neither arena, weights, scratch nor a declared input/output" % p)
@@ -179,7 +184,18 @@ class Recorder:
                     if p:
                         fixes.append((off,) + self._resolve(p))
                         struct.pack_into("<Q", blob, off, 0)
-                enc.append((TAG_STRUCT, bytes(blob), fixes))
+                # floats that are a function of the CHECKPOINT (the 2^-e of a layer's fp16 weight planes): the runtime patches
+                # them from the recipe of the weight region the paired pointer field resolves to
+                sfixes = []
+                for f_scalar, f_ptr in _SCALAR_FIELDS.get(st.__name__, ()):
+                    p = getattr(obj, f_ptr)
+                    if p:
+                        reg, _ = self._resolve(int(p))
+                        recipe = self.regions[reg].get("recipe")
+                        if recipe is not None:
+                            idx = _SCALAR_OF_BLOB[(recipe[0][0], recipe[1])]
+                            sfixes.append((getattr(st, f_scalar).offset, reg, idx))
+                enc.append((TAG_STRUCT, bytes(blob), fixes, sfixes))
         return stream, enc
 
     def __enter__(self):
@@ -221,10 +237,22 @@ class Recorder:
         out += s48(kind)
         for name, v in meta:
             out += s48(name) + struct.pack("<q", int(v))
+        def s120(x):
+            b = x.encode()
+            assert len(b) < 120, x
+            return b + b"\0" * (120 - len(b))
         for r in self.regions:
             nbytes = self.arena.peak if r["kind"] == REGION_ARENA else r["nbytes"]
             shape = list(r.get("shape", ())) + [0] * 4
             out += struct.pack("<IQ4q", r["kind"], nbytes, *shape[:4]) + s48(r["name"])
+            if r["kind"] == REGION_WEIGHTS:
+                rec = r.get("recipe")
+                if rec is None:
+                    out += struct.pack("<I", 0)                 # no recipe: the bytes follow the launch list (tables' medians)
+                else:
+                    (kind, name, name2, splits, flag), blob = rec
+                    sp = list(splits) + [0] * 3
+                    out += struct.pack("<I6i", 1, kind, blob, len(splits), sp[0], sp[1], sp[2]) + struct.pack("<i", flag) + s120(name) + s120(name2)
         for name, stream, args in self.launches:
             out += s48(name) + struct.pack("<2I", stream, len(args))
             for a in args:
@@ -236,6 +264,9 @@ class Recorder:
                     out += struct.pack("<2I", len(a[1]), len(a[2])) + a[1] + b"\0" * (-len(a[1]) % 8)
                     for off, reg, roff in a[2]:
                         out += struct.pack("<2IQ", off, reg, roff)
+                    out += struct.pack("<I", len(a[3]))
+                    for off, reg, idx in a[3]:
+                        out += struct.pack("<3I", off, reg, idx)
                 elif tag == TAG_F32:
                     out += struct.pack("<f", a[1])
                 elif tag == TAG_I32:
@@ -248,12 +279,14 @@ class Recorder:
             out += struct.pack("<2I", t.cdfs.shape[0], t.cdfs.shape[1]) + t.cdfs.tobytes() + t.sizes.tobytes() + t.offsets.tobytes()
         with open(path, "wb") as f:
             f.write(out)
-            for r in self.regions:                              # weight payloads, in region order, 256-byte aligned
-                if r["kind"] == REGION_WEIGHTS:
+            for r in self.regions:                              # payloads of the weight regions without a recipe, in region order, 256-byte aligned
+                if r["kind"] == REGION_WEIGHTS and r.get("recipe") is None:
                     pad = -f.tell() % 256
                     f.write(b"\0" * pad)
                     f.write(r["data"].contiguous().cpu().numpy().tobytes())
         return {"launches": len(self.launches), "regions": len(self.regions), "arena_bytes": self.arena.peak, "streams": len(self.streams),
+                "weight_recipes": sum(1 for r in self.regions if r["kind"] == REGION_WEIGHTS and r.get("recipe") is not None),
+                "embedded_weight_bytes": sum(r["nbytes"] for r in self.regions if r["kind"] == REGION_WEIGHTS and r.get("recipe") is None),
                 "host_steps": sum(1 for n, _, _ in self.launches if n.startswith("__") and n != FN_WAIT), "tables": len(self.tables)}
 
 

@@ -4,8 +4,11 @@
  * back by the caller after clamping the two reconstructions to [0, 1]. All buffers here are host memory (the engine accepts
  * host or device pointers).
  *
- *   engine_demo <iframe.plan> <first_p.plan> <steady_p.plan> <case.bin> <out.bin>
+ *   engine_demo <intra.ckpt> <inter.ckpt> <iframe.plan> <first_p.plan> <steady_p.plan> <case.bin> <out.bin>
  *
+ * *.ckpt: the two RAW checkpoints (tests/ckpt_blob.h: the reference's state dicts dumped tensor by tensor, OIHW fp32, no
+ *         re-layout); the engine prepares its device weights from them (lssvc_engine_load_checkpoint) and the plan files hold
+ *         launches only.
  * case.bin: int32 n_frames, H, W, h, w; float scale; then per frame x_bl (3*h*w floats) and x_el (3*H*W floats), NCHW.
  * out.bin:  per frame: double bit_bl, bit_el; then recon_bl (3hw), recon_el (3HW), feature_el (Cf*H*W, Cf = 64 for the
  *           I-frame, 48 for P-frames), and for P-frames feature_bl (64hw), mv_hat (2HW), warp_frame (3HW); un-clamped.
@@ -15,6 +18,7 @@
 #include <string.h>
 
 #include "lssvc_hip.h"
+#include "ckpt_blob.h"
 
 static void die(const char *what) {
     fprintf(stderr, "engine_demo: %s: %s\n", what, lssvc_last_error());
@@ -35,10 +39,12 @@ static void clamp01(float *x, size_t n) {
 }
 
 int main(int argc, char **argv) {
-    if (argc != 6) {
-        fprintf(stderr, "usage: engine_demo <iframe.plan> <first_p.plan> <steady_p.plan> <case.bin> <out.bin>\n");
+    if (argc != 8) {
+        fprintf(stderr, "usage: engine_demo <intra.ckpt> <inter.ckpt> <iframe.plan> <first_p.plan> <steady_p.plan> <case.bin> <out.bin>\n");
         return 2;
     }
+    const char *ckpt_i = argv[1], *ckpt_p = argv[2];
+    argv += 2;
     FILE *in = fopen(argv[4], "rb"), *out = fopen(argv[5], "wb");
     if (!in || !out) {
         fprintf(stderr, "engine_demo: cannot open %s / %s\n", argv[4], argv[5]);
@@ -52,6 +58,18 @@ int main(int argc, char **argv) {
 
     void *eng = lssvc_engine_create(0);
     if (!eng) die("engine_create");
+    {   /* the checkpoints first: plans name their weights by layer, the bytes come from here */
+        int32_t n_i = 0, n_p = 0;
+        lssvc_tensor *sd_i = read_checkpoint_blob(ckpt_i, &n_i);
+        if (lssvc_engine_load_checkpoint(eng, 0, sd_i, n_i)) die("load_checkpoint(IntraSS)");
+        free_checkpoint_blob(sd_i, n_i);                         /* the engine keeps its own copy */
+        if (n_frames > 1) {
+            lssvc_tensor *sd_p = read_checkpoint_blob(ckpt_p, &n_p);
+            if (lssvc_engine_load_checkpoint(eng, 1, sd_p, n_p)) die("load_checkpoint(LSSVC)");
+            free_checkpoint_blob(sd_p, n_p);
+        }
+        printf("checkpoints: %d + %d tensors\n", n_i, n_p);
+    }
     if (lssvc_engine_load_intra(eng, argv[1])) die("load_intra");
     if (n_frames > 1 && lssvc_engine_load_inter(eng, argv[2], argv[3])) die("load_inter");
     if (lssvc_engine_set_scale(eng, scale, H, W)) die("set_scale");

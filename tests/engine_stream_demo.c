@@ -10,12 +10,16 @@
  *   engine_stream_demo dec <dir> <case.bin>   DECODER: loads <dir>/{i,p1,p}_dec.plan, reads only the header of case.bin (frame
  *        count and sizes) and the .bin files, reconstructs every frame, writes <dir>/dec.out in the same layout.
  *
+ * Both roles first read <dir>/intra.ckpt and <dir>/inter.ckpt, the two RAW checkpoints (tests/ckpt_blob.h), and hand them to
+ * lssvc_engine_load_checkpoint: the plan files hold launches, host steps and CDF tables; the network weights come from the caller.
+ *
  * case.bin: int32 n_frames, H, W, h, w; float scale; then per frame x_bl (3*h*w floats) and x_el (3*H*W floats), NCHW. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "lssvc_hip.h"
+#include "ckpt_blob.h"
 
 static void die(const char *what) {
     fprintf(stderr, "engine_stream_demo: %s: %s\n", what, lssvc_last_error());
@@ -75,6 +79,16 @@ int main(int argc, char **argv) {
 
     void *eng = lssvc_engine_create(0);
     if (!eng) die("engine_create");
+    {
+        static const char *const ck[2] = {"intra.ckpt", "inter.ckpt"};
+        for (int m = 0; m < (n_frames > 1 ? 2 : 1); ++m) {
+            int32_t n = 0;
+            path_of(p0, sizeof p0, dir, ck[m]);
+            lssvc_tensor *sd = read_checkpoint_blob(p0, &n);
+            if (lssvc_engine_load_checkpoint(eng, m, sd, n)) die("load_checkpoint");
+            free_checkpoint_blob(sd, n);
+        }
+    }
     path_of(p0, sizeof p0, dir, encoder ? "i_enc.plan" : "i_dec.plan");
     path_of(p1, sizeof p1, dir, encoder ? "p1_enc.plan" : "p1_dec.plan");
     path_of(p2, sizeof p2, dir, encoder ? "p_enc.plan" : "p_dec.plan");

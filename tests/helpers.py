@@ -166,3 +166,18 @@ def decode_from_symbols(syms, H, W, h, w, t, inet, pnet, dpb):
     return {"dpb": {"ref_frame_bl": bl["recon"].to_nchw(), "ref_feature_bl": bl["feature"].to_nchw(),
                     "ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()},
             "mv_hat": mv_hat.to_nchw(), "warp_frame": warp_frame.to_nchw()}
+
+
+def write_checkpoint_blob(sd, path):
+    """A state dict as a raw checkpoint file for the C demo programs (tests/ckpt_blob.h): every floating tensor as it is
+    (OIHW fp32, the reference's keys), no re-layout."""
+    import struct
+    items = [(k, v.detach().cpu().float().contiguous()) for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point() and v.dim() <= 4]
+    with open(path, "wb") as f:
+        f.write(b"LSSVCCK1" + struct.pack("<i", len(items)))
+        for k, v in items:
+            name = k.encode()
+            shape = list(v.shape) + [1] * (4 - v.dim())
+            f.write(struct.pack("<i", len(name)) + name + struct.pack("<i4q", v.dim(), *shape))
+            f.write(v.numpy().tobytes())
+    return len(items)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_case
+from helpers import load_case, write_checkpoint_blob
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -59,6 +59,13 @@ def test_c_program_codes_a_gop_through_compiled_plans(tmp_path):
     info_2, _ = plan_compiler.compile_pframe(pnet, x_bl[2], x_el[2], dpbs[1], plans[2])
     print("plans:", info_i, info_1, info_2)
     assert info_1["streams"] >= 2 and info_2["launches"] > 300       # side-stream branches are part of the P plans
+    # a plan holds launches only: every weight tensor is a recipe over the raw checkpoint, and the file is small
+    for info, path in ((info_i, plans[0]), (info_1, plans[1]), (info_2, plans[2])):
+        assert info["weight_recipes"] > 50 and info["embedded_weight_bytes"] == 0, info
+        assert os.path.getsize(path) <= 5 * 2 ** 20, (path, os.path.getsize(path))
+    ckpts = [str(tmp_path / "intra.ckpt"), str(tmp_path / "inter.ckpt")]
+    write_checkpoint_blob(synth_state_dict("intra_ss", m["seed"], m["gain"]), ckpts[0])
+    write_checkpoint_blob(synth_state_dict("lssvc_extend", m["seed"], m["gain"]), ckpts[1])
 
     # ---- the C program, in its own process
     case, outp, exe = str(tmp_path / "case.bin"), str(tmp_path / "out.bin"), str(tmp_path / "engine_demo")
@@ -72,7 +79,7 @@ def test_c_program_codes_a_gop_through_compiled_plans(tmp_path):
                            "-L", libdir, "-llssvc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     env = dict(os.environ)
     env.pop("LD_PRELOAD", None)
-    res = subprocess.run([exe] + plans + [case, outp], capture_output=True, text=True, env=env, timeout=600)
+    res = subprocess.run([exe] + ckpts + plans + [case, outp], capture_output=True, text=True, env=env, timeout=600)
     print(res.stdout, res.stderr)
     assert res.returncode == 0, res.stderr
 
@@ -150,6 +157,10 @@ def test_c_programs_write_and_read_real_bitstreams(tmp_path):
     e1, d1, s_1 = plan_compiler.compile_pframe_stream(pnet, x_bl[1], x_el[1], dpbs[0], str(d / "p1_enc.plan"), str(d / "p1_dec.plan"))
     e2, d2, s_2 = plan_compiler.compile_pframe_stream(pnet, x_bl[2], x_el[2], dpbs[1], str(d / "p_enc.plan"), str(d / "p_dec.plan"))
     print("stream plans:", ie, idc, e1, d1, e2, d2)
+    write_checkpoint_blob(synth_state_dict("intra_ss", m["seed"], m["gain"]), str(d / "intra.ckpt"))
+    write_checkpoint_blob(synth_state_dict("lssvc_extend", m["seed"], m["gain"]), str(d / "inter.ckpt"))
+    for info in (ie, idc, e1, d1, e2, d2):                        # what a stream plan still embeds: the bottleneck medians of update()'s tables
+        assert info["weight_recipes"] > 20 and info["embedded_weight_bytes"] <= 4096, info
     assert ie["host_steps"] >= 8 and d2["host_steps"] >= 20 and e2["tables"] >= 3
     assert len(s_i) == 4 and len(s_1) == 2 and len(s_2) == 2
 
@@ -219,6 +230,10 @@ def test_plan_with_inter_layer_padding_replays_through_the_engine(tmp_path):
     eng = lib.lssvc_engine_create(0)
     assert eng
     try:
+        assert lib.lssvc_engine_load_intra(eng, path.encode()) != 0            # no checkpoint yet: a clean error
+        assert b"lssvc_engine_load_checkpoint" in lib.lssvc_last_error()
+        table, n = inet.W._ckpt()                                              # the raw tensors, as the library takes them
+        _lib.check(lib.lssvc_engine_load_checkpoint(eng, 0, table, n))
         _lib.check(lib.lssvc_engine_load_intra(eng, path.encode()))
         _lib.check(lib.lssvc_engine_set_scale(eng, C.c_float(m["scale"]), H, W))
         v = C.c_int64()

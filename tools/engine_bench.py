@@ -77,6 +77,9 @@ def main():
     torch.cuda.empty_cache()
 
     eng = C.c_void_p(lib.lssvc_engine_create(0))
+    for model, net in ((0, inet), (1, pnet)):                      # the raw checkpoints first: plans hold launches only
+        table, n = net.W._ckpt()
+        check(lib.lssvc_engine_load_checkpoint(eng, model, table, n))
     check(lib.lssvc_engine_load_intra(eng, paths[0].encode()))
     check(lib.lssvc_engine_load_inter(eng, paths[1].encode(), paths[2].encode()))
     check(lib.lssvc_engine_set_scale(eng, 2.0, H, W))

@@ -70,6 +70,9 @@ def main():
     torch.cuda.empty_cache()
 
     eng = C.c_void_p(lib.lssvc_engine_create(0))
+    for model, net in ((0, inet), (1, pnet)):                      # the raw checkpoints first: plans hold launches only
+        table, n = net.W._ckpt()
+        check(lib.lssvc_engine_load_checkpoint(eng, model, table, n))
     check(lib.lssvc_engine_load_stream(eng, *[paths[k].encode() for k in names]))
     check(lib.lssvc_engine_set_scale(eng, 2.0, H, W))
     P = lambda t: C.c_void_p(t.data_ptr())
