@@ -52,6 +52,17 @@ struct P3Geom {
     static constexpr int NPROD = kP3ProducerThreads / 64;
     static constexpr int NDMA = (W_INSTR + NPROD - 1) / NPROD;
     static constexpr int LDS_BYTES = 2 * (2 * PATCH_HALFS + 2 * W_HALFS) * 2;      // + the bias vector (launch_p3)
+    // ---- STAGE variant (staged epilogue, see the kernel): the whole 160 KB, laid out [patch 0][weights 0][F][weights 1][patch 1][tail]
+    // so that either operand buffer pair plus the free middle F is ONE contiguous run the finished tile can be parked in
+    static constexpr int PB = 2 * PATCH_HALFS * 2, WB = 2 * W_HALFS * 2;          // bytes of one patch / weight buffer (both planes)
+    static constexpr int BIAS_MAX = 1024, TAIL = BIAS_MAX + 64 + 2 * kP3ProducerThreads * 8;      // bias (Cout <= 256), hand-off slots, trash slots
+    static constexpr int TOTAL = 160 * 1024;
+    static constexpr int FB = (TOTAL - 2 * (PB + WB) - TAIL) / 16 * 16;
+    static constexpr int ROWSET = kP3Consumers * 16 * TM * 4;                     // bytes of one output row of every consumer wave (fp32)
+    static constexpr int SR = (PB + WB + FB) / ROWSET < RPW ? (PB + WB + FB) / ROWSET : RPW;      // rows per wave that fit: 5 of 6 at MF = 4, all 6 below
+    static constexpr int STAGE_BYTES = SR * ROWSET;
+    static constexpr int OFF_P0 = 0, OFF_W0 = PB, OFF_F = PB + WB, OFF_W1 = PB + WB + FB, OFF_P1 = PB + WB + FB + WB, OFF_TAIL = 2 * (PB + WB) + FB;
+    static_assert(FB >= 0 && STAGE_BYTES <= PB + WB + FB && OFF_TAIL + TAIL <= TOTAL, "staged layout");
 };
 
 struct P3Phase {
@@ -62,22 +73,42 @@ struct P3Phase {
 // STAMP: diagnostic build only (LSSVC_CONV_DEBUG & 256; never dispatched otherwise): consumer wave 0..3 of every workgroup
 // accumulates s_memtime deltas of its compute / barrier-wait / epilogue sections and writes them, with the s_memrealtime
 // span of the loop, to the buffer passed in p.gdn_x.p (unused on this path): 8 x int64 per wave.
-template <int MF, bool INACT, bool STAMP = false>
+//
+// STAGE (staged epilogue; round 4): with the epilogue in the consumer waves the matrix pipe idles while they store -- a store
+// instruction blocks the issuing wave until the CU's memory pipeline takes it, and a residual is a full memory round trip with
+// nothing else to do (ablation, 64->64 @1152x1920: 444 us -> 381 us without the epilogue, 48->48: 315 -> 231; with a residual
+// at 576x960: 149 -> 93). Only another WAVE can issue those stores beside the MFMAs, and the only way to hand a wave's
+// accumulators to another wave is LDS, which the operand buffers fill. But when a tile's last phase k has been computed, the
+// operand pair k & 1 is dead until the producers refill it for phase k + 2: in the STAGE layout that pair and the free middle
+// of the LDS are one contiguous run, the consumers park the finished tile there (bias and activation applied, fp32, 16 bytes
+// per lane; SR = 5 of a wave's 6 rows at MF = 4, all 6 at MF <= 3 -- the sixth row of an MF = 4 tile is stored by the consumer
+// as before) and go straight on to the next tile; each producer wave then moves one consumer wave's rows to global memory
+// (adding the residuals, plain or pixel-shuffle store) with the NEXT fill's patch loads already in flight, and only after all
+// four have drained is the pair refilled. Same arithmetic per element as the direct epilogue: results are bit-identical.
+template <int MF, bool INACT, bool STAMP = false, bool STAGE = false>
 __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP p) {
     using G = P3Geom<MF>;
     constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP, NP = G::NP;
+    constexpr int SR = STAGE ? G::SR : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *const patch0 = reinterpret_cast<_Float16 *>(smem);                    // [buf][plane][PH*PW][16]
-    _Float16 *const wts0 = patch0 + 4 * G::PATCH_HALFS;                             // [buf][plane][tap][m][16]
-    float *const bias_s = reinterpret_cast<float *>(wts0 + 4 * G::W_HALFS);         // [m_tiles * TM], zero past M_pad
+    _Float16 *const wts0 = STAGE ? reinterpret_cast<_Float16 *>(smem + G::OFF_W0) : patch0 + 4 * G::PATCH_HALFS;      // [buf][plane][tap][m][16]
+    float *const bias_s = STAGE ? reinterpret_cast<float *>(smem + G::OFF_TAIL) : reinterpret_cast<float *>(wts0 + 4 * G::W_HALFS);   // [m_tiles * TM], zero past M_pad
+    // operand buffer b of the double buffer (STAGE: buffer 1 sits at the far end, see P3Geom)
+    auto patch_buf = [&](int b) { return STAGE ? reinterpret_cast<_Float16 *>(smem + (b ? G::OFF_P1 : G::OFF_P0)) : patch0 + b * 2 * G::PATCH_HALFS; };
+    auto wts_buf = [&](int b) { return STAGE ? reinterpret_cast<_Float16 *>(smem + (b ? G::OFF_W1 : G::OFF_W0)) : wts0 + b * 2 * G::W_HALFS; };
+    // where the tile whose last phase used buffer pair b is parked: pair 0 + F from the front, F + pair 1 up to the back
+    auto stage_off = [&](int b) { return (unsigned)(b ? G::OFF_TAIL - G::STAGE_BYTES : 0); };
     // Hand-off slots: fills finished by each producer wave / phases finished by each consumer wave.
     // One s_barrier per phase makes every consumer wait for the SLOWEST consumer of that phase (stamps: ~600 of 6600
     // cycles); with the counters a consumer only waits for the data of its next phase, which the producers finish a
     // couple of thousand cycles ahead, and only the producers -- which have the slack -- wait for the last consumer.
     // One slot per wave (a shared counter could be satisfied by a fast wave signalling twice while a slow one has not signalled
     // at all): slot = number of fills / phases that wave has completed.
-    int *const sync_s = reinterpret_cast<int *>(bias_s + p.m_tiles * TM);             // [0..3] producer waves: fills done; [4..7] consumer waves: phases done
-    _Float16 *const trash_s = reinterpret_cast<_Float16 *>(sync_s + 8);               // one 8-byte slot per producer lane and plane: staged items past the patch land here
+    int *const sync_s = STAGE ? reinterpret_cast<int *>(smem + G::OFF_TAIL + G::BIAS_MAX)
+                              : reinterpret_cast<int *>(bias_s + p.m_tiles * TM);     // [0..3] producer waves: fills done; [4..7] consumer waves: phases done;
+    //                                                                                   STAGE: [8..11] consumer waves: tiles parked; [12..15] producer waves: tiles drained
+    _Float16 *const trash_s = reinterpret_cast<_Float16 *>(sync_s + (STAGE ? 16 : 8)); // one 8-byte slot per producer lane and plane: staged items past the patch land here
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,7 +127,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     if (n_it == 0) return;
     const int phases_per_tile = p.n_chunks16;
     for (int i = tid; i < p.m_tiles * TM; i += kP3Threads) bias_s[i] = (p.bias && i < p.M_pad) ? p.bias[i] : 0.f;   // visible after barrier (A)
-    if (tid < 8) sync_s[tid] = 0;
+    if (tid < (STAGE ? 16 : 8)) sync_s[tid] = 0;
     // spin until all four slots of a group are >= target (monotonic: every target is reached, and the grid drains, because a
     // fill never waits for a phase that needs it and a phase never waits for a fill that needs it)
     auto wait_for = [&](int *slots, int target) {
@@ -118,6 +149,9 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
 #endif
     };
 
+    // parked tile: [consumer wave][row][pixel column][TM floats], the 16-byte channel quads of a pixel rotated by its column so that
+    // the 8-lane groups of a ds_write_b128 (8 pixel columns, one quad) spread over the banks
+    constexpr int QN = 4 * MF;
     auto tile_origin = [&](int it, int &oy0, int &ox0, int &m0) {
         const int tile = t_begin + kb + it * nb_x;
         const int mt = tile % p.m_tiles, pt = tile / p.m_tiles;
@@ -194,7 +228,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             if (STAMP) ts = __builtin_amdgcn_s_memtime();
             if (ph.it != wgeom_it) weight_geometry(ph.it);
             {
-                unsigned char *dst = reinterpret_cast<unsigned char *>(wts0 + buf * 2 * G::W_HALFS);
+                unsigned char *dst = reinterpret_cast<unsigned char *>(wts_buf(buf));
                 const _Float16 *src0 = w16 + (size_t)ph.k.kc * NTAP * p.M_pad * CK16;
 #pragma unroll
                 for (int t = 0; t < G::NDMA; ++t) {
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         auto store_patch = [&](int buf) {
             long long ts = 0;
             if (STAMP) ts = __builtin_amdgcn_s_memtime();
-            _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;
+            _Float16 *ph_ = patch_buf(buf);
             _Float16 *pl_ = ph_ + G::PATCH_HALFS;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
@@ -264,6 +298,74 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 s_cvt += __builtin_amdgcn_s_memtime() - ts;
             }
         };
+        // STAGE, at a tile boundary: the patch registers are made plain values here (the empty asm reads them, so the compiler
+        // waits for their loads in front of it) -- behind the drain, whose stores are younger than these loads, its wait for
+        // them would also be a wait for the stores' acknowledgements.
+        auto settle_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(preg[i].x), "+v"(preg[i].y), "+v"(preg[i].z), "+v"(preg[i].w));
+        };
+        // STAGE: the rows consumer wave `pw` parked for tile `it` in operand pair b -> global memory (+ residuals; plain or
+        // pixel-shuffle store): conv_epilogue_fast_impl's arithmetic after its lane transposition, element for element. All
+        // residual loads go out first, so that no wait in here names a store.
+        auto drain = [&](int it, int b, auto nres_c) __attribute__((always_inline)) {
+            constexpr int NRES = decltype(nres_c)::value;
+            constexpr int NI = STAGE ? SR * MF : 1;           // 16-byte items per lane: SR rows x 16 pixels x QN quads over 64 lanes
+            constexpr int NPASS = NRES > 1 ? 2 : 1;           // two residuals: in two halves (2 x NI float4 of them do not fit the registers)
+            constexpr int NC = (NI + NPASS - 1) / NPASS;
+            int oy0, ox0, m0;
+            tile_origin(it, oy0, ox0, m0);
+            const unsigned sbase = (unsigned)(size_t)(lds_cfloat_ptr)(const float *)(const void *)smem + stage_off(b) + (unsigned)(pw * SR * 16 * TM * 4);
+            const int oy_w = oy0 + pw * RPW;
+            const bool ps = p.fast_epi == 2;
+            const int cps = p.Cout >> 2;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                float4 rs[NRES > 0 ? NC : 1], rs2[NRES > 1 ? NC : 1];
+                unsigned ooff[NC];                            // element offsets (the host keeps tensors of >= 2^32 elements off this path)
+                unsigned ok = 0;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const int i = pass * NC + j;
+                    if (i >= NI) break;
+                    const int idx = lane + 64 * i;
+                    const int qd = idx % QN, pc = idx / QN, col = pc & 15, r = pc >> 4;
+                    const int oy = oy_w + r, ox = ox0 + col, mt = m0 + 4 * qd;
+                    const bool v = oy < p.Hout && ox < p.Wout && mt < p.Cout;
+                    ok |= v ? (1u << j) : 0u;
+                    const unsigned px = v ? (unsigned)oy * (unsigned)p.Wout + (unsigned)ox : 0u;
+                    const unsigned mtv = v ? (unsigned)mt : 0u;
+                    if (NRES > 0) rs[j] = *reinterpret_cast<const float4 *>(p.res.p + (size_t)(px * (unsigned)p.res.ld + mtv));
+                    if (NRES > 1) rs2[j] = *reinterpret_cast<const float4 *>(p.res2.p + (size_t)(px * (unsigned)p.res2.ld + mtv));
+                    if (ps) {                                 // channel m = q * cps + c goes to sub-pixel q = dy * 2 + dx, channel c
+                        const unsigned q = mtv / (unsigned)cps, c = mtv - q * (unsigned)cps;
+                        ooff[j] = ((2u * (v ? (unsigned)oy : 0u) + (q >> 1)) * (unsigned)p.out.W + 2u * (v ? (unsigned)ox : 0u) + (q & 1u)) * (unsigned)p.out.ld + c;
+                    } else {
+                        ooff[j] = px * (unsigned)p.out.ld + mtv;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const int i = pass * NC + j;
+                    if (i >= NI) break;
+                    const int idx = lane + 64 * i;
+                    const int qd = idx % QN, pc = idx / QN, col = pc & 15, r = pc >> 4;
+                    const unsigned a = sbase + (unsigned)(((r * 16 + col) * TM + ((qd + col) % QN) * 4) * 4);
+                    f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((size_t)a);
+                    if (NRES > 0) v = v + f32x4{rs[j].x, rs[j].y, rs[j].z, rs[j].w};
+                    if (NRES > 1) v = v + f32x4{rs2[j].x, rs2[j].y, rs2[j].z, rs2[j].w};
+                    if ((ok >> j) & 1u) *reinterpret_cast<float4 *>(p.out.p + (size_t)ooff[j]) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        };
+        auto drain_tile = [&](int it, int b) __attribute__((always_inline)) {
+            if constexpr (STAGE) {
+                if (p.debug & 32) return;
+                if (p.res2.p) drain(it, b, std::integral_constant<int, 2>{});
+                else if (p.res.p) drain(it, b, std::integral_constant<int, 1>{});
+                else drain(it, b, std::integral_constant<int, 0>{});
+            }
+        };
 
         // Schedule: fill(k+1) = weights by DMA + patch through registers, while the consumers run phase k. (Requesting the patch
         // of phase k+2 before the buffer of phase k+1 is released -- only the LDS writes need the buffer -- was tried: the
@@ -276,17 +378,43 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         store_patch(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of this wave has landed
         __syncthreads();                                   // (A) phase 0 is in buffer 0
+        int drained = 0;                                   // STAGE: tiles this wave has moved out of the LDS
         for (int k = 0; k + 1 < total; ++k) {              // fill(k+1) while the consumers run phase k
             long long tb = 0;
             if (STAMP) tb = __builtin_amdgcn_s_memtime();
             if (k >= 1) wait_for(sync_s + 4, k);           // buffer (k+1)&1 was read in phase k-1: every consumer has left it
             if (STAMP) s_bar += __builtin_amdgcn_s_memtime() - tb;
             ph = next_phase(ph);
-            stage_weights(ph, (k + 1) & 1);
-            load_patch(ph);
-            store_patch((k + 1) & 1);
+            if (STAGE && k >= 1 && k % phases_per_tile == 0) {
+                // phase k-1 closed a tile: it is parked in the very pair this fill is about to overwrite. Patch loads first (they
+                // only need registers), then wait for the parked rows, convert, drain, and only when all four producer waves
+                // have drained may the DMA and the patch stores touch the pair.
+                load_patch(ph);
+                wait_for(sync_s + 8, drained + 1);
+                settle_patch();
+                drain_tile(drained, (k + 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the parked rows have returned
+                ++drained;
+                signal(sync_s + 12 + pw, drained);
+                wait_for(sync_s + 12, drained);
+                stage_weights(ph, (k + 1) & 1);
+                store_patch((k + 1) & 1);
+            } else {
+                stage_weights(ph, (k + 1) & 1);
+                load_patch(ph);
+                store_patch((k + 1) & 1);
+            }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMA has landed, its LDS stores are done
             signal(sync_s + pw, k + 1);
+        }
+        if (STAGE) {                                       // the tiles parked after the last fill (the last one, two if a tile is one phase)
+            while (drained < n_it) {
+                wait_for(sync_s + 8, drained + 1);
+                drain_tile(drained, ((drained + 1) * phases_per_tile - 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ++drained;
+                signal(sync_s + 12 + pw, drained);
+            }
         }
         if (STAMP && lane == 0 && p.gdn_x.p) {
             long long *o = reinterpret_cast<long long *>(p.gdn_x.p) + ((size_t)gridDim.x * kP3Consumers + (size_t)blockIdx.x * 4 + pw) * 8;
@@ -318,8 +446,8 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     for (int k = 0; k < total; ++k) {
         int fill_seen = 0;                                 // producers' slots as read during the last unit of this phase
         const int buf = k & 1;
-        const _Float16 *ph_ = patch0 + buf * 2 * G::PATCH_HALFS;            // hi plane; the lo plane follows it
-        const _Float16 *wh_ = wts0 + buf * 2 * G::W_HALFS;
+        const _Float16 *ph_ = patch_buf(buf);                               // hi plane; the lo plane follows it
+        const _Float16 *wh_ = wts_buf(buf);
         // The phase as NSTEP x NG units (K step u, row group g of GR rows), software-pipelined and INTERLEAVED by hand.
         // In-kernel stamps: the straightforward loop takes 6.6 k cycles per phase for 336 MFMAs = 5.4 k issue cycles, with
         // the producers idle or not and with the fragment reads prefetched or not -- it is neither LDS latency nor
@@ -451,16 +579,47 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         if (++kt == phases_per_tile) {
             int oy0, ox0, m0;
             tile_origin(it, oy0, ox0, m0);
-            if (!(p.debug & 32)) {
+            const int oy_w = oy0 + wave * RPW;
+            auto pix = [&](int r, int col) {              // pixel index of column col of this wave's row r, -1 outside the image
+                return (ox0 + col < p.Wout && oy_w + r < p.Hout) ? (long long)(oy_w + r) * p.Wout + ox0 + col : -1LL;
+            };
+            // interior: this wave's rows, the tile's 16 columns and its 16*MF channels all lie inside the output
+            const bool interior = oy0 + wave * RPW + RPW <= p.Hout && ox0 + 16 <= p.Wout && m0 + TM <= p.Cout;
+            if constexpr (STAGE) {
+                // Park the tile in the operand pair of the phase just computed (+ the free middle of the LDS): every consumer
+                // must have left that pair (they all read its weights), and the previous tile must be out of the LDS (the two
+                // parking areas share part of the middle; normally long done: its drain ran a whole tile ago).
+                wait_for(sync_s + 4, k + 1);
+                wait_for(sync_s + 12, it);
+                if (!(p.debug & 32)) {
+                    const float us = p.w16_unscale;
+                    const float s_neg = p.act == LSSVC_ACT_LRELU ? p.slope : (p.act == LSSVC_ACT_RELU ? 0.0f : 1.0f);
+                    const bool act = p.act != LSSVC_ACT_NONE;
+                    const unsigned sb = (unsigned)(size_t)(lds_cfloat_ptr)(const float *)(const void *)smem + stage_off(buf) +
+                                        (unsigned)((wave * SR * 16 + li) * TM * 4);
+#pragma unroll
+                    for (int f = 0; f < MF; ++f) {
+                        const f32x4 bv = *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>((lds_cfloat_ptr)bias_s + m0 + f * 16 + 4 * lg);
+                        const unsigned qoff = (unsigned)(((f * 4 + lg + li) % QN) * 16);
+#pragma unroll
+                        for (int r = 0; r < SR; ++r) {
+                            f32x4 v = acc[f][r] * us + bv;                                   // (no contraction: -ffp-contract=off)
+                            if (act) {
+                                const f32x4 n = v * s_neg;
+                                v = f32x4{fmaxf(v[0], n[0]), fmaxf(v[1], n[1]), fmaxf(v[2], n[2]), fmaxf(v[3], n[3])};
+                            }
+                            *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>((size_t)(sb + (unsigned)(r * 16 * TM * 4) + qoff)) = v;
+                        }
+                    }
+                    if constexpr (SR < RPW)                  // the rows that do not fit (one, at MF = 4): stored from here as before
+                        conv_epilogue_fast_f<MF, RPW, true, SR>(p, acc, pix, m0, lg, p.w16_unscale, interior, (lds_cfloat_ptr)bias_s);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the parked rows are in the LDS
+                signal(sync_s + 8 + wave, it + 1);
+            } else if (!(p.debug & 32)) {
                 // ONE pass over the wave's rows, straight from the accumulators: the epilogue issues row r+1's residual loads
                 // before row r's stores, so no wait inside it ever names a store (a second pass would start by waiting for
                 // the first one's stores to be acknowledged: 6 of the 8 thousand cycles per tile this section used to take)
-                const int oy_w = oy0 + wave * RPW;
-                auto pix = [&](int r, int col) {              // pixel index of column col of this wave's row r, -1 outside the image
-                    return (ox0 + col < p.Wout && oy_w + r < p.Hout) ? (long long)(oy_w + r) * p.Wout + ox0 + col : -1LL;
-                };
-                // interior: this wave's rows, the tile's 16 columns and its 16*MF channels all lie inside the output
-                const bool interior = oy0 + wave * RPW + RPW <= p.Hout && ox0 + 16 <= p.Wout && m0 + TM <= p.Cout;
                 conv_epilogue_fast_f<MF, RPW, true>(p, acc, pix, m0, lg, p.w16_unscale, interior,     // the dispatcher only sends p.fast_epi convs here
                                                     (lds_cfloat_ptr)bias_s);
             }
@@ -517,6 +676,16 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
         if (grant_s.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<4, false, true>), lds)) return 1;
         hipLaunchKernelGGL((conv3_f16x3p_kernel<4, false, true>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
         return launch_status("conv2d(f16x3p, stamps)");
+    }
+    // staged epilogue (the kernel's STAGE note): worth it where a tile's output is a large share of its work -- MF >= 3 (MF <= 2
+    // launches are paced by their producers) -- and the bias of every M tile fits the fixed tail of the staged layout
+    auto elems = [](const V &v) { return v.p ? (unsigned long long)v.H * v.W * v.ld : 0ull; };      // the drain addresses with 32-bit element offsets
+    const bool small32 = elems(p.out) < (1ull << 32) && elems(p.res) < (1ull << 32) && elems(p.res2) < (1ull << 32);
+    if (MF >= 3 && option_get(OPT_P3_STAGE) && small32 && (size_t)q.m_tiles * G::TM * sizeof(float) <= (size_t)G::BIAS_MAX) {
+        static LdsGrant grant_g;
+        if (grant_g.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, INACT, false, true>), G::TOTAL)) return 1;
+        hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, INACT, false, true>), dim3((unsigned)blocks), dim3(kP3Threads), G::TOTAL, st, q);
+        return launch_status("conv2d(f16x3p, staged)");
     }
     hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, INACT>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
     return launch_status("conv2d(f16x3p)");

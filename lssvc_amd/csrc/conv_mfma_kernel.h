@@ -79,7 +79,7 @@ typedef __attribute__((address_space(3))) const float *lds_cfloat_ptr;
 // memory) to lane 4 li + lg, so that 4 consecutive lanes hold the 16 channels of one pixel of a fragment; bias and
 // activation are applied before the move (native lane = native channel), residuals are loaded and added and the
 // result stored in the transposed layout. Same arithmetic per element, same results.
-template <int MF, int RPW, bool PS, int RES, bool INTERIOR, bool ACT, bool BIAS_LDS, typename PIXF>      // RES: number of residual operands (0, 1, 2)
+template <int MF, int RPW, bool PS, int RES, bool INTERIOR, bool ACT, bool BIAS_LDS, typename PIXF, int R0 = 0>      // RES: number of residual operands (0, 1, 2); rows R0 .. RPW-1
 __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&acc)[MF][RPW], const PIXF &pixf, int m0,
                                                         int lg, float unscale, lds_cfloat_ptr bias_lds) {
     const float s_neg = p.act == LSSVC_ACT_LRELU ? p.slope : (p.act == LSSVC_ACT_RELU ? 0.0f : 1.0f);
@@ -130,9 +130,9 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
             }
         }
     };
-    load_res(0, rs[0], rs2[0]);
+    load_res(R0, rs[R0 & 1], rs2[R0 & 1]);
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
+    for (int r = R0; r < RPW; ++r) {
         if (r + 1 < RPW) load_res(r + 1, rs[(r + 1) & 1], rs2[(r + 1) & 1]);      // issued before row r's stores (see conv_epilogue_flat)
         const long long px = pixf(r, tcol);
         const size_t opix = (size_t)((INTERIOR || px >= 0) ? px : 0);
@@ -177,7 +177,7 @@ __device__ __forceinline__ void conv_epilogue_fast_impl(const ConvP &p, f32x4 (&
     }
 }
 
-template <int MF, int RPW, bool BIAS_LDS = false, typename PIXF>
+template <int MF, int RPW, bool BIAS_LDS = false, int R0 = 0, typename PIXF>
 __device__ __forceinline__ void conv_epilogue_fast_f(const ConvP &p, f32x4 (&acc)[MF][RPW], const PIXF &pix, int m0,
                                                      int lg, float unscale = 1.0f, bool interior = false,
                                                      lds_cfloat_ptr bias_lds = nullptr) {
@@ -186,10 +186,10 @@ __device__ __forceinline__ void conv_epilogue_fast_f(const ConvP &p, f32x4 (&acc
 #define LSSVC_EPI_CALL(PS_, RES_)                                                                                              \
     do {                                                                                                                       \
         if (interior) {                                                                                                        \
-            if (act) conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, true, BIAS_LDS>(p, acc, pix, m0, lg, unscale, bias_lds);          \
-            else conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, false, BIAS_LDS>(p, acc, pix, m0, lg, unscale, bias_lds);             \
+            if (act) conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, true, BIAS_LDS, PIXF, R0>(p, acc, pix, m0, lg, unscale, bias_lds);  \
+            else conv_epilogue_fast_impl<MF, RPW, PS_, RES_, true, false, BIAS_LDS, PIXF, R0>(p, acc, pix, m0, lg, unscale, bias_lds);     \
         } else {                                                                                                               \
-            conv_epilogue_fast_impl<MF, RPW, PS_, RES_, false, true, BIAS_LDS>(p, acc, pix, m0, lg, unscale, bias_lds);                  \
+            conv_epilogue_fast_impl<MF, RPW, PS_, RES_, false, true, BIAS_LDS, PIXF, R0>(p, acc, pix, m0, lg, unscale, bias_lds);          \
         }                                                                                                                      \
     } while (0)
     if (p.fast_epi == 2) LSSVC_EPI_CALL(true, 0);                            // pixel-shuffle store (never with a residual)

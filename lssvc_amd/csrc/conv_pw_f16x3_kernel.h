@@ -368,9 +368,9 @@ static int launch_pwk_f16x3(const ConvP &p, hipStream_t st) {
 // slice every 8 steps (two barriers), while each wave owns ONE 64-pixel group whose MF x 4 accumulators live in
 // registers across all slices; the X ring prefetch runs straight through the slice boundaries. One group per wave,
 // no persistence: meant for launches with few pixel groups.
-template <int MF, bool MULTI, int RPW = 4>
+template <int MF, bool MULTI, int RPW = 4, int D = 2>
 __global__ __launch_bounds__(256, 2) void conv_pwks_f16x3_kernel(const ConvP p) {
-    constexpr int TM = 16 * MF, D = 2, SLICE_STEPS = 8, SLICE_SLOTS = 2 * SLICE_STEPS;      // (a ring of 4 for the 32-pixel variant measured slower)
+    constexpr int TM = 16 * MF, SLICE_STEPS = 8, SLICE_SLOTS = 2 * SLICE_STEPS;      // D: X steps in flight per wave (register ring)
     extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];     // [hi|lo][slot in slice][TM][16]
     constexpr int plane = SLICE_SLOTS * TM * CK16;
     const int tid = threadIdx.x;
@@ -521,7 +521,14 @@ static int launch_pwks_f16x3(const ConvP &p, hipStream_t st) {
     const long long ngroups = small ? (npix + 31) / 32 : (npix + 63) / 64;
     const long long blocks = ((ngroups + 3) / 4) * q.m_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return fail("conv2d(pwks f16x3): bad grid %lld", blocks);
-    if (small) {
+    static const int ring = getenv("LSSVC_PWKS_RING") ? atoi(getenv("LSSVC_PWKS_RING")) : 2;       // experiment: deeper X prefetch on the small maps
+    if (small && ring == 4) {
+        if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true, 2, 4>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+        else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false, 2, 4>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    } else if (small && ring == 8) {
+        if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true, 2, 8>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+        else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false, 2, 8>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    } else if (small) {
         if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true, 2>), dim3((unsigned)blocks), dim3(256), lds, st, q);
         else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false, 2>), dim3((unsigned)blocks), dim3(256), lds, st, q);
     } else {

@@ -152,6 +152,40 @@ def test_persistent_3x3_is_bit_identical_to_tiled(hip, cins, cout, H, W, in_act,
     assert torch.equal(c, b_)
 
 
+@pytest.mark.parametrize("cins,cout,H,W,in_act,act,residual,shuffle,mf", [c for c in P3_CASES if c[8] >= 3])
+def test_persistent_3x3_staged_epilogue_is_bit_identical(hip, cins, cout, H, W, in_act, act, residual, shuffle, mf):
+    """The staged epilogue (conv3_f16x3p.hip, STAGE: the consumers park the finished tile in the operand buffers they have
+    just consumed and the producer waves store it) against the same kernel with the epilogue in the consumer waves (option
+    p3_stage = 0), on every MF >= 3 shape of the list: partial tiles at the right and bottom edges, 3 M tiles, two- and
+    three-phase tiles (the parking area alternates between the two buffer pairs when a tile has an odd number of phases),
+    residual, pixel-shuffle store. Twice each, so that a hand-off that only sometimes loses a row shows up."""
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, W)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(1, cout, H, W, generator=g) if residual else None
+    name = "s.0" if shuffle else "c"
+    Wt = _W({name + ".weight": w, name + ".bias": b})
+
+    def launch():
+        kw = dict(in_act=in_act, in_slope=0.1, act=act, slope=0.01, residual=nhwc(hip, r) if residual else None)
+        ins = [nhwc(hip, x) for x in xs]
+        return back(hip.subpel(Wt, "s", ins, **kw) if shuffle else hip.conv(Wt, "c", ins, **kw))
+
+    old = _get("p3_stage")
+    try:
+        _set("p3_stage", 0)
+        plain, k0 = _run(hip, "f16x3", launch)
+        _set("p3_stage", 1)
+        staged = [_run(hip, "f16x3", launch)[0] for _ in range(2)]
+    finally:
+        _set("p3_stage", old)
+    assert k0.startswith("conv3_f16x3p_kernel")
+    for s in staged:
+        assert torch.equal(s, plain), (s - plain).abs().max().item()
+
+
 def test_persistent_3x3_small_grids(hip):
     """Grids with fewer than 8 workgroups (tile ranges keyed by blockIdx & 7 left tiles uncomputed): force
     the persistent kernel onto convs with 1..7 tiles and compare with the tiled kernel."""
