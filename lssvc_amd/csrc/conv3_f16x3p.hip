@@ -59,7 +59,8 @@ struct P3Geom {
     static constexpr int TOTAL = 160 * 1024;
     static constexpr int FB = (TOTAL - 2 * (PB + WB) - TAIL) / 16 * 16;
     static constexpr int ROWSET = kP3Consumers * 16 * TM * 4;                     // bytes of one output row of every consumer wave (fp32)
-    static constexpr int SR = (PB + WB + FB) / ROWSET < RPW ? (PB + WB + FB) / ROWSET : RPW;      // rows per wave that fit: 5 of 6 at MF = 4, all 6 below
+    static constexpr int SR_FIT = (PB + WB + FB) / ROWSET < RPW ? (PB + WB + FB) / ROWSET : RPW;   // rows per wave that fit: 5 of 6 at MF = 4, all 6 below
+    static constexpr int SR = (MF == 4 && SR_FIT > 4) ? 4 : SR_FIT;        // (MF = 4: 4, so that a producer lane's 16 items + their residuals stay in registers)
     static constexpr int STAGE_BYTES = SR * ROWSET;
     static constexpr int OFF_P0 = 0, OFF_W0 = PB, OFF_F = PB + WB, OFF_W1 = PB + WB + FB, OFF_P1 = PB + WB + FB + WB, OFF_TAIL = 2 * (PB + WB) + FB;
     static_assert(FB >= 0 && STAGE_BYTES <= PB + WB + FB && OFF_TAIL + TAIL <= TOTAL, "staged layout");
@@ -306,64 +307,109 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(preg[i].x), "+v"(preg[i].y), "+v"(preg[i].z), "+v"(preg[i].w));
         };
         // STAGE: the rows consumer wave `pw` parked for tile `it` in operand pair b -> global memory (+ residuals; plain or
-        // pixel-shuffle store): conv_epilogue_fast_impl's arithmetic after its lane transposition, element for element. All
-        // residual loads go out first, so that no wait in here names a store.
-        auto drain = [&](int it, int b, auto nres_c) __attribute__((always_inline)) {
-            constexpr int NRES = decltype(nres_c)::value;
-            constexpr int NI = STAGE ? SR * MF : 1;           // 16-byte items per lane: SR rows x 16 pixels x QN quads over 64 lanes
-            constexpr int NPASS = NRES > 1 ? 2 : 1;           // two residuals: in two halves (2 x NI float4 of them do not fit the registers)
-            constexpr int NC = (NI + NPASS - 1) / NPASS;
-            int oy0, ox0, m0;
-            tile_origin(it, oy0, ox0, m0);
-            const unsigned sbase = (unsigned)(size_t)(lds_cfloat_ptr)(const float *)(const void *)smem + stage_off(b) + (unsigned)(pw * SR * 16 * TM * 4);
-            const int oy_w = oy0 + pw * RPW;
-            const bool ps = p.fast_epi == 2;
-            const int cps = p.Cout >> 2;
+        // pixel-shuffle store): conv_epilogue_fast_impl's arithmetic after its lane transposition, element for element, in
+        // THREE steps so that nothing the consumers wait for waits for a store:
+        //   drain_prefetch  residual loads (with the next fill's patch loads, before the tile is even parked)
+        //   drain_read      parked rows -> registers, + residual; after it the pair may be overwritten
+        //   drain_store     -> global; issued AFTER the fill has been signalled: loads, stores and the weight
+        //                   DMA share one in-order counter, so a wait for the DMA behind these stores would also wait for their
+        //                   acknowledgement, which takes as long as the burst of all 256 CUs' tiles takes to reach memory
+        constexpr int NI = STAGE ? SR * MF : 1;               // 16-byte items per lane: SR rows x 16 pixels x QN quads over 64 lanes
+        constexpr int NH = (NI + 1) / 2;                      // residuals are held for half of them at a time (registers)
+        f32x4 dv[NI];
+        float4 drs[NH];
+        int d_oy0 = 0, d_ox0 = 0, d_m0 = 0;
+        // (each step recomputes its addresses from an OPAQUE copy of the lane id: the compiler would otherwise keep the 20 pixel
+        // and channel offsets of the prefetch alive for the later steps, ~60 registers that push the producers into scratch)
+        auto opaque_lane = [&]() __attribute__((always_inline)) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            return ln;
+        };
+        auto d_item = [&](int ln, int i, int &qd, int &col, int &r) __attribute__((always_inline)) {
+            const int idx = ln + 64 * i;
+            qd = idx % QN;
+            const int pc = idx / QN;
+            col = pc & 15;
+            r = pc >> 4;
+        };
+        auto d_valid = [&](int qd, int col, int r, unsigned &px, unsigned &mt) __attribute__((always_inline)) {
+            const int oy = d_oy0 + pw * RPW + r, ox = d_ox0 + col, m = d_m0 + 4 * qd;
+            const bool v = oy < p.Hout && ox < p.Wout && m < p.Cout;
+            px = v ? (unsigned)oy * (unsigned)p.Wout + (unsigned)ox : 0u;
+            mt = v ? (unsigned)m : 0u;
+            return v;
+        };
+        // residuals of items [i0, i0 + NH) of `src` -> drs
+        auto d_load_res = [&](const V &src, int i0) __attribute__((always_inline)) {
+            const int ln = opaque_lane();
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                float4 rs[NRES > 0 ? NC : 1], rs2[NRES > 1 ? NC : 1];
-                unsigned ooff[NC];                            // element offsets (the host keeps tensors of >= 2^32 elements off this path)
-                unsigned ok = 0;
+            for (int j = 0; j < NH; ++j) {
+                if (i0 + j >= NI) break;
+                int qd, col, r;
+                unsigned px, mt;
+                d_item(ln, i0 + j, qd, col, r);
+                d_valid(qd, col, r, px, mt);
+                drs[j] = *reinterpret_cast<const float4 *>(src.p + (size_t)(px * (unsigned)src.ld + mt));
+            }
+        };
+        auto d_add_res = [&](int i0) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < NC; ++j) {
-                    const int i = pass * NC + j;
-                    if (i >= NI) break;
-                    const int idx = lane + 64 * i;
-                    const int qd = idx % QN, pc = idx / QN, col = pc & 15, r = pc >> 4;
-                    const int oy = oy_w + r, ox = ox0 + col, mt = m0 + 4 * qd;
-                    const bool v = oy < p.Hout && ox < p.Wout && mt < p.Cout;
-                    ok |= v ? (1u << j) : 0u;
-                    const unsigned px = v ? (unsigned)oy * (unsigned)p.Wout + (unsigned)ox : 0u;
-                    const unsigned mtv = v ? (unsigned)mt : 0u;
-                    if (NRES > 0) rs[j] = *reinterpret_cast<const float4 *>(p.res.p + (size_t)(px * (unsigned)p.res.ld + mtv));
-                    if (NRES > 1) rs2[j] = *reinterpret_cast<const float4 *>(p.res2.p + (size_t)(px * (unsigned)p.res2.ld + mtv));
-                    if (ps) {                                 // channel m = q * cps + c goes to sub-pixel q = dy * 2 + dx, channel c
-                        const unsigned q = mtv / (unsigned)cps, c = mtv - q * (unsigned)cps;
-                        ooff[j] = ((2u * (v ? (unsigned)oy : 0u) + (q >> 1)) * (unsigned)p.out.W + 2u * (v ? (unsigned)ox : 0u) + (q & 1u)) * (unsigned)p.out.ld + c;
-                    } else {
-                        ooff[j] = px * (unsigned)p.out.ld + mtv;
-                    }
-                }
+            for (int j = 0; j < NH; ++j)
+                if (i0 + j < NI) dv[i0 + j] = dv[i0 + j] + f32x4{drs[j].x, drs[j].y, drs[j].z, drs[j].w};
+        };
+        auto drain_prefetch = [&](int it) __attribute__((always_inline)) {
+            if constexpr (STAGE) {
+                tile_origin(it, d_oy0, d_ox0, d_m0);
+                if ((p.debug & 32) || !p.res.p) return;
+                d_load_res(p.res, 0);                         // the first half's residuals: in flight while the consumers park the tile
+            }
+        };
+        auto drain_read = [&](int b) __attribute__((always_inline)) {
+            if constexpr (STAGE) {
+                if (p.debug & 32) return;
+                const unsigned sbase = (unsigned)(size_t)(lds_cfloat_ptr)(const float *)(const void *)smem + stage_off(b) + (unsigned)(pw * SR * 16 * TM * 4);
+                const int ln = opaque_lane();
 #pragma unroll
-                for (int j = 0; j < NC; ++j) {
-                    const int i = pass * NC + j;
-                    if (i >= NI) break;
-                    const int idx = lane + 64 * i;
-                    const int qd = idx % QN, pc = idx / QN, col = pc & 15, r = pc >> 4;
+                for (int i = 0; i < NI; ++i) {
+                    int qd, col, r;
+                    d_item(ln, i, qd, col, r);
                     const unsigned a = sbase + (unsigned)(((r * 16 + col) * TM + ((qd + col) % QN) * 4) * 4);
-                    f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((size_t)a);
-                    if (NRES > 0) v = v + f32x4{rs[j].x, rs[j].y, rs[j].z, rs[j].w};
-                    if (NRES > 1) v = v + f32x4{rs2[j].x, rs2[j].y, rs2[j].z, rs2[j].w};
-                    if ((ok >> j) & 1u) *reinterpret_cast<float4 *>(p.out.p + (size_t)ooff[j]) = make_float4(v[0], v[1], v[2], v[3]);
+                    dv[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((size_t)a);
+                }
+                if (p.res.p) {
+                    d_add_res(0);
+                    d_load_res(p.res, NH);
+                    d_add_res(NH);
+                }
+                if (p.res2.p) {                               // second residual (few convs): added after the first, as the direct epilogue does
+                    d_load_res(p.res2, 0);
+                    d_add_res(0);
+                    d_load_res(p.res2, NH);
+                    d_add_res(NH);
                 }
             }
         };
-        auto drain_tile = [&](int it, int b) __attribute__((always_inline)) {
+        auto drain_store = [&]() __attribute__((always_inline)) {
             if constexpr (STAGE) {
                 if (p.debug & 32) return;
-                if (p.res2.p) drain(it, b, std::integral_constant<int, 2>{});
-                else if (p.res.p) drain(it, b, std::integral_constant<int, 1>{});
-                else drain(it, b, std::integral_constant<int, 0>{});
+                const bool ps = p.fast_epi == 2;
+                const unsigned cps = (unsigned)(p.Cout >> 2);
+                const int ln = opaque_lane();
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    int qd, col, r;
+                    unsigned px, mt;
+                    d_item(ln, i, qd, col, r);
+                    const bool v = d_valid(qd, col, r, px, mt);
+                    unsigned o = px * (unsigned)p.out.ld + mt;       // element offsets (the host keeps tensors of >= 2^32 elements off this path)
+                    if (ps) {                                 // channel m = q * cps + c goes to sub-pixel q = dy * 2 + dx, channel c
+                        const unsigned oy = px / (unsigned)p.Wout, ox = px - oy * (unsigned)p.Wout;
+                        const unsigned q = mt / cps, c = mt - q * cps;
+                        o = ((2u * oy + (q >> 1)) * (unsigned)p.out.W + 2u * ox + (q & 1u)) * (unsigned)p.out.ld + c;
+                    }
+                    if (v) *reinterpret_cast<float4 *>(p.out.p + (size_t)o) = make_float4(dv[i][0], dv[i][1], dv[i][2], dv[i][3]);
+                }
             }
         };
 
@@ -378,24 +424,27 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         store_patch(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of this wave has landed
         __syncthreads();                                   // (A) phase 0 is in buffer 0
-        int drained = 0;                                   // STAGE: tiles this wave has moved out of the LDS
+        int drained = 0;                                   // STAGE: tiles this wave has taken out of the LDS
         for (int k = 0; k + 1 < total; ++k) {              // fill(k+1) while the consumers run phase k
             long long tb = 0;
             if (STAMP) tb = __builtin_amdgcn_s_memtime();
             if (k >= 1) wait_for(sync_s + 4, k);           // buffer (k+1)&1 was read in phase k-1: every consumer has left it
             if (STAMP) s_bar += __builtin_amdgcn_s_memtime() - tb;
             ph = next_phase(ph);
-            if (STAGE && k >= 1 && k % phases_per_tile == 0) {
-                // phase k-1 closed a tile: it is parked in the very pair this fill is about to overwrite. Patch loads first (they
-                // only need registers), then wait for the parked rows, convert, drain, and only when all four producer waves
-                // have drained may the DMA and the patch stores touch the pair.
-                load_patch(ph);
+            const bool boundary = STAGE && k >= 1 && k % phases_per_tile == 0;
+            long long tw = 0;
+            if (STAMP && boundary) tw = __builtin_amdgcn_s_memtime();
+            if (boundary) {
+                // phase k-1 closed a tile: it is parked in the very pair this fill is about to overwrite. The tile's residual loads
+                // first (registers only); the parked rows into registers; the patch loads; when all four producer waves have their
+                // rows, the DMA and the patch stores may touch the pair; the tile's stores go out after the fill has been signalled.
+                drain_prefetch(drained);
                 wait_for(sync_s + 8, drained + 1);
-                settle_patch();
-                drain_tile(drained, (k + 1) & 1);
+                drain_read((k + 1) & 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the parked rows have returned
                 ++drained;
                 signal(sync_s + 12 + pw, drained);
+                load_patch(ph);                                        // (after the residuals have been added: 80 registers fewer in flight)
                 wait_for(sync_s + 12, drained);
                 stage_weights(ph, (k + 1) & 1);
                 store_patch((k + 1) & 1);
@@ -406,14 +455,18 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMA has landed, its LDS stores are done
             signal(sync_s + pw, k + 1);
+            if (STAMP && boundary) s_wait += __builtin_amdgcn_s_memtime() - tw;      // (STAGE stamps: cycles of the boundary fills, wait for the consumers excluded)
+            if (boundary) drain_store();
         }
         if (STAGE) {                                       // the tiles parked after the last fill (the last one, two if a tile is one phase)
             while (drained < n_it) {
+                drain_prefetch(drained);
                 wait_for(sync_s + 8, drained + 1);
-                drain_tile(drained, ((drained + 1) * phases_per_tile - 1) & 1);
+                drain_read(((drained + 1) * phases_per_tile - 1) & 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 ++drained;
                 signal(sync_s + 12 + pw, drained);
+                drain_store();
             }
         }
         if (STAMP && lane == 0 && p.gdn_x.p) {
@@ -611,11 +664,11 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                             *reinterpret_cast<__attribute__((address_space(3))) f32x4 *>((size_t)(sb + (unsigned)(r * 16 * TM * 4) + qoff)) = v;
                         }
                     }
-                    if constexpr (SR < RPW)                  // the rows that do not fit (one, at MF = 4): stored from here as before
-                        conv_epilogue_fast_f<MF, RPW, true, SR>(p, acc, pix, m0, lg, p.w16_unscale, interior, (lds_cfloat_ptr)bias_s);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the parked rows are in the LDS
                 signal(sync_s + 8 + wave, it + 1);
+                if constexpr (SR < RPW)                      // the rows that are not parked (MF = 4): stored from here as before, after the signal
+                    if (!(p.debug & 32)) conv_epilogue_fast_f<MF, RPW, true, SR>(p, acc, pix, m0, lg, p.w16_unscale, interior, (lds_cfloat_ptr)bias_s);
             } else if (!(p.debug & 32)) {
                 // ONE pass over the wave's rows, straight from the accumulators: the epilogue issues row r+1's residual loads
                 // before row r's stores, so no wait inside it ever names a store (a second pass would start by waiting for
@@ -671,14 +724,21 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
     long long blocks = cus;                       // one persistent 8-wave workgroup per CU
     if (const int forced = option_get(OPT_P3_BLOCKS); forced > 0) blocks = forced;      // experiments (tools/p3_scaling.py)
     if (blocks > ntiles) blocks = ntiles;
+    if (MF == 4 && !INACT && (p.debug & 256) && option_get(OPT_P3_STAGE) && (size_t)q.m_tiles * G::TM * sizeof(float) <= (size_t)G::BIAS_MAX) {
+        static LdsGrant grant_ss;
+        if (grant_ss.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<4, false, true, true>), G::TOTAL)) return 1;
+        hipLaunchKernelGGL((conv3_f16x3p_kernel<4, false, true, true>), dim3((unsigned)blocks), dim3(kP3Threads), G::TOTAL, st, q);
+        return launch_status("conv2d(f16x3p, staged, stamps)");
+    }
     if (MF == 4 && !INACT && (p.debug & 256)) {             // diagnostic: in-kernel stamps (tools/p3_stamps.py)
         static LdsGrant grant_s;
         if (grant_s.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<4, false, true>), lds)) return 1;
         hipLaunchKernelGGL((conv3_f16x3p_kernel<4, false, true>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
         return launch_status("conv2d(f16x3p, stamps)");
     }
-    // staged epilogue (the kernel's STAGE note): worth it where a tile's output is a large share of its work -- MF >= 3 (MF <= 2
-    // launches are paced by their producers) -- and the bias of every M tile fits the fixed tail of the staged layout
+    // staged epilogue (the kernel's STAGE note; option p3_stage, OFF by default: measured 5-12 % SLOWER than the direct epilogue,
+    // profiles/r04_p3_stage_ab.txt -- the producer waves have no slack to spare for it): MF >= 3 and the bias of every M tile
+    // must fit the fixed tail of the staged layout
     auto elems = [](const V &v) { return v.p ? (unsigned long long)v.H * v.W * v.ld : 0ull; };      // the drain addresses with 32-bit element offsets
     const bool small32 = elems(p.out) < (1ull << 32) && elems(p.res) < (1ull << 32) && elems(p.res2) < (1ull << 32);
     if (MF >= 3 && option_get(OPT_P3_STAGE) && small32 && (size_t)q.m_tiles * G::TM * sizeof(float) <= (size_t)G::BIAS_MAX) {

@@ -58,8 +58,9 @@ def main():
                                                     100 * epi / cyc, epi / max(tiles, 1), zero / max(tiles, 1)))
         if pr.shape[0]:
             dma, ld, wait, cvt, pbar, pph, geo = (pr[:, i].median().item() for i in range(7))
-            print("   producer wave, cycles per phase: weight-DMA issue %.0f, patch-load issue %.0f, load wait %.0f, convert + LDS stores %.0f, "
-                  "barrier wait %.0f, tile geometry %.0f" % (dma / pph, ld / pph, wait / pph, cvt / pph, pbar / pph, geo / pph))
+            print("   producer wave, cycles per phase: weight-DMA issue %.0f, patch-load issue %.0f, convert + LDS stores %.0f, "
+                  "barrier wait %.0f, tile geometry %.0f; staged build: boundary fill (consumers done -> fill signalled) %.0f cycles per tile" % (
+                      dma / pph, ld / pph, cvt / pph, pbar / pph, geo / pph, wait / max(tiles, 1)))
 
 
 def _unused():
