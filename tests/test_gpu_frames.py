@@ -234,9 +234,10 @@ def _gpu_gop_symbol_aware(n, H, W, seed, gain, scale=2.0, bl=None):
 
 @pytest.mark.parametrize("seed", [7, pytest.param(8, marks=pytest.mark.slow), pytest.param(9, marks=pytest.mark.slow)])
 def test_gop_drift_symbol_aware(seed, precision):
-    """The 32-frame GOP of test_gop_drift_vs_oracle on three more seeds, with ties handled instead of avoided (seeds 8 and 9
-    are marked slow: each is 32 oracle frames of CPU work; profiles/r04_slow_gpu_tests.txt holds their run)."""
-    _gpu_gop_symbol_aware(32, 128, 128, seed, 0.55)
+    """The GOP of test_gop_drift_vs_oracle on three more seeds, with ties handled instead of avoided: 12 frames on seed 7 by
+    default, the full 32 on seeds 8 and 9, which are marked slow (each is 32 oracle frames of CPU work;
+    profiles/r04_slow_gpu_tests.txt holds their run)."""
+    _gpu_gop_symbol_aware(12 if seed == 7 else 32, 128, 128, seed, 0.55)
 
 
 def test_gop_drift_vs_oracle(precision):

@@ -14,9 +14,10 @@ once per frame at this size (noise floor 2.6e-7 at the quan
 saw exactly that). One flipped symbol changes the reconstruction by ~2e-3 in a 100x100-pixel neighbourhood and from then
 on the closed loop drifts locally, although bits and PSNR stay inside the bars. So every frame is checked twice:
 
-  ENCODER pass (the public estimate-mode API, from a DPB that is aligned with the reference's): bits and PSNR at the bars;
-      every symbol against the reference's -- differences must be rare (<= MAX_FLIPS per latent plane of 0.2-1.1 M
-      symbols) and off by exactly one, i.e. ties, not errors.
+  ENCODER pass (the public estimate-mode API, from a DPB that is aligned with the reference's): PSNR at the bar; every symbol
+      against the reference's -- differences must be rare (<= MAX_FLIPS per latent plane of 0.2-1.6 M symbols) and off by
+      exactly one, i.e. ties, not errors; bits at 1e-5 bpp, plus FLIP_BITS per symbol that fell the other way (the I-frame of
+      x2_2160p_ipp has two such BL symbols in the f32 mode: 38 bits = 1.8e-5 bpp of its 2.09 M pixels).
   DECODER pass (the decoder role of the same codec functions, fed the REFERENCE's symbols): every tensor the model hands
       back (reconstructions, features, mv_hat, warp_frame) against the reference's samples and whole-tensor sums, with no
       rounding in the way. Its outputs are the DPB of the next frame, which keeps the loop aligned with the reference.
@@ -30,6 +31,8 @@ from helpers import load_full_case, replay_full, full_sample, decode_from_symbol
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 MAX_FLIPS = 8          # per latent plane (0.2-1.1 M symbols each); the expectation from the fp32 noise floor is ~0-1
+FLIP_BITS = 40.0       # what ONE symbol on the other side of a rounding tie may move a layer's bit count (likelihoods are floored at 1e-9 = 29.9 bits);
+#                        same rule as tests/test_gpu_frames.py::_gpu_gop_symbol_aware: with no flip the plain 1e-5 bpp bar
 
 
 @pytest.fixture(params=["f16x3", "f32"])
@@ -89,7 +92,10 @@ def test_full_size_frames_match_reference(case, precision):
             case, precision, t, d_bpp[0], d_bpp[1], p_enc[0] - want_psnr[0], p_enc[1] - want_psnr[1], nflip or "none", exact), flush=True)
         for key, (n, mx) in flips.items():
             assert n <= MAX_FLIPS and mx <= 1, (t, key, n, mx)
-        assert d_bpp[0] <= 1e-5 and d_bpp[1] <= 1e-5, (t, r["bit_bl"], bits[0], r["bit_el"], bits[1])
+        n_bl = sum(v[0] for k, v in flips.items() if k.startswith("bl"))
+        n_el = sum(v[0] for k, v in flips.items() if k.startswith("el"))
+        assert abs(r["bit_bl"] - bits[0]) <= 1e-5 * m["h"] * m["w"] + FLIP_BITS * n_bl, (t, r["bit_bl"], bits[0], n_bl)
+        assert abs(r["bit_el"] - bits[1]) <= 1e-5 * m["H"] * m["W"] + FLIP_BITS * n_el, (t, r["bit_el"], bits[1], n_el)
         assert abs(p_enc[0] - want_psnr[0]) <= 1e-4 and abs(p_enc[1] - want_psnr[1]) <= 1e-4, (t, p_enc, want_psnr)
         del r, enc
         # ---------------- decoder pass on the reference's symbols: every tensor, tight, and the next frame's DPB
