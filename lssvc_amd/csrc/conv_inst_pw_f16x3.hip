@@ -20,7 +20,22 @@ int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name) {
         if (big && mf_big > mf_fit) MF = mf_big < want ? mf_big : want;
     }
     if (p.epilogue != LSSVC_EPI_NONE || p.in_act == LSSVC_INACT_SQUARE) {
-        // GDN / IGDN (square input, normalising epilogue): the generic streaming kernel with the GDN epilogue compiled in
+        // GDN / IGDN (square input, normalising epilogue). Up to 64 channels the whole gamma matrix fits LDS: the all-M kernel
+        // (pixels converted once, next group's loads in flight during the M loop) with the GDN epilogue compiled in; the
+        // generic streaming kernel has no cross-group prefetch and ran these at 1.3-1.8 TB/s
+        static const int gdn_allm = getenv("LSSVC_GDN_ALLM") ? atoi(getenv("LSSVC_GDN_ALLM")) : 1;
+        {
+            int mf = frags < 4 ? frags : 4;
+            if (frags % 4 != 0 && frags % 3 == 0) mf = 3;
+            const int m_tiles = (frags + mf - 1) / mf;
+            if (gdn_allm && p.n_chunks16 <= 4 && (long long)nslot * m_tiles * mf * 1024 <= kPwMaxLds) {
+                snprintf(kernel_name, 96, "conv_pw_allm_f16x3_kernel<%d, 2, true>", mf);
+                if (mf == 4) return launch_pw_allm_f16x3<4, 2, true>(p, st);
+                if (mf == 3) return launch_pw_allm_f16x3<3, 2, true>(p, st);
+                if (mf == 2) return launch_pw_allm_f16x3<2, 2, true>(p, st);
+                return launch_pw_allm_f16x3<1, 2, true>(p, st);
+            }
+        }
         if (MF > mf_fit) MF = mf_fit;
         if (MF < 1) return fail("conv2d(pw f16x3): Cin too large for the LDS-resident weight tile");
         snprintf(kernel_name, 96, "conv_pw_f16x3_kernel<%d, 2, true>", MF);

@@ -543,7 +543,7 @@ static int launch_pwks_f16x3(const ConvP &p, hipStream_t st) {
 // the wave converts its pixel fragments ONCE, keeps them in registers and walks every M tile itself (so X is
 // read and split once instead of once per M tile, and all output channels of a pixel are written by one wave),
 // while the raw loads of its next pixel group are already in flight.
-template <int MF, int RPW>
+template <int MF, int RPW, bool GDN = false>
 __global__ __launch_bounds__(256, 2) void conv_pw_allm_f16x3_kernel(const ConvP p) {
     constexpr int TM = 16 * MF;
     constexpr int NS = 2;                                                   // K-steps held in registers
@@ -680,12 +680,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_allm_f16x3_kernel(const ConvP 
                 }
             }
             conv_unscale<MF, RPW>(p, acc);
-            conv_epilogue_flat<MF, RPW, false>(p, acc, pix, [&](int r, int col) { const long long q = (grp * RPW + r) * 16 + col; return q < npix ? q : -1LL; }, mt * TM, lg);
+            conv_epilogue_flat<MF, RPW, GDN>(p, acc, pix, [&](int r, int col) { const long long q = (grp * RPW + r) * 16 + col; return q < npix ? q : -1LL; }, mt * TM, lg);
         }
     }
 }
 
-template <int MF, int RPW>
+template <int MF, int RPW, bool GDN = false>
 static int launch_pw_allm_f16x3(const ConvP &p, hipStream_t st) {
     ConvP q = p;
     q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
@@ -694,7 +694,7 @@ static int launch_pw_allm_f16x3(const ConvP &p, hipStream_t st) {
     if (lds > (size_t)kPwMaxLds || p.n_chunks16 > 4) return fail("conv2d(pw all-M f16x3): shape does not fit");
     static const int per_cu = [] {
         int v = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_pw_allm_f16x3_kernel<MF, RPW>, 256, kPwMaxLds) != hipSuccess || v < 1) v = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, conv_pw_allm_f16x3_kernel<MF, RPW, GDN>, 256, kPwMaxLds) != hipSuccess || v < 1) v = 1;
         return v;
     }();
     const int resident = per_cu * device_cus();
@@ -707,7 +707,7 @@ static int launch_pw_allm_f16x3(const ConvP &p, hipStream_t st) {
     if (cap > by_lds) cap = by_lds;
     if (cap > 2 * 256) cap = 2 * 256;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((conv_pw_allm_f16x3_kernel<MF, RPW>), dim3((unsigned)blocks), dim3(256), lds, st, q);
+    hipLaunchKernelGGL((conv_pw_allm_f16x3_kernel<MF, RPW, GDN>), dim3((unsigned)blocks), dim3(256), lds, st, q);
     return launch_status("conv2d(pw all-M f16x3)");
 }
 
