@@ -39,10 +39,16 @@ constexpr int kP3Threads = 512;
 constexpr int kP3Consumers = 4;          // waves 0..3
 constexpr int kP3ProducerThreads = kP3Threads - 64 * kP3Consumers;
 
-template <int MF>
+// S = 2 (stride-2 convs, round 4): the input patch of a tile is 4x its output, so the tile is 8x16 output pixels (RPW = 2 rows per
+// consumer wave, (2*8+1) x 33 input pixels per 16-channel chunk: 2 x 36 KB of patch + 2 x 37 KB of weights at MF = 4); fragment
+// column li reads patch column 2*li + kx, a 64-byte lane stride that would be a 4-way bank conflict on ds_read_b128, so the even
+// and the odd columns of a patch row are stored as two runs ([even 0,2,.. | odd 1,3,..]: column c lives at (c & 1) * PWE + (c >> 1)),
+// as in the tiled kernel. These launches are paced by their producers (4 input pixels per output pixel: they are HBM-bound at a
+// matrix-pipe occupancy of about 0.4), which is the point: the tiled kernel ran them at half that.
+template <int MF, int S = 1>
 struct P3Geom {
-    static constexpr int RPW = LSSVC_P3_RPW, HALF = RPW / 2, TH = RPW * kP3Consumers, TM = 16 * MF;
-    static constexpr int PH = TH + 2, PW = 18, NTAP = 9, NSTEP = 5;
+    static constexpr int RPW = S == 2 ? 2 : LSSVC_P3_RPW, HALF = RPW / 2, TH = RPW * kP3Consumers, TM = 16 * MF;
+    static constexpr int PH = (TH - 1) * S + 3, PW = 15 * S + 3, PWE = (PW + 1) / 2, NTAP = 9, NSTEP = 5;
     static constexpr int PATCH_HALFS = PH * PW * CK16;            // per plane
     static constexpr int PATCH_ITEMS = PH * PW * 4;               // float4 items
     static constexpr int NP = (PATCH_ITEMS + kP3ProducerThreads - 1) / kP3ProducerThreads;
@@ -86,9 +92,10 @@ struct P3Phase {
 // as before) and go straight on to the next tile; each producer wave then moves one consumer wave's rows to global memory
 // (adding the residuals, plain or pixel-shuffle store) with the NEXT fill's patch loads already in flight, and only after all
 // four have drained is the pair refilled. Same arithmetic per element as the direct epilogue: results are bit-identical.
-template <int MF, bool INACT, bool STAMP = false, bool STAGE = false>
+template <int MF, bool INACT, bool STAMP = false, bool STAGE = false, int S = 1>
 __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP p) {
-    using G = P3Geom<MF>;
+    static_assert(!(STAGE && S != 1), "the staged epilogue is laid out for stride 1");
+    using G = P3Geom<MF, S>;
     constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP, NP = G::NP;
     constexpr int SR = STAGE ? G::SR : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 const int idx = lt + i * kP3ProducerThreads;
                 const int pix = idx >> 2;
                 const int py = pix / PW, px = pix - py * PW;
-                const int gy = oy0 - p.pad_t + py, gx = ox0 - p.pad_l + px;
+                const int gy = oy0 * S - p.pad_t + py, gx = ox0 * S - p.pad_l + px;
                 const bool ok = idx < G::PATCH_ITEMS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
                 ppix[i] = ok ? gy * Win + gx : -1;
             }
@@ -290,7 +297,12 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 // that round's global load INTO the guarded block, behind every other store, and two of the four producer
                 // waves then sit out a full memory latency at the end of every fill
                 const bool in_patch = i + 1 < NP || idx < G::PATCH_ITEMS;
-                const int o = (idx >> 2) * CK16 + quad4;
+                int ppos = idx >> 2;                               // patch pixel py * PW + px ...
+                if (S == 2) {                                      // ... stride 2: even columns first, then the odd ones (P3Geom)
+                    const int py = ppos / PW, px = ppos - py * PW;
+                    ppos = py * PW + (px & 1) * G::PWE + (px >> 1);
+                }
+                const int o = ppos * CK16 + quad4;
                 *reinterpret_cast<f16x4 *>(in_patch ? ph_ + o : trash_s + lt * 4) = h;
                 *reinterpret_cast<f16x4 *>(in_patch ? pl_ + o : trash_s + (kP3ProducerThreads + lt) * 4) = l;
             }
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         // a lane group is 2u + tsel, so the tap part is a per-lane select between two constants); fragment f / row r are
         // compile-time byte offsets that the ds_read carries as its immediate. Base pointers as LDS byte addresses.
         const unsigned a_lane = (unsigned)(li * CK16 + ch8) * 2u;                                  // bytes
-        const unsigned b_lane = (unsigned)(((wave * RPW) * PW + li) * CK16 + ch8) * 2u;
+        const unsigned b_lane = (unsigned)(((wave * RPW * S) * PW + li) * CK16 + ch8) * 2u;
         const unsigned wh_b = (unsigned)(size_t)(lds_cfloat_ptr)(const float *)(const void *)wh_;   // LDS byte address of the hi plane
         const unsigned wl_b = wh_b + (unsigned)G::W_HALFS * 2u;
         const unsigned ph_b = (unsigned)(size_t)(lds_cfloat_ptr)(const float *)(const void *)ph_;
@@ -538,12 +550,14 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         auto load_b = [&](int u, int g, f16x8 (&b1)[GR], f16x8 (&b2)[GR]) {
             const bool odd = 2 * u + 1 >= NTAP;
             const int tap0 = 2 * u, tap1 = odd ? tap0 : 2 * u + 1;
-            const unsigned o0 = (unsigned)(((tap0 / 3) * PW + tap0 % 3) * CK16) * 2u, o1 = (unsigned)(((tap1 / 3) * PW + tap1 % 3) * CK16) * 2u;
+            // tap (ky, kx) -> patch offset of fragment column 0: stride 1 column kx; stride 2 column kx of the de-interleaved row
+            auto tap_off = [](int tap) { const int ky = tap / 3, kx = tap % 3; return (unsigned)((ky * PW + (S == 2 ? (kx & 1) * G::PWE + (kx >> 1) : kx)) * CK16) * 2u; };
+            const unsigned o0 = tap_off(tap0), o1 = tap_off(tap1);
             const unsigned tap_b = b_lane + (tsel ? o1 : o0);
             const unsigned p1 = ((odd && tsel) ? pl_b : ph_b) + tap_b, p2 = pl_b + tap_b;
 #pragma unroll
             for (int r = 0; r < GR; ++r) {
-                const unsigned ro = (unsigned)((g * GR + r) * PW * CK16) * 2u;
+                const unsigned ro = (unsigned)((g * GR + r) * S * PW * CK16) * 2u;
                 b1[r] = lds_read(p1 + ro);
                 if (!odd) b2[r] = lds_read(p2 + ro);
             }
@@ -706,9 +720,9 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     }
 }
 
-template <int MF, bool INACT>
+template <int MF, bool INACT, int S = 1>
 static int launch_p3(const ConvP &p, hipStream_t st) {
-    using G = P3Geom<MF>;
+    using G = P3Geom<MF, S>;
     const int cus = device_cus();
     ConvP q = p;
     q.tiles_x = (p.Wout + 15) / 16;
@@ -717,13 +731,17 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
     const size_t lds = (size_t)G::LDS_BYTES + (size_t)q.m_tiles * G::TM * sizeof(float) + 32 + 2 * kP3ProducerThreads * 8;      // + bias vector + hand-off slots + trash slots
     if (lds > 160 * 1024) return fail("conv2d(f16x3p): %zu bytes of LDS", lds);
     static LdsGrant grant;
-    if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, INACT>), lds)) return 1;
+    if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, INACT, false, false, S>), lds)) return 1;
     const long long ntiles = (long long)q.tiles_x * q.tiles_y * q.m_tiles;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return fail("conv2d(f16x3p): bad tile count %lld", ntiles);
     if (p.w16_plane * 2 > 0x7fffffffLL) return fail("conv2d(f16x3p): weight image too large for 32-bit lane offsets");
     long long blocks = cus;                       // one persistent 8-wave workgroup per CU
     if (const int forced = option_get(OPT_P3_BLOCKS); forced > 0) blocks = forced;      // experiments (tools/p3_scaling.py)
     if (blocks > ntiles) blocks = ntiles;
+    if constexpr (S != 1) {
+        hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, INACT, false, false, S>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
+        return launch_status("conv2d(f16x3p, stride 2)");
+    } else {
     if (MF == 4 && !INACT && (p.debug & 256) && option_get(OPT_P3_STAGE) && (size_t)q.m_tiles * G::TM * sizeof(float) <= (size_t)G::BIAS_MAX) {
         static LdsGrant grant_ss;
         if (grant_ss.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<4, false, true, true>), G::TOTAL)) return 1;
@@ -749,6 +767,7 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
     }
     hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, INACT>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
     return launch_status("conv2d(f16x3p)");
+    }
 }
 
 static int p3_pick_mf(int frags) {
@@ -765,6 +784,27 @@ bool conv3_f16x3p_wanted(const ConvP &p) {
     const int mf = p3_pick_mf(p.M_pad / 16);
     const long long ntiles = (long long)((p.Wout + 15) / 16) * ((p.Hout + 4 * LSSVC_P3_RPW - 1) / (4 * LSSVC_P3_RPW)) * ((p.M_pad / 16 + mf - 1) / mf);
     return ntiles >= min_tiles;
+}
+
+// stride 2: 8x16-pixel output tiles (P3Geom<MF, 2>); MF >= 3 only (narrower outputs leave the consumers one or two fragments
+// of work per 33x17-pixel patch, the tiled kernel's two workgroups per CU do as well there)
+bool conv3s2_f16x3p_wanted(const ConvP &p) {
+    const int on = option_get(OPT_P3_S2), min_tiles = option_get(OPT_P3_MIN_TILES);
+    if (!on || !p.fast_epi) return false;
+    if (p.in_act == LSSVC_INACT_LRELU && !(p.in_slope >= 0.0f && p.in_slope <= 1.0f)) return false;
+    const int mf = p3_pick_mf(p.M_pad / 16);
+    if (mf < 3) return false;
+    const long long ntiles = (long long)((p.Wout + 15) / 16) * ((p.Hout + 7) / 8) * ((p.M_pad / 16 + mf - 1) / mf);
+    return ntiles >= min_tiles;
+}
+
+int dispatch_conv3s2_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
+    const int mf = p3_pick_mf(p.M_pad / 16);
+    const bool inact = p.in_act == LSSVC_INACT_LRELU;
+    snprintf(kernel_name, 96, "conv3s2_f16x3p_kernel<%d, %s>", mf, inact ? "true" : "false");
+    if (mf == 4) return inact ? launch_p3<4, true, 2>(p, st) : launch_p3<4, false, 2>(p, st);
+    if (mf == 3) return inact ? launch_p3<3, true, 2>(p, st) : launch_p3<3, false, 2>(p, st);
+    return fail("conv2d(f16x3p, stride 2): no kernel for MF=%d", mf);
 }
 
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {

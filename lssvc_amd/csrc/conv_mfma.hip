@@ -26,9 +26,9 @@ namespace lssvc {
 // ---- runtime tuning switches: environment at first use, lssvc_set_option() afterwards ----------------
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<bool> g_opt_set[OPT_COUNT];
-static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS", "LSSVC_DWPRE_DEEP", "LSSVC_P3_BLOCKS", "LSSVC_P3_STAGE"};
-static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks", "dwpre_deep", "p3_blocks", "p3_stage"};
-static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0};      // p3_stage: off (measured slower); kept for the record and its test
+static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS", "LSSVC_DWPRE_DEEP", "LSSVC_P3_BLOCKS", "LSSVC_P3_STAGE", "LSSVC_F16X3_PERSIST_S2"};
+static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks", "dwpre_deep", "p3_blocks", "p3_stage", "f16x3_persist_s2"};
+static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1};      // p3_stage: off (measured slower); kept for the record and its test
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
         const char *e = getenv(kOptEnv[which]);
@@ -200,6 +200,8 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         if (vec && sd == 1 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3_f16x3p_wanted(p))
             return dispatch_conv3_f16x3p(p, st, kname);
         static const int s2_on = getenv("LSSVC_F16X3_S2") ? atoi(getenv("LSSVC_F16X3_S2")) : 1;
+        if (s2_on && vec && sd == 2 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3s2_f16x3p_wanted(p))
+            return dispatch_conv3s2_f16x3p(p, st, kname);
         if (s2_on && vec && sd == 2 && ks == 3 && RPW <= 2) {
             snprintf(kname, 96, "conv_f16x3_kernel<%d, %d, 3, 2>", MF, RPW);
             return dispatch_tile_f16x3_s2<3>(p, MF, RPW, st);

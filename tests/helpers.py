@@ -181,3 +181,28 @@ def write_checkpoint_blob(sd, path):
             f.write(struct.pack("<i", len(name)) + name + struct.pack("<i4q", v.dim(), *shape))
             f.write(v.numpy().tobytes())
     return len(items)
+
+
+# ---- rounding ties (tests/test_gpu_golden_full.py, tests/test_gpu_frames.py) ------------------------------------------------
+def tie_clusters(diff, key, H, W, h, w, radius=8):
+    """diff: (GPU symbols - reference symbols) of one latent plane, flattened channel-major; key: "el_y", "bl_mv_z", ...
+    -> (number of symbols that differ, largest |difference|, number of spatial CLUSTERS of them). A value that lies on a
+    rounding tie falls either way under a differently ordered fp32 sum; in the 4-step spatial prior of the EL residual
+    (LSSVC_net.py:338-443) that symbol then shifts the means of the later steps in its 7x7 neighbourhood by a little, and a
+    neighbour that was itself close to a tie follows. So what must be rare is not a differing symbol but an independent
+    EVENT: the differing positions are grouped by distance (Chebyshev <= radius on the latent grid, any channel)."""
+    import numpy as np
+    n = int(np.count_nonzero(diff))
+    if n == 0:
+        return 0, 0, 0
+    down = 16 if key.endswith("_y") else 64
+    gh, gw = ((H, W) if key.startswith("el") else (h, w))
+    gh, gw = -(-gh // down), -(-gw // down)
+    assert diff.size % (gh * gw) == 0, (key, diff.size, gh, gw)
+    pos = np.flatnonzero(diff.reshape(-1)) % (gh * gw)
+    ys, xs = pos // gw, pos % gw
+    centres = []
+    for y, x in sorted(zip(ys.tolist(), xs.tolist())):
+        if not any(abs(y - cy) <= radius and abs(x - cx) <= radius for cy, cx in centres):
+            centres.append((y, x))
+    return n, int(np.abs(diff).max()), len(centres)

@@ -186,6 +186,61 @@ def test_persistent_3x3_staged_epilogue_is_bit_identical(hip, cins, cout, H, W, 
         assert torch.equal(s, plain), (s - plain).abs().max().item()
 
 
+# cins, cout, H_in, W_in, in_act, act, residual  (stride-2 3x3, padding 1: out = ceil(in / 2))
+P3S2_CASES = [
+    ([48], 64, 300, 340, None, None, False),             # the bench's 48 -> 64 @1152x1920 -> 576x960 form
+    ([64], 64, 293, 331, "lrelu", "lrelu", False),       # odd input sizes: partial tiles on both edges
+    ([4], 64, 300, 340, None, None, False),              # RGB input padded to 4 channels: one phase per tile
+    ([48, 8], 64, 280, 360, None, "lrelu", False),       # two-input concat, 56 channels (the bench's 52 / 56 -> 64 forms)
+    ([64], 96, 260, 300, None, "lrelu", False),          # MF = 3, two M tiles
+    ([128], 96, 200, 260, "lrelu", None, True),          # MF = 3, 8 phases, with a residual
+]
+
+
+@pytest.mark.parametrize("cins,cout,H,W,in_act,act,residual", P3S2_CASES)
+def test_persistent_3x3_stride2(hip, cins, cout, H, W, in_act, act, residual):
+    """The stride-2 form of the persistent kernel (8x16-pixel output tiles, patch columns de-interleaved): fp32-class accuracy
+    against fp64, bit-identical to the tiled stride-2 kernel (same K order, same epilogue), and really dispatched."""
+    g = torch.Generator().manual_seed(hash((tuple(cins), cout, H, 2)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    r = torch.randn(1, cout, Ho, Wo, generator=g) if residual else None
+    x64 = torch.cat(xs, 1).double()
+    if in_act == "lrelu":
+        x64 = F.leaky_relu(x64, 0.1)
+    ref = F.conv2d(x64, w.double(), b.double(), stride=2, padding=1)
+    if act == "lrelu":
+        ref = F.leaky_relu(ref, 0.01)
+    if residual:
+        ref = ref + r.double()
+    Wt = _W({"c.weight": w, "c.bias": b})
+
+    def launch():
+        return back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], stride=2, in_act=in_act, in_slope=0.1, act=act, slope=0.01,
+                             residual=nhwc(hip, r) if residual else None))
+
+    old = _get("f16x3_persist_s2")
+    try:
+        _set("f16x3_persist_s2", 1)
+        got, k1 = _run(hip, "f16x3", launch)
+        again, _ = _run(hip, "f16x3", launch)
+        _set("f16x3_persist_s2", 0)
+        tiled, k0 = _run(hip, "f16x3", launch)
+    finally:
+        _set("f16x3_persist_s2", old)
+    got32, _ = _run(hip, "f32", launch)
+    assert k1.startswith("conv3s2_f16x3p_kernel<%d" % (4 if cout % 64 == 0 else 3)), k1
+    assert k0.startswith("conv_f16x3_kernel"), k0
+    assert got.shape == ref.shape
+    assert torch.equal(got, tiled) and torch.equal(got, again)
+    e16 = (got.double() - ref).abs().max().item()
+    e32 = (got32.double() - ref).abs().max().item()
+    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
+
+
 def test_persistent_3x3_small_grids(hip):
     """Grids with fewer than 8 workgroups (tile ranges keyed by blockIdx & 7 left tiles uncomputed): force
     the persistent kernel onto convs with 1..7 tiles and compare with the tiled kernel."""
