@@ -188,12 +188,12 @@ def test_persistent_3x3_staged_epilogue_is_bit_identical(hip, cins, cout, H, W, 
 
 # cins, cout, H_in, W_in, in_act, act, residual  (stride-2 3x3, padding 1: out = ceil(in / 2))
 P3S2_CASES = [
-    ([48], 64, 300, 340, None, None, False),             # the bench's 48 -> 64 @1152x1920 -> 576x960 form
-    ([64], 64, 293, 331, "lrelu", "lrelu", False),       # odd input sizes: partial tiles on both edges
-    ([4], 64, 300, 340, None, None, False),              # RGB input padded to 4 channels: one phase per tile
-    ([48, 8], 64, 280, 360, None, "lrelu", False),       # two-input concat, 56 channels (the bench's 52 / 56 -> 64 forms)
+    ([48], 64, 360, 420, None, None, False),             # the bench's 48 -> 64 @1152x1920 -> 576x960 form (>= 256 tiles of 8x16 outputs)
+    ([64], 64, 373, 411, "lrelu", "lrelu", False),       # odd input sizes: partial tiles on both edges
+    ([4], 64, 360, 420, None, None, False),              # RGB input padded to 4 channels: one phase per tile
+    ([48, 8], 64, 380, 400, None, "lrelu", False),       # two-input concat, 56 channels (the bench's 52 / 56 -> 64 forms)
     ([64], 96, 260, 300, None, "lrelu", False),          # MF = 3, two M tiles
-    ([128], 96, 200, 260, "lrelu", None, True),          # MF = 3, 8 phases, with a residual
+    ([128], 96, 260, 310, "lrelu", None, True),          # MF = 3, 8 phases, with a residual
 ]
 
 
