@@ -705,12 +705,19 @@ class SymbolStage:
         self.capacity = self.used = 0
         self.dev = self.host = self.host_np = None
         self._down = (0, 0)
+        self._pre = None
+        self.uploaded = None                                                   # event behind the last asynchronous H2D out of the pinned buffer
         self.flag = torch.zeros(1, dtype=torch.int32, device=device)           # set by a symbol that does not fit 16 bits
         self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.done = torch.cuda.Event()
 
     def begin(self, capacity):
-        """Start a layer: everything staged before is dead (its copies were waited for when its string was flushed)."""
+        """Start a layer: everything staged before is dead (its copies were waited for when its string was flushed; an
+        upload still in flight out of the pinned buffer is waited for here, before the host writes into it again -- what
+        plan_runtime.cpp does with hipStreamSynchronize before every decode step)."""
+        if self.uploaded is not None:
+            self.uploaded.synchronize()
+            self.uploaded = None
         if capacity > self.capacity:
             self.capacity = int(capacity)
             self.dev = torch.empty(self.capacity, dtype=torch.int16, device=self.device)
@@ -772,6 +779,9 @@ class SymbolStage:
     def upload(self, ref):
         t0 = _prof_start()
         self.dev[ref.off:ref.off + ref.n].copy_(self.host[ref.off:ref.off + ref.n], non_blocking=True)
+        if self.uploaded is None:
+            self.uploaded = torch.cuda.Event()
+        self.uploaded.record()
         if t0 is not None:
             _prof("h2d_s", t0)
             STREAM_PROF["h2d_bytes"] = STREAM_PROF.get("h2d_bytes", 0) + 2 * ref.n

@@ -184,6 +184,7 @@ class _HostModel:
                 break
             import warnings
             self.W.force_f32 |= set(bad)
+            self._plans = {}                   # captured launch sequences bake the kernel choice in: drop them
             worst = max(bad, key=bad.get)
             warnings.warn("fp16 range audit (%s): %d conv layer(s) moved to the exact fp32 kernel, e.g. %s with max |input| = %.3g; a "
                           "separate decoder process must be given the same set (get_f32_layers / set_f32_layers)"

@@ -254,3 +254,80 @@ def test_plan_with_inter_layer_padding_replays_through_the_engine(tmp_path):
                 assert torch.equal(o, r[k].contiguous()), k
     finally:
         lib.lssvc_engine_destroy(eng)
+
+
+def test_a_plan_serves_any_checkpoint_of_the_architecture(tmp_path):
+    """A plan holds launches and weight RECIPES, no weights: compiled from one checkpoint it codes with another (handed to
+    lssvc_engine_load_checkpoint as a raw state dict), and gives that checkpoint's Python-path result bit for bit -- including
+    the per-layer power-of-two prescale of the fp16 weight planes, which is a function of the checkpoint and is patched into the
+    launch descriptors when the plan is bound. I-frame and first P-frame at 128x128 / 64x64."""
+    import ctypes as C
+    from lssvc_amd import IntraSS, LSSVC_extend, plan_compiler, _lib
+    from lssvc_amd.synth import synth_state_dict
+    g = torch.Generator().manual_seed(12)
+    H = W = 128
+    x_el = [torch.rand(1, 3, H, W, generator=g).to(DEV) for _ in range(2)]
+    x_bl = [torch.rand(1, 3, H // 2, W // 2, generator=g).to(DEV) for _ in range(2)]
+
+    def nets(seed, gain):
+        inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", seed, gain)).to(DEV).eval()
+        pnet = LSSVC_extend()
+        pnet.load_dict(synth_state_dict("lssvc_extend", seed, gain))
+        pnet.to(DEV).eval()
+        for net in (inet, pnet):
+            net.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+        return inet, pnet
+
+    def python_path(inet, pnet):
+        r = inet.encode_decode(x_bl[0], x_el[0], None, None, H // 2, W // 2, H, W)
+        dpb = {"ref_frame_bl": r["x_hat_bl"].clone().clamp_(0, 1), "ref_frame_el": r["x_hat_el"].clone().clamp_(0, 1), "ref_feature_bl": None,
+               "ref_feature_el": r["feature_el"]}
+        q = pnet.encode_decode(x_bl[1], x_el[1], dpb, None, None, W, H, W // 2, H // 2)
+        return r, dpb, q
+
+    a_i, a_p = nets(3, 0.6)                                       # the checkpoint the plans are compiled from
+    _, dpb_a, _ = python_path(a_i, a_p)
+    plans = [str(tmp_path / "i.plan"), str(tmp_path / "p1.plan")]
+    plan_compiler.compile_iframe(a_i, x_bl[0], x_el[0], plans[0])
+    plan_compiler.compile_pframe(a_p, x_bl[1], x_el[1], {k: (None if v is None else v.contiguous()) for k, v in dpb_a.items()}, plans[1])
+    b_i, b_p = nets(4, 0.45)                                      # another checkpoint: other weights, other magnitudes
+    want_i, dpb_b, want_p = python_path(b_i, b_p)
+    assert want_i["bit_el"] != python_path(a_i, a_p)[0]["bit_el"]
+    lib = _lib.lib
+    eng = lib.lssvc_engine_create(0)
+    try:
+        for model, net in ((0, b_i), (1, b_p)):
+            table, n = net.W._ckpt()
+            _lib.check(lib.lssvc_engine_load_checkpoint(eng, model, table, n))
+        _lib.check(lib.lssvc_engine_load_intra(eng, plans[0].encode()))
+        P = lambda t: C.c_void_p(t.data_ptr())
+        bits = (C.c_double * 2)()
+        oi = [torch.empty(1, 3, H // 2, W // 2, device=DEV), torch.empty(1, 3, H, W, device=DEV), torch.empty(1, 64, H, W, device=DEV)]
+        _lib.check(lib.lssvc_engine_iframe(eng, P(x_bl[0]), P(x_el[0]), bits, *[P(o) for o in oi], None))
+        torch.cuda.synchronize()
+        assert (bits[0], bits[1]) == (want_i["bit_bl"], want_i["bit_el"])
+        for o, k in zip(oi, ("x_hat_bl", "x_hat_el", "feature_el")):
+            assert torch.equal(o, want_i[k].contiguous()), k
+    finally:
+        lib.lssvc_engine_destroy(eng)
+    # the P-frame plan through its own engine (load_inter wants both P plans; the first-P plan alone goes through the stream-less
+    # loader of a second engine with the same checkpoint)
+    eng = lib.lssvc_engine_create(0)
+    try:
+        table, n = b_p.W._ckpt()
+        _lib.check(lib.lssvc_engine_load_checkpoint(eng, 1, table, n))
+        steady = str(tmp_path / "p.plan")
+        plan_compiler.compile_pframe(a_p, x_bl[1], x_el[1], {k: v.contiguous() for k, v in python_path(a_i, a_p)[2]["dpb"].items()}, steady)
+        _lib.check(lib.lssvc_engine_load_inter(eng, plans[1].encode(), steady.encode()))
+        op = [torch.empty(1, 3, H // 2, W // 2, device=DEV), torch.empty(1, 64, H // 2, W // 2, device=DEV), torch.empty(1, 3, H, W, device=DEV),
+              torch.empty(1, 48, H, W, device=DEV), torch.empty(1, 2, H, W, device=DEV), torch.empty(1, 3, H, W, device=DEV)]
+        d = {k: v.contiguous() for k, v in dpb_b.items() if v is not None}
+        _lib.check(lib.lssvc_engine_pframe(eng, P(x_bl[1]), P(x_el[1]), P(d["ref_frame_bl"]), P(d["ref_frame_el"]), None, P(d["ref_feature_el"]), bits,
+                                           *[P(o) for o in op], None))
+        torch.cuda.synchronize()
+        assert (bits[0], bits[1]) == (want_p["bit_bl"], want_p["bit_el"])
+        for o, x in zip(op, (want_p["dpb"]["ref_frame_bl"], want_p["dpb"]["ref_feature_bl"], want_p["dpb"]["ref_frame_el"], want_p["dpb"]["ref_feature_el"],
+                             want_p["mv_hat"], want_p["warp_frame"])):
+            assert torch.equal(o, x.contiguous())
+    finally:
+        lib.lssvc_engine_destroy(eng)
