@@ -34,7 +34,7 @@ struct ConvP {
     const void *w16; // f16x3 mode: fp16 weights [plane hi|lo][chunk16][ky][kx][m][16]
     long long w16_plane;   // elements per plane
     float w16_unscale;     // f16x3 mode: accumulators *= this (power of two) before the epilogue
-    int debug;       // perf-ablation switches (env LSSVC_CONV_DEBUG; results are WRONG when set): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger, 16 skip LDS fragment reads
+    int debug;       // perf-ablation switches (env LSSVC_CONV_DEBUG; results are WRONG when set): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger, 16 skip LDS fragment reads, 32 skip the epilogue, 64 skip the fp32 -> fp16 split (K-sliced 1x1), 256 in-kernel stamps
     int out_vec, res_vec, gdn_vec;
     int fast_epi;    // host: Cout % 4 == 0, 16-byte addressable out / residual, no pixel shuffle, no GDN -> straight-line epilogue
 };

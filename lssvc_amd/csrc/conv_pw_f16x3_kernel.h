@@ -455,6 +455,11 @@ __global__ __launch_bounds__(256, 2) void conv_pwks_f16x3_kernel(const ConvP p) 
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const float v[8] = {src[r][0].x, src[r][0].y, src[r][0].z, src[r][0].w, src[r][1].x, src[r][1].y, src[r][1].z, src[r][1].w};
+            if (p.debug & 64) {                                   // ablation (results WRONG): no fp32 -> fp16 hi / lo conversion
+                bh[r] = __builtin_bit_cast(f16x8, src[r][0]);
+                bl[r] = __builtin_bit_cast(f16x8, src[r][1]);
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float x = (pix[r] >= 0 && j < left8) ? v[j] : 0.f;
