@@ -57,18 +57,6 @@ int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name) {
             return launch_pw_allm_f16x3<1, 2>(p, st);
         }
     }
-    // large K on a SMALL map (the 72x120 prior chain): pixels stationary in registers, all weights streamed through LDS by DMA
-    {
-        const long long groups16 = ((long long)p.Hout * p.Wout + 15) / 16;
-        const int nstep = (p.n_chunks16 + 1) / 2;
-        if (option_get(OPT_PWX) && p.n_chunks16 >= 16 && nstep <= 32 && p.M_pad >= 128 && groups16 <= 4 * 256 && p.fast_epi &&
-            p.in_act != LSSVC_INACT_SQUARE && (p.in_act != LSSVC_INACT_LRELU || (p.in_slope >= 0.0f && p.in_slope <= 1.0f))) {
-            snprintf(kernel_name, 96, "conv_pwx_f16x3_kernel<%d>", nstep <= 12 ? 12 : (nstep <= 16 ? 16 : 32));
-            if (nstep <= 12) return launch_pwx_f16x3<12>(p, st);
-            if (nstep <= 16) return launch_pwx_f16x3<16>(p, st);
-            return launch_pwx_f16x3<32>(p, st);
-        }
-    }
     // large K on a small map: K-sliced kernel with a full-height M tile (X is re-read M/64 instead of M/16 times)
     static const int ksliced = getenv("LSSVC_PW_KSLICED") ? atoi(getenv("LSSVC_PW_KSLICED")) : 1;
     {

@@ -26,9 +26,9 @@ namespace lssvc {
 // ---- runtime tuning switches: environment at first use, lssvc_set_option() afterwards ----------------
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<bool> g_opt_set[OPT_COUNT];
-static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS", "LSSVC_DWPRE_DEEP", "LSSVC_P3_BLOCKS", "LSSVC_P3_STAGE", "LSSVC_F16X3_PERSIST_S2", "LSSVC_PWX"};
-static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks", "dwpre_deep", "p3_blocks", "p3_stage", "f16x3_persist_s2", "pw_x_stationary"};
-static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1, 1};      // p3_stage: off (measured slower); kept for the record and its test
+static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS", "LSSVC_DWPRE_DEEP", "LSSVC_P3_BLOCKS", "LSSVC_P3_STAGE", "LSSVC_F16X3_PERSIST_S2"};
+static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks", "dwpre_deep", "p3_blocks", "p3_stage", "f16x3_persist_s2"};
+static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1};      // p3_stage: off (measured slower); kept for the record and its test
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
         const char *e = getenv(kOptEnv[which]);

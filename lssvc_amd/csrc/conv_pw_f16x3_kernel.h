@@ -716,161 +716,6 @@ static int launch_pw_allm_f16x3(const ConvP &p, hipStream_t st) {
     return launch_status("conv2d(pw all-M f16x3)");
 }
 
-// ---- "X-stationary" variant for large K on SMALL maps (the prior chain at 72x120: 1x1 convs with K, M = 256 .. 1024 on 8640
-// pixels; round 4). The K-sliced kernel above gives every M tile its own workgroups, so the pixels of a group are loaded and split
-// to fp16 hi / lo once per M tile (6x at M = 384), each workgroup stages its weight slices through registers between two barriers,
-// and a launch is a chain of such steps on fewer waves than the chip has SIMDs: 32-75 us for 2.5-6.8 GFLOP. Here the roles are
-// swapped: a wave keeps the split fragments of ONE 16-pixel group for all of K in registers (K / 32 x 8 registers; one wave per
-// SIMD, 512 registers) and walks over ALL output channels in groups of 64, while the workgroup's four waves stream the weights of
-// every (M group, 64-channel K block) through a ring of 16 KiB LDS slots by LDS-DMA (each slot is 16 contiguous 1-KiB runs of the
-// host layout [plane][chunk16][m][16]). Pixels are read and converted once, weights never pass through registers, one barrier per
-// slot. Per accumulator the K steps and the three products of a step come in the same order as in the other 1x1 kernels:
-// results are bit-identical to them.
-constexpr int kPwxRing = 6;                 // slots of 16 KiB: the DMA runs up to four slots ahead of the MFMAs
-template <int KSTEPS_MAX>
-__global__ __launch_bounds__(256, 1) void conv_pwx_f16x3_kernel(const ConvP p) {
-    constexpr int MG = 64, SLOT_HALFS = 2 * 4 * MG * CK16;          // [plane][chunk 4][m 64][16]
-    extern __shared__ __attribute__((aligned(16))) _Float16 ring[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int li = lane & 15;
-    const int lg = lane >> 4;
-    const int tsel = lg >> 1;
-    const int ch8 = (lg & 1) * 8;
-    const int nchunk = p.n_chunks16;
-    const int nstep = (nchunk + 1) >> 1;
-    const int nkb = (nstep + 1) >> 1;                                // 64-channel K blocks = slots per M group
-    const int ngrp = (p.M_pad + MG - 1) / MG;
-    const int nslots = ngrp * nkb;
-    const float in_slope = p.in_act == LSSVC_INACT_LRELU ? p.in_slope : 1.0f;
-    const long long npix = (long long)p.Hout * p.Wout;
-    const long long grp = (long long)blockIdx.x * 4 + wave;          // this wave's 16-pixel group (may be past the end: it still helps with the DMA)
-    long long pix[1];
-    {
-        const long long q = grp * 16 + li;
-        pix[0] = q < npix ? q : -1;
-    }
-    const size_t poff = (size_t)(pix[0] >= 0 ? pix[0] : 0);
-    const int n0 = (p.in[0].C + 15) >> 4, n1 = p.n_in > 1 ? (p.in[1].C + 15) >> 4 : 0;
-    const _Float16 *g_w = reinterpret_cast<const _Float16 *>(p.w16);
-
-    // slot t = (M group g, K block kb) -> ring slot t % kPwxRing: 16 pieces of 1 KiB, four per wave
-    auto issue_slot = [&](int t) {
-        const int g = t / nkb, kb = t - g * nkb;
-        unsigned char *dst = reinterpret_cast<unsigned char *>(ring + (size_t)(t % kPwxRing) * SLOT_HALFS);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = wave * 4 + q;                              // piece: plane j / 8, chunk (j % 8) / 2 of the block, m half j % 2
-            const int plane = j >> 3, c = (j & 7) >> 1, mh = j & 1;
-            int chunk = 4 * kb + c;
-            if (chunk >= nchunk) chunk = nchunk - 1;                 // past K: any finite bytes, they meet zero pixels
-            int m = g * MG + mh * 32 + (lane >> 1);
-            if (m >= p.M_pad) m = p.M_pad - 1;                       // past M_pad: masked by the epilogue
-            const _Float16 *src = g_w + (size_t)plane * p.w16_plane + ((size_t)chunk * p.M_pad + m) * CK16 + (lane & 1) * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
-        }
-    };
-    // the pixel fragments of K step s: loaded, activated, split
-    f16x8 xh[KSTEPS_MAX], xl[KSTEPS_MAX];
-    auto load_x = [&](int s, float4 (&raw)[2], int &left8) {
-        int c = 2 * s + tsel;
-        const bool in_range = c < nchunk;
-        c = in_range ? c : nchunk - 1;
-        const bool s1 = c >= n0, s2 = c >= n0 + n1;
-        const float *base = s2 ? p.in[2].p : (s1 ? p.in[1].p : p.in[0].p);
-        const int ld = s2 ? p.in[2].ld : (s1 ? p.in[1].ld : p.in[0].ld);
-        const int cseg = s2 ? p.in[2].C : (s1 ? p.in[1].C : p.in[0].C);
-        const int c0 = (c - (s2 ? n0 + n1 : (s1 ? n0 : 0))) * 16;
-        const int avail = cseg - c0 - ch8;
-        left8 = in_range ? avail : 0;
-        const float *src = base + poff * ld + (avail > 0 ? c0 + ch8 : 0);
-        raw[0] = *reinterpret_cast<const float4 *>(src);
-        raw[1] = *reinterpret_cast<const float4 *>(src + (avail > 4 ? 4 : 0));
-    };
-    auto split_x = [&](const float4 (&raw)[2], int left8, f16x8 &h, f16x8 &l) {
-        const float v[8] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float x = (pix[0] >= 0 && j < left8) ? v[j] : 0.f;
-            x = fmaxf(x, in_slope * x);
-            x = fminf(fmaxf(x, -65504.f), 65504.f);
-            const _Float16 hh = (_Float16)x;
-            h[j] = hh;
-            l[j] = (_Float16)(x - (float)hh);
-        }
-    };
-
-    // prologue: the first slots' DMA, then all of this group's pixels (K / 32 steps) -- converted while the first weights arrive
-#pragma unroll
-    for (int t = 0; t < kPwxRing - 2; ++t)
-        if (t < nslots) issue_slot(t);
-#pragma unroll
-    for (int s = 0; s < KSTEPS_MAX; ++s) {
-        if (s < nstep) {
-            float4 raw[2];
-            int left8;
-            load_x(s, raw, left8);
-            split_x(raw, left8, xh[s], xl[s]);
-        }
-    }
-    for (int g = 0; g < ngrp; ++g) {
-        f32x4 acc[4][1];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < KSTEPS_MAX / 2; ++kb) {                // (unrolled: the pixel fragments are indexed by compile-time constants)
-            if (kb < nkb) {
-                const int t = g * nkb + kb;
-                // this wave's pieces of slot t have landed (younger ones, of up to kPwxRing - 3 later slots, may still be in flight), then
-                // everybody's; the barrier also says every wave is done with slot t - 1, whose ring slot the next DMA overwrites
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kPwxRing - 3)) : "memory");
-                __syncthreads();
-                if (t + kPwxRing - 2 < nslots) issue_slot(t + kPwxRing - 2);
-                const _Float16 *wh = ring + (size_t)(t % kPwxRing) * SLOT_HALFS;
-                const _Float16 *wl = wh + 4 * MG * CK16;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int s = 2 * kb + u;
-                    if (s < nstep) {
-                        f16x8 ah[4], al[4];
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) {
-                            const int o = ((2 * u + tsel) * MG + f * 16 + li) * CK16 + ch8;
-                            ah[f] = *reinterpret_cast<const f16x8 *>(wh + o);
-                            al[f] = *reinterpret_cast<const f16x8 *>(wl + o);
-                        }
-                        const f16x8 bh = xh[s < KSTEPS_MAX ? s : 0], bl = xl[s < KSTEPS_MAX ? s : 0];
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh, acc[f][0], 0, 0, 0);
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl, acc[f][0], 0, 0, 0);
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) acc[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh, acc[f][0], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        conv_unscale<4, 1>(p, acc);
-        conv_epilogue_flat<4, 1, false>(p, acc, pix, [&](int r, int col) { const long long q = grp * 16 + col; return q < npix ? q : -1LL; }, g * MG, lg);
-    }
-}
-
-template <int KSTEPS_MAX>
-static int launch_pwx_f16x3(const ConvP &p, hipStream_t st) {
-    ConvP q = p;
-    q.m_tiles = (p.M_pad + 63) / 64;
-    const size_t lds = (size_t)kPwxRing * 2 * 4 * 64 * CK16 * sizeof(_Float16);        // 96 KiB
-    static LdsGrant grant;
-    if (grant.ensure(reinterpret_cast<const void *>(conv_pwx_f16x3_kernel<KSTEPS_MAX>), lds)) return 1;
-    const long long npix = (long long)p.Hout * p.Wout;
-    const long long blocks = ((npix + 15) / 16 + 3) / 4;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return fail("conv2d(pwx f16x3): bad grid %lld", blocks);
-    hipLaunchKernelGGL((conv_pwx_f16x3_kernel<KSTEPS_MAX>), dim3((unsigned)blocks), dim3(256), lds, st, q);
-    return launch_status("conv2d(pwx f16x3)");
-}
-
 int dispatch_pw_f16x3(const ConvP &p, hipStream_t st, char *kernel_name);
 
 }  // namespace lssvc

@@ -437,56 +437,6 @@ def test_conv1x1_f16x3_matches_fp64(hip, cins, cout, H, W):
     assert e16 <= 8 * e32 + 1e-6, (e16, e32)
 
 
-@pytest.mark.parametrize("cins,cout,H,W,in_act,act,residual", [
-    ([384], 384, 72, 120, None, None, False),            # the 4-step prior's adaptor / DepthConv 1x1s
-    ([1024], 384, 72, 120, None, "lrelu", False),        # ConvFFN second half: 32 K steps
-    ([384], 1024, 36, 60, "lrelu", None, False),         # ConvFFN first half: 16 M groups
-    ([128, 256], 384, 35, 41, None, None, True),         # two-input concat, odd pixel count (ragged last group), residual
-    ([256, 128, 128], 208, 20, 36, "lrelu", "lrelu", False),   # three inputs, M_pad = 208: a partial last M group
-])
-def test_conv1x1_x_stationary_kernel(hip, cins, cout, H, W, in_act, act, residual):
-    """conv_pwx_f16x3_kernel (large K on small maps: pixels stationary in registers, every weight streamed through LDS by DMA)
-    against fp64, and bit for bit against the K-sliced kernel it replaces (option pw_x_stationary = 0): per accumulator the K
-    steps and the three products of a step come in the same order."""
-    import ctypes as C
-    from lssvc_amd._lib import lib, check
-    g = torch.Generator().manual_seed(sum(cins) + cout)
-    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
-    cin = sum(cins)
-    w = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
-    b = torch.randn(cout, generator=g)
-    r = torch.randn(1, cout, H, W, generator=g) if residual else None
-    x64 = torch.cat(xs, 1).double()
-    if in_act:
-        x64 = F.leaky_relu(x64, 0.1)
-    ref = F.conv2d(x64, w.double(), b.double())
-    if act:
-        ref = F.leaky_relu(ref, 0.01)
-    if residual:
-        ref = ref + r.double()
-    Wt = FakeW({"c.weight": w, "c.bias": b})
-    out, names = {}, {}
-    old = C.c_int32()
-    check(lib.lssvc_get_option(b"pw_x_stationary", C.byref(old)))
-    try:
-        hip.set_conv_precision("f16x3")
-        for on in (1, 0):
-            check(lib.lssvc_set_option(b"pw_x_stationary", on))
-            hip.OP_LOG = []
-            out[on] = back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], in_act=in_act, in_slope=0.1, act=act, slope=0.01,
-                                    residual=nhwc(hip, r) if residual else None))
-            names[on] = hip.OP_LOG[-1]["kernel"]
-    finally:
-        hip.OP_LOG = None
-        hip.set_conv_precision("f32")
-        check(lib.lssvc_set_option(b"pw_x_stationary", old.value))
-    assert names[1].startswith("conv_pwx_f16x3_kernel") and not names[0].startswith("conv_pwx"), names
-    assert torch.equal(out[1], out[0]), (out[1] - out[0]).abs().max().item()
-    got32 = back(hip.conv(Wt, "c", [nhwc(hip, x) for x in xs], in_act=in_act, in_slope=0.1, act=act, slope=0.01, residual=nhwc(hip, r) if residual else None))
-    e16, e32 = (out[1].double() - ref).abs().max().item(), (got32.double() - ref).abs().max().item()
-    assert e16 <= 8 * e32 + 1e-6, (e16, e32)
-
-
 def test_subpel1x1_f16x3(hip):
     g = torch.Generator().manual_seed(33)
     x = torch.randn(1, 128, 12, 20, generator=g)

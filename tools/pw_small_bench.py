@@ -1,4 +1,4 @@
-"""1x1 convs with large K on small maps (the prior networks): python tools/pw_small_bench.py  (env LSSVC_PWKS_SMALL=0/1, LSSVC_PWX=0/1)"""
+"""1x1 convs with large K on small maps (the prior networks): python tools/pw_small_bench.py  (env LSSVC_PWKS_SMALL=0/1)"""
 import math
 import os
 import sys
