@@ -368,9 +368,9 @@ static int launch_pwk_f16x3(const ConvP &p, hipStream_t st) {
 // slice every 8 steps (two barriers), while each wave owns ONE 64-pixel group whose MF x 4 accumulators live in
 // registers across all slices; the X ring prefetch runs straight through the slice boundaries. One group per wave,
 // no persistence: meant for launches with few pixel groups.
-template <int MF, bool MULTI, int RPW = 4, int D = 2>
+template <int MF, bool MULTI, int RPW = 4>
 __global__ __launch_bounds__(256, 2) void conv_pwks_f16x3_kernel(const ConvP p) {
-    constexpr int TM = 16 * MF, SLICE_STEPS = 8, SLICE_SLOTS = 2 * SLICE_STEPS;      // D: X steps in flight per wave (register ring)
+    constexpr int TM = 16 * MF, D = 2, SLICE_STEPS = 8, SLICE_SLOTS = 2 * SLICE_STEPS;      // D: X steps in flight per wave (rings of 4 and 8 measured 7-25 % slower, profiles/r04_pwks_ring_ab.txt)
     extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];     // [hi|lo][slot in slice][TM][16]
     constexpr int plane = SLICE_SLOTS * TM * CK16;
     const int tid = threadIdx.x;
@@ -407,20 +407,57 @@ __global__ __launch_bounds__(256, 2) void conv_pwks_f16x3_kernel(const ConvP p) 
     auto stage_slice = [&](int s0) {                       // weights of K-steps s0 .. s0+7 for this M tile
         const _Float16 *g_h = reinterpret_cast<const _Float16 *>(p.w16);
         const _Float16 *g_l = g_h + p.w16_plane;
-        for (int idx = tid; idx < SLICE_SLOTS * TM * 2; idx += 256) {
-            const int c = idx / (TM * 2);
-            const int r = idx - c * (TM * 2);
-            const int m = r >> 1, half = r & 1;
-            const int cg = 2 * s0 + c;
-            f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (cg < nchunk && m0 + m < p.M_pad) {
-                const size_t o = ((size_t)cg * p.M_pad + m0 + m) * CK16 + half * 8;
-                h = *reinterpret_cast<const f16x8 *>(g_h + o);
-                l = *reinterpret_cast<const f16x8 *>(g_l + o);
+        // SLICE_SLOTS * TM * 2 sixteen-byte items per plane = TM / 8 per thread, in batches of four whose eight loads go out
+        // together: as a run-time loop (load, load, wait, store, store per item) this was eight serial L2 round trips per slice,
+        // most of what a launch on a 72x120 map took
+        constexpr int NIT = SLICE_SLOTS * TM * 2 / 256, NB = NIT < 4 ? NIT : 4;
+        static_assert(SLICE_SLOTS * TM * 2 % 256 == 0, "slice items per thread");
+        if constexpr (RPW >= 4 && MF >= 4) {               // (the 64-pixel MF = 4 variant is at its register limit: item by item, as before)
+            for (int idx = tid; idx < SLICE_SLOTS * TM * 2; idx += 256) {
+                const int c = idx / (TM * 2);
+                const int r = idx - c * (TM * 2);
+                const int m = r >> 1, half = r & 1;
+                const int cg = 2 * s0 + c;
+                f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (cg < nchunk && m0 + m < p.M_pad) {
+                    const size_t o = ((size_t)cg * p.M_pad + m0 + m) * CK16 + half * 8;
+                    h = *reinterpret_cast<const f16x8 *>(g_h + o);
+                    l = *reinterpret_cast<const f16x8 *>(g_l + o);
+                }
+                const int d = (c * TM + m) * CK16 + half * 8;
+                *reinterpret_cast<f16x8 *>(wlds + d) = h;
+                *reinterpret_cast<f16x8 *>(wlds + plane + d) = l;
             }
-            const int d = (c * TM + m) * CK16 + half * 8;
-            *reinterpret_cast<f16x8 *>(wlds + d) = h;
-            *reinterpret_cast<f16x8 *>(wlds + plane + d) = l;
+            return;
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < NIT; i0 += NB) {
+            f16x8 h[NB], l[NB];
+            bool ok[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = tid + (i0 + j) * 256;
+                const int c = idx / (TM * 2);
+                const int r = idx - c * (TM * 2);
+                const int m = r >> 1, half = r & 1;
+                const int cg = 2 * s0 + c;
+                ok[j] = i0 + j < NIT && cg < nchunk && m0 + m < p.M_pad;
+                const size_t o = ok[j] ? ((size_t)cg * p.M_pad + m0 + m) * CK16 + half * 8 : 0;
+                h[j] = *reinterpret_cast<const f16x8 *>(g_h + o);
+                l[j] = *reinterpret_cast<const f16x8 *>(g_l + o);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (i0 + j >= NIT) break;
+                const int idx = tid + (i0 + j) * 256;
+                const int c = idx / (TM * 2);
+                const int r = idx - c * (TM * 2);
+                const int m = r >> 1, half = r & 1;
+                const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int d = (c * TM + m) * CK16 + half * 8;
+                *reinterpret_cast<f16x8 *>(wlds + d) = ok[j] ? h[j] : z;
+                *reinterpret_cast<f16x8 *>(wlds + plane + d) = ok[j] ? l[j] : z;
+            }
         }
     };
     float4 raw[D][RPW][2];
@@ -526,14 +563,7 @@ static int launch_pwks_f16x3(const ConvP &p, hipStream_t st) {
     const long long ngroups = small ? (npix + 31) / 32 : (npix + 63) / 64;
     const long long blocks = ((ngroups + 3) / 4) * q.m_tiles;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return fail("conv2d(pwks f16x3): bad grid %lld", blocks);
-    static const int ring = getenv("LSSVC_PWKS_RING") ? atoi(getenv("LSSVC_PWKS_RING")) : 2;       // experiment: deeper X prefetch on the small maps
-    if (small && ring == 4) {
-        if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true, 2, 4>), dim3((unsigned)blocks), dim3(256), lds, st, q);
-        else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false, 2, 4>), dim3((unsigned)blocks), dim3(256), lds, st, q);
-    } else if (small && ring == 8) {
-        if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true, 2, 8>), dim3((unsigned)blocks), dim3(256), lds, st, q);
-        else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false, 2, 8>), dim3((unsigned)blocks), dim3(256), lds, st, q);
-    } else if (small) {
+    if (small) {
         if (p.n_in > 1) hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, true, 2>), dim3((unsigned)blocks), dim3(256), lds, st, q);
         else hipLaunchKernelGGL((conv_pwks_f16x3_kernel<MF, false, 2>), dim3((unsigned)blocks), dim3(256), lds, st, q);
     } else {

@@ -398,14 +398,23 @@ __global__ __launch_bounds__(kFfnThreads, 1) void ffn_stream_f16x3_kernel(const 
         if (PRE) {
 #pragma unroll
             for (int f = 0; f < CF; ++f) o1[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // all K steps' loads first, unconditionally (steps past p.sa re-read step 0 and are not used): inside the run-time
+            // `if (s < p.sa)` the compiler waited vmcnt(0) after every step's loads, four to eight serial round trips per pass
+            float4 pr0[SA_MAX], pr1[SA_MAX];
+#pragma unroll
+            for (int s = 0; s < SA_MAX; ++s) {
+                const int c0 = 32 * (s < p.sa ? s : 0) + 8 * lg;
+                const int left = p.pre_in.C - c0;
+                const float *tp = p.pre_in.p + (size_t)q * p.pre_in.ld + (left > 0 ? c0 : 0);
+                pr0[s] = *reinterpret_cast<const float4 *>(tp);
+                pr1[s] = *reinterpret_cast<const float4 *>(tp + (left > 4 ? 4 : 0));
+            }
 #pragma unroll
             for (int s = 0; s < SA_MAX; ++s) {
                 if (s < p.sa) {
                     const int c0 = 32 * s + 8 * lg;
                     const int left = p.pre_in.C - c0;
-                    const float *tp = p.pre_in.p + (size_t)q * p.pre_in.ld + (left > 0 ? c0 : 0);
-                    const float4 r0 = *reinterpret_cast<const float4 *>(tp);
-                    const float4 r1 = *reinterpret_cast<const float4 *>(tp + (left > 4 ? 4 : 0));
+                    const float4 r0 = pr0[s], r1 = pr1[s];
                     const float raw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
                     float v[8];
 #pragma unroll
