@@ -70,35 +70,50 @@ class HostFrames:
         return x_bl, x_el
 
 
-EVENT_FRAMES = 8      # per-launch HIP events are sampled on P-frames 1..8 of the last timed GOP only: the event markers cost
+EVENT_FRAMES = 8      # per-launch HIP events are sampled on the last 8 P-frames of the last timed GOP only: the event markers cost
 #                       ~2.5 % of stream time when put around every launch, and 8 P-frames (31 of a GOP's 32 frames are
 #                       P-frames, so this is the GOP's launch mix) already hold >650 launches of the dominant kernel
 
 
-def encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log=None, host_frames=None):
+LOOKAHEAD = True      # P-frames name the next frame's base-layer input: BL(t+1) is coded beside EL(t) (LSSVC_extend.forward_one_frame)
+
+
+def encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log=None, host_frames=None, lookahead=None):
     """test.py's frame loop (test.py:182-250) for one GOP: I-frame, then P-frames chained through the DPB.
-    op_log: list that receives the per-launch records (with HIP events) of P-frames 1..EVENT_FRAMES.
-    host_frames: a HostFrames -- take every frame from host memory instead of the resident x_bls / x_els."""
+    op_log: list that receives the per-launch records (with HIP events) of the last EVENT_FRAMES P-frames.
+    host_frames: a HostFrames -- take every frame from host memory instead of the resident x_bls / x_els.
+    lookahead (default: LOOKAHEAD): the loop knows the next frame, so it hands its base-layer input to the P-frame call."""
     from lssvc_amd import hip_ops
+    lookahead = LOOKAHEAD if lookahead is None else lookahead
     bits = []
     dpb = None
     n = len(host_frames) if host_frames is not None else len(x_els)
     graph, streams = pnet.graph_mode, hip_ops.MULTI_STREAM
+    ahead_layers = None               # host_frames: frame t+1's layers, made one frame early for its base-layer input
     for t in range(n):
-        logging = op_log is not None and 1 <= t <= EVENT_FRAMES
+        first_logged = max(1, n - EVENT_FRAMES)           # the LAST EVENT_FRAMES P-frames: behind them nothing needs a plan the
+        logging = op_log is not None and t >= first_logged      # look-ahead GOPs never use (the whole-frame steady-P plan)
         hip_ops.OP_LOG = op_log if logging else None
         pnet.graph_mode = graph and not logging        # per-launch events need the eager path for these frames ...
         hip_ops.MULTI_STREAM = streams and not logging # ... and one stream: a launch timed beside another stream's kernels
         #                                                measures the contention, not the kernel
         inet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
         pnet.set_scale_information(RATIO, shape_hr, (0, 0, 0, 0))
-        x_bl, x_el = host_frames.layers(t) if host_frames is not None else (x_bls[t], x_els[t])
+        if host_frames is not None:
+            x_bl, x_el = ahead_layers if ahead_layers is not None else host_frames.layers(t)
+            ahead_layers = host_frames.layers(t + 1) if (lookahead and t >= 1 and t + 1 < n) else None
+            next_bl = ahead_layers[0] if ahead_layers is not None else None
+        else:
+            x_bl, x_el = x_bls[t], x_els[t]
+            next_bl = x_bls[t + 1] if t + 1 < n else None
+        if op_log is not None and t + 1 >= max(1, n - EVENT_FRAMES):
+            next_bl = None                                  # the next frame is coded eagerly with events: no base layer ahead of it
         if t == 0:
             r = inet.encode_decode(x_bl, x_el, None, None)
             dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None,
                    "ref_feature_el": r["feature_el"]}
         else:
-            r = pnet.encode_decode(x_bl, x_el, dpb)
+            r = pnet.encode_decode(x_bl, x_el, dpb, **(dict(next_x_bl=next_bl, frame_id=t) if lookahead else {}))
             dpb = r["dpb"]
         dpb["ref_frame_bl"].clamp_(0, 1)
         dpb["ref_frame_el"].clamp_(0, 1)
@@ -386,15 +401,15 @@ def config3_2160p(device, gop=12):
         x_bls, x_els, pad, _ = build_inputs(device, seed=5, frames=gop)
         shape_hr = pad["HR_padded_size"]
         with torch.no_grad():
-            encode_gop(inet, pnet, x_bls, x_els, shape_hr)                  # eager first calls of the three frame types; steady-P captured
-            encode_gop(inet, pnet, x_bls, x_els, shape_hr)                  # I and first-P captured (a plan is captured on its SECOND call)
+            encode_gop(inet, pnet, x_bls, x_els, shape_hr, lookahead=False)                  # eager first calls of the three frame types; steady-P captured
+            encode_gop(inet, pnet, x_bls, x_els, shape_hr, lookahead=False)                  # I and first-P captured (a plan is captured on its SECOND call)
             torch.cuda.synchronize()
             t0 = time.time()
-            bits, _ = encode_gop(inet, pnet, x_bls, x_els, shape_hr)
+            bits, _ = encode_gop(inet, pnet, x_bls, x_els, shape_hr, lookahead=False)
             torch.cuda.synchronize()
             dt = time.time() - t0
             op_log = []
-            encode_gop(inet, pnet, x_bls[:1 + EVENT_FRAMES], x_els[:1 + EVENT_FRAMES], shape_hr, op_log)
+            encode_gop(inet, pnet, x_bls[:1 + EVENT_FRAMES], x_els[:1 + EVENT_FRAMES], shape_hr, op_log, lookahead=False)
             torch.cuda.synchronize()
         roof, _ = roofline_from_log(op_log)
         for k in ("traffic", "mfma_busy"):
@@ -523,6 +538,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events in the last timed step")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying hipGraph frame plans")
     ap.add_argument("--no-streams", action="store_true", help="one stream: no parallel branches in the frame plans (same as LSSVC_STREAMS=0)")
+    ap.add_argument("--no-lookahead", action="store_true", help="code BL(t+1) after EL(t), not beside it (the plain per-frame protocol of test.py)")
     ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop (per-frame H2D + pre-processing included)")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline at the full 1152x1920 size, 1 I + 2 P (takes > 7 min on a 16-core host share)")
     ap.add_argument("--no-side-configs", action="store_true", help="skip the configs[3] (2160p IP12) and configs[4] (write_stream=1) side measurements")
@@ -571,6 +587,8 @@ def main():
     from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
     if args.precision:
         hip_ops.set_conv_precision(args.precision)
+    if args.no_lookahead:
+        globals()["LOOKAHEAD"] = False
     if args.no_streams:
         hip_ops.MULTI_STREAM = False
     from lssvc_amd.synth import synth_state_dict
@@ -606,6 +624,16 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        if LOOKAHEAD and hip_ops.MULTI_STREAM and not args.no_graph:
+            # set-up, before the W warm-up steps: the frame-after-frame plans (two GOPs: eager first calls with their fp16 range audit,
+            # then the captures) -- the event-sampled frames of the last timed step and the look-ahead self-check use them -- and the
+            # eager first calls of the look-ahead plans, so that the first warm-up step captures those and the timed steps only replay
+            t0 = time.time()
+            for la in (False, False, True):
+                encode_gop(inet, pnet, x_bls, x_els, shape_hr, lookahead=la)
+            torch.cuda.synchronize()
+            if rank == 0:
+                log("frame plans primed in %.2f s (2 GOPs frame after frame, 1 with look-ahead)" % (time.time() - t0))
         for w in range(args.warmup):
             t0 = time.time()
             encode_gop(inet, pnet, x_bls, x_els, shape_hr)
@@ -622,6 +650,25 @@ def main():
             bits, _ = encode_gop(inet, pnet, x_bls, x_els, shape_hr, op_log)
         sync_all()
         dt = time.time() - t_start
+        # look-ahead self-check: the timed GOPs' bit counts against one GOP coded frame after frame (untimed). A mismatch voids the
+        # look-ahead number: the timed loop is then repeated without it.
+        lookahead_check = None
+        if LOOKAHEAD and hip_ops.MULTI_STREAM:
+            plain_bits, _ = encode_gop(inet, pnet, x_bls, x_els, shape_hr, lookahead=False)
+            sync_all()
+            lookahead_check = bool(plain_bits == bits)
+            if not lookahead_check:
+                log("!! look-ahead bits differ from the plain protocol's: timing again without look-ahead")
+                globals()["LOOKAHEAD"] = False
+                for _ in range(2):
+                    encode_gop(inet, pnet, x_bls, x_els, shape_hr)
+                sync_all()
+                t_start = time.time()
+                for k in range(args.steps):
+                    bits, _ = encode_gop(inet, pnet, x_bls, x_els, shape_hr)
+                sync_all()
+                dt = time.time() - t_start
+                op_log = None
         # the same GOP with per-frame H2D + pre-processing inside the clock (reported beside `value`, never as it)
         dt_incl, incl_steps = None, 0
         if not args.no_h2d_pass:
@@ -665,6 +712,9 @@ def main():
                         "(6.2 MB), u8 -> fp32, zero padding to 1152x1920, MATLAB-bicubic BL 576x960 (HIP kernels, csrc/prepost.hip), "
                         "encode, D2H of the bit counts (BASELINE.md section 3 'GPU side')",
                 "bits_equal_resident_run": bool(bits_incl == bits)}
+        out["lookahead"] = {"on": bool(LOOKAHEAD and hip_ops.MULTI_STREAM), "bits_equal_frame_after_frame_run": lookahead_check,
+                            "what": "the frame loop hands frame t+1's base-layer input to the call of frame t (LSSVC_extend.forward_one_frame, "
+                                    "frame_id / next_x_bl): BL(t+1) is coded on a second stream beside EL(t); same launches, bit-identical results"}
         pel = HEIGHT * WIDTH
         out["bpp_check"] = {"i_frame_bpp_el": round(bits[0][1] / pel, 5),
                             "p_frame_bpp_el_mean": round(sum(b[1] for b in bits[1:]) / max(1, len(bits) - 1) / pel, 5)}
@@ -673,8 +723,8 @@ def main():
             out["roofline"] = roof
             out["roofline_by_kernel"] = table[:6]
             # progress outside the dominant kernel: ALGORITHMIC conv flops of the whole GOP over the GOP's wall time. The
-            # per-P-frame figure is the sampled launches' (P-frames 1..EVENT_FRAMES; P-frame 1 lacks the feature adaptors'
-            # inputs, a < 1 % difference); the I-frame's share comes from SURVEY section 8d (5.04 TFLOP).
+            # per-P-frame figure is the sampled launches' (the GOP's last EVENT_FRAMES P-frames); the I-frame's share comes from
+            # SURVEY section 8d (5.04 TFLOP).
             p_tflop = roof["conv_tflop_sampled"] / EVENT_FRAMES
             gop_tflop = 5.04 + (args.frames - 1) * p_tflop
             ach = gop_tflop / (dt / args.steps)
@@ -682,7 +732,7 @@ def main():
                                   "peak": PEAK_FP16_MFMA_TFLOPS, "frac": round(ach / PEAK_FP16_MFMA_TFLOPS, 4),
                                   "frac_issued_fp16": round(3.0 * ach / PEAK_FP16_MFMA_TFLOPS, 4),
                                   }
-            out["timed_region_note"] = ("the last timed step issues P-frames 1..%d eagerly on one stream with a HIP event pair around "
+            out["timed_region_note"] = ("the last timed step issues its last %d P-frames eagerly on one stream with a HIP event pair around "
                                         "every launch (the roofline's live durations); that costs the headline about 1 %%" % EVENT_FRAMES)
         else:
             out["roofline"] = None

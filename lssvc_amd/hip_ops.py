@@ -67,6 +67,7 @@ import threading as _threading
 
 
 class _Tls(_threading.local):
+    fork = None           # the Fork whose branch is open (None outside branches)
     keep = None           # buffers touched while a branch is open (None outside branches); per host thread, because several
     #                       GOPs may be in flight on one GPU, each coded by its own thread on its own stream (bench.py)
 
@@ -77,12 +78,15 @@ _SIDE_STREAMS = {}        # (device, main stream) -> its side streams
 
 class _Branch:
     def __init__(self, fork, i):
-        self.fork, self.i, self.ctx = fork, i, None
+        self.fork, self.i, self.ctx, self.outer_keep = fork, i, None, None
 
     def __enter__(self):
         f = self.fork
         if f.enabled:
-            assert _TLS.keep is None, "branches do not nest"
+            # (a branch of ANOTHER Fork may be open around this one -- the look-ahead base layer runs as one branch of the frame and
+            # forks its own chains inside it: that Fork must have been made with its own `tag`, i.e. its own side streams)
+            assert _TLS.keep is None or _TLS.fork is not f, "branches of one Fork do not nest"
+            self.outer_keep, self.outer_fork = _TLS.keep, _TLS.fork
             s = f.streams[self.i]
             s.wait_stream(torch.cuda.current_stream())
             if PLAN_RECORDER is not None:
@@ -90,12 +94,13 @@ class _Branch:
             self.ctx = torch.cuda.stream(s)
             self.ctx.__enter__()
             _TLS.keep = f.keep.setdefault(self.i, [])
+            _TLS.fork = f
             f.open.add(self.i)
         return self
 
     def __exit__(self, *exc):
         if self.fork.enabled:
-            _TLS.keep = None
+            _TLS.keep, _TLS.fork = self.outer_keep, self.outer_fork
             self.ctx.__exit__(*exc)
         return False
 
@@ -106,12 +111,12 @@ class Fork:
     for that branch. A branch index may be reused after its join. Disabled (LSSVC_STREAMS=0 / enabled=False) it is a no-op
     and everything runs in program order on the current stream."""
 
-    def __init__(self, device, enabled=None, n=3):
+    def __init__(self, device, enabled=None, n=3, tag=""):
         self.enabled = MULTI_STREAM if enabled is None else bool(enabled)
         self.keep, self.open = {}, set()          # keep: branch index -> buffers its launches have touched since its last join
         if self.enabled:
             main = torch.cuda.current_stream(device)
-            key = (device.index, n, main.cuda_stream if not torch.cuda.is_current_stream_capturing() else "capture")
+            key = (device.index, n, tag, main.cuda_stream if not torch.cuda.is_current_stream_capturing() else "capture")
             if key not in _SIDE_STREAMS:
                 _SIDE_STREAMS[key] = [torch.cuda.Stream(device) for _ in range(n)]
             self.streams = _SIDE_STREAMS[key]
@@ -120,13 +125,15 @@ class Fork:
         return _Branch(self, i)
 
     def join(self, i):
-        assert _TLS.keep is None, "join from the forking stream, not from inside a branch"     # (the release below relies on it)
+        assert _TLS.keep is None or _TLS.fork is not self, "join from the forking stream, not from inside a branch of the same Fork"
         if self.enabled and i in self.open:
             torch.cuda.current_stream().wait_stream(self.streams[i])
             if PLAN_RECORDER is not None:
                 PLAN_RECORDER.wait(torch.cuda.current_stream().cuda_stream, self.streams[i].cuda_stream)
             self.open.discard(i)
-            self.keep.pop(i, None)                 # the joining stream has waited for the branch: its buffers may be recycled
+            done = self.keep.pop(i, None)          # the joining stream has waited for the branch: its buffers may be recycled ...
+            if done and _TLS.keep is not None:
+                _TLS.keep.extend(done)             # ... unless the joining stream is itself a branch (of another Fork): then with that one
 
     def close(self):
         for i in sorted(self.open):
@@ -175,6 +182,21 @@ class RangeAudit:
         return bad
 
 
+POISON_EMPTY = _os.environ.get("LSSVC_POISON_EMPTY", "0") == "1"
+GUARD_EMPTY = False
+_GUARDS = []
+
+
+def check_guards():
+    """-> [(shape, 'before' | 'after', first bad offset)] of the guarded buffers (GUARD_EMPTY) whose sentinel zones were written."""
+    bad = []
+    for whole, G, shape in _GUARDS:
+        for side, zone in (("before", whole[:G]), ("after", whole[-G:])):
+            ne = (zone != 12345.0).nonzero()
+            if ne.numel():
+                bad.append((shape, side, int(ne[0]) if side == "after" else int(ne[-1]) - G, int(ne.numel())))
+    _GUARDS.clear()
+    return bad
 ARENA = None                  # plan_compiler.Arena while a frame plan is being recorded
 PLAN_RECORDER = None          # plan_compiler.Recorder while a frame plan is being recorded (fork / join edges are reported to it)
 
@@ -191,12 +213,19 @@ class T:
     def empty(H, W, Cc, device):
         if ARENA is not None:                    # a frame plan is being compiled (plan_compiler.py): activations from ONE arena
             return T(ARENA.alloc_f32(H * W * Cc), H, W, Cc, Cc)
+        if GUARD_EMPTY:              # debugging aid: every activation buffer between two sentinel zones, checked by check_guards()
+            G = 1024
+            whole = torch.full((H * W * Cc + 2 * G,), 12345.0, dtype=torch.float32, device=device)
+            _GUARDS.append((whole, G, (H, W, Cc)))
+            return T(whole, H, W, Cc, Cc, off=G)
+        if POISON_EMPTY:             # debugging aid (LSSVC_POISON_EMPTY=1): fresh activation buffers start as NaN, so a read of
+            return T(torch.full((H * W * Cc,), float("nan"), dtype=torch.float32, device=device), H, W, Cc, Cc)      # unwritten memory shows
         return T(torch.empty(H * W * Cc, dtype=torch.float32, device=device), H, W, Cc, Cc)
 
     @staticmethod
     def zeros(H, W, Cc, device):
         t = T.empty(H, W, Cc, device)
-        check(lib.lssvc_fill_zero(C.c_void_p(t.buf.data_ptr()), 4 * H * W * Cc, stream_ptr()))     # a library launch, so plans see it
+        check(lib.lssvc_fill_zero(C.c_void_p(t.buf.data_ptr() + 4 * t.off), 4 * H * W * Cc, stream_ptr()))     # a library launch, so plans see it
         return t
 
     @property
@@ -608,8 +637,10 @@ class BitSlots:
         self.vals = torch.zeros(n, dtype=torch.float64, device=device)
         self.device = device
         words = int(lib.lssvc_reduce_workspace_bytes()) // 8
-        self._free = [torch.empty(words, dtype=torch.float64, device=device) for _ in range(8)]   # up front: none is ever
+        self._free = [torch.empty(words, dtype=torch.float64, device=device) for _ in range(16)]  # up front: none is ever
         self._ws = {}                                                                             # allocated inside a capture
+        self.lane = 0             # 1 while the look-ahead base layer is issued (inter.py): its plan is captured on the SAME capture-time
+        #                           side streams as the frame's other plan and replayed beside it, so the stream alone does not tell them apart
 
     def slot(self, i):
         return C.c_void_p(self.vals.data_ptr() + 8 * i)
@@ -617,11 +648,11 @@ class BitSlots:
     @property
     def wsp(self):
         """The reduction workspace of the CURRENT stream (reductions on different streams may run concurrently)."""
-        sid = torch.cuda.current_stream().cuda_stream
+        sid = (self.lane, torch.cuda.current_stream().cuda_stream)
         ws = self._ws.get(sid)
         if ws is None:
             if not self._free:
-                raise RuntimeError("BitSlots: more than 8 streams issued bit reductions")
+                raise RuntimeError("BitSlots: more than 16 (lane, stream) pairs issued bit reductions")
             ws = self._ws[sid] = self._free.pop()
         return C.c_void_p(ws.data_ptr())
 

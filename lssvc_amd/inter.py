@@ -29,6 +29,9 @@ class LSSVC_extend(_HostModel):
     def __init__(self):
         super().__init__()
         self._sd = None
+        self._ahead = None             # look-ahead protocol: {"for": frame id, "bits": its four BL bit counts} of the base layer coded ahead
+        self._stash = [None, None]     # ... and that base layer's tensors (STASH_KEYS), by frame parity
+        self._ahead_stream = None      # the stream BL(t+1) is launched on
 
     def load_dict(self, pretrained_dict, strict=True):
         """LSSVC.load_dict (LSSVC_net.py:141-149): strip 'module.' and load strictly."""
@@ -63,12 +66,12 @@ class LSSVC_extend(_HostModel):
             out = T.empty(scales.H, scales.W, scales.C, self.device)
         return self._pull(source, self._tables["laplace"], out, sigma=scales, idx_params=LAPLACE_IDX, mean=means, chunk_of_mask=chunk_of_mask)
 
-    def _bl_codec(self, x, ref_frame, ref_feature, sink=None, source=None, fk=None):
+    def _bl_codec(self, x, ref_frame, ref_feature, sink=None, source=None, fk=None, slot_base=0):
         """DMC base layer in one of two roles sharing every decoder-side kernel:
         encoder (x given): get_inter_layer_information (dmc_net.py:421-488) / DMCExtend.compress
         (dmc_net_extend.py:55-107, symbols pushed to `sink` in the order mv_z, mv_y, z, y);
         decoder (source given): DMCExtend.decompress (dmc_net_extend.py:109-146).
-        Estimate-mode bit slots 0..3 = y, z, mv_y, mv_z.
+        Estimate-mode bit slots slot_base + 0..3 = y, z, mv_y, mv_z (slot_base 8: the look-ahead base layer, _frame_body_ahead).
         fk: the frame's ops.Fork -- chains that do not depend on the motion-vector codec (the feature pyramid of the
         reference, later the temporal prior) are issued as parallel branches (side streams 1 and 2)."""
         W, S, p = self.W, self.slots, "base_layer_model"
@@ -91,7 +94,7 @@ class LSSVC_extend(_HostModel):
             mv_y = ops.conv(W, e + ".12", t, stride=2)
             mv_z = self._prior_encoder(p + ".mv_prior_encoder", mv_y)
             mv_z_hat = mv_z.like()
-            ops.factorized_quant_bits(mv_z, W.bit_estimator(p + ".bit_estimator_z_mv"), S, 3, z_hat=mv_z_hat)
+            ops.factorized_quant_bits(mv_z, W.bit_estimator(p + ".bit_estimator_z_mv"), S, slot_base + 3, z_hat=mv_z_hat)
             self._tap("bl_mv_z", mv_z_hat)
             if sink:
                 self._push(sink, mv_z_hat, None, tb["bl_z_mv"])
@@ -102,7 +105,7 @@ class LSSVC_extend(_HostModel):
         if not decoding:
             mv_y_hat = mv_y.like()
             mv_y_q = mv_y.like() if (sink or self.taps is not None) else None
-            ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, 2, y_q=mv_y_q, y_hat=mv_y_hat)
+            ops.laplace_quant_bits(mv_y, mv_means, mv_scales, S, slot_base + 2, y_q=mv_y_q, y_hat=mv_y_hat)
             self._tap("bl_mv_y", mv_y_q)
             if sink:
                 self._push(sink, mv_y_q, mv_scales, tb["laplace"], LAPLACE_IDX)
@@ -135,7 +138,7 @@ class LSSVC_extend(_HostModel):
             y = B.res_encoder_gdn(W, p + ".res_encoder", x, c1, c2, c3, "inter")
             z = self._prior_encoder(p + ".res_prior_encoder", y)
             z_hat = z.like()
-            ops.factorized_quant_bits(z, W.bit_estimator(p + ".bit_estimator_z"), S, 1, z_hat=z_hat)
+            ops.factorized_quant_bits(z, W.bit_estimator(p + ".bit_estimator_z"), S, slot_base + 1, z_hat=z_hat)
             self._tap("bl_z", z_hat)
             if sink:
                 self._push(sink, z_hat, None, tb["bl_z"])
@@ -152,7 +155,7 @@ class LSSVC_extend(_HostModel):
         if not decoding:
             y_hat = y.like()
             y_q = y.like() if (sink or self.taps is not None) else None
-            ops.laplace_quant_bits(y, means, scales, S, 0, y_q=y_q, y_hat=y_hat)
+            ops.laplace_quant_bits(y, means, scales, S, slot_base + 0, y_q=y_q, y_hat=y_hat)
             self._tap("bl_y", y_q)
             if sink:
                 self._push(sink, y_q, scales, tb["laplace"], LAPLACE_IDX)
@@ -458,23 +461,111 @@ class LSSVC_extend(_HostModel):
         return {"recon_bl": bl["recon"], "feature_bl": bl["feature"], "recon_el": recon_el, "feature_el": feature,
                 "mv_hat": mv_hat, "warp_frame": warp_frame}
 
+    # ---- look-ahead: the base layer of frame t+1 beside the enhancement layer of frame t ---------------------------------------
+    # The base layer of a P-frame needs the previous frame's BASE layer only (dmc_net.py:421-488: its reference frame and feature),
+    # the enhancement layer needs its own previous frame and the base layer of the SAME frame (LSSVC_net.py:445-528). So BL(t+1) and
+    # EL(t) are independent, and a caller that can name the next frame (test.py's loop can: the frames are all there) may have them
+    # in flight together: same launches, same order inside either layer, bit-identical results -- but the small-map launches and the
+    # tails of the big ones of one layer now fill with the other layer's work. They are TWO frame plans (two
+    # hipGraphs), BL(t+1) launched on a second stream and EL(t) on the caller's; forking BL(t+1)'s own side chains from a branch of
+    # one captured graph -- a fork inside a fork -- crashes hipGraph capture on this ROCm. BL(t+1) reads frame t's BL reconstruction
+    # clamped to [0,1] -- what test.py:249-250 makes of the DPB before the next frame; a caller of this mode promises that clamp --
+    # and leaves its four results in persistent buffers (self._stash, by frame parity) for the next call, which codes its EL only.
+    STASH_KEYS = ("recon", "feature", "y_hat", "mv_hat")
+
+    def _ahead_bl_body(self, t, src_parity, out_parity):
+        """BL(t+1): reference = clamp(frame t's BL reconstruction) and its feature, from the stash (src_parity) or, behind a frame
+        coded whole, from the inputs ref_recon / ref_feature; bit slots 8..11; results -> self._stash[out_parity]."""
+        src = self._stash[src_parity] if src_parity is not None else {"recon": t["ref_recon"], "feature": t["ref_feature"]}
+        rec = src["recon"]
+        n = rec.H * rec.W * rec.C
+        assert rec.ld == rec.C
+        ref = T.empty(rec.H, rec.W, rec.C, self.device)
+        torch.clamp(rec.buf.view(-1)[rec.off:rec.off + n], 0.0, 1.0, out=ref.buf.view(-1)[ref.off:ref.off + n])      # = test.py:249's clamp_(0, 1)
+        fk = ops.Fork(self.device)
+        self.slots.lane = 1                                # (its own reduction workspaces: this plan runs beside the EL's)
+        try:
+            nb = self._bl_codec(t["next_x_bl"], ref, src["feature"], fk=fk, slot_base=8)
+        finally:
+            self.slots.lane = 0
+        fk.close()
+        if self._stash[out_parity] is None:                # (first, eager call of this plan: never inside a capture)
+            assert not torch.cuda.is_current_stream_capturing()
+            self._stash[out_parity] = {k: T(torch.empty(nb[k].H * nb[k].W * nb[k].C, dtype=torch.float32, device=self.device),
+                                            nb[k].H, nb[k].W, nb[k].C, nb[k].C) for k in self.STASH_KEYS}
+        for k in self.STASH_KEYS:
+            ops.copy(nb[k], self._stash[out_parity][k])
+        return {}
+
+    def _ahead_el_body(self, t, parity):
+        """EL(t) on the base layer that was coded ahead (self._stash[parity])."""
+        bl = self._stash[parity]
+        fk, pre = self._fork_el_head(t["x_el"], t["ref_frame_el"], t["ref_feature_el"])
+        feature, recon_el, mv_hat, warp_frame = self._el_codec(t["x_el"], bl, t["ref_frame_el"], t["ref_feature_el"], fk=fk, pre=pre)
+        fk.close()
+        return {"recon_bl": bl["recon"], "feature_bl": bl["feature"], "recon_el": recon_el, "feature_el": feature,
+                "mv_hat": mv_hat, "warp_frame": warp_frame}
+
+    def _run_body(self, key, tensors, body):
+        if self.graph_mode:
+            return self._run_planned(key, tensors, body)
+        ins = {k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()}
+        return self._with_range_audit(key, lambda: body(ins))
+
     @staticmethod
     def _frame_key(tensors):
         """Frame type + sizes: first-P (no BL feature, 64-channel EL feature) and steady-P differ in their shapes."""
         return ("p",) + tuple(None if v is None else tuple(v.shape) for v in tensors.values())
 
-    def forward_one_frame(self, x_bl, x_el, ref_frame_bl, ref_frame_el, ref_feature_bl, ref_feature_el):
-        """LSSVC.forward_one_frame (LSSVC_net.py:445-528): estimate mode."""
+    def forward_one_frame(self, x_bl, x_el, ref_frame_bl, ref_frame_el, ref_feature_bl, ref_feature_el, next_x_bl=None, frame_id=None):
+        """LSSVC.forward_one_frame (LSSVC_net.py:445-528): estimate mode.
+        frame_id (an int that grows by one per frame of the sequence) switches the look-ahead protocol on (_ahead_bl_body):
+        next_x_bl is the NEXT frame's base-layer input (None behind the last frame), whose base layer is coded beside this frame's
+        enhancement layer and kept for the call with frame_id + 1. The caller clamps the DPB's reference frames to [0, 1] between
+        frames, as test.py:249-250 does. Results are those of the plain calls, bit for bit."""
         self._require_device()
         assert tuple(x_el.shape[2:]) == self.shape_hr, "x_el is %dx%d but shape_hr is %s" % (x_el.shape[2], x_el.shape[3], self.shape_hr)
         tensors = {"x_bl": x_bl, "x_el": x_el, "ref_frame_bl": ref_frame_bl, "ref_frame_el": ref_frame_el,
                    "ref_feature_bl": ref_feature_bl, "ref_feature_el": ref_feature_el}
         t_issue = time.perf_counter()
-        if self.graph_mode:
-            r = self._run_planned(self._frame_key(tensors), tensors, self._frame_body)
+        stashed = None
+        if frame_id is None or not ops.MULTI_STREAM:
+            # (single-stream mode, LSSVC_STREAMS=0, codes the frames one after the other whatever the caller offers: replayed beside
+            # each other, the LINEAR hipGraphs that mode captures corrupted each other's results on this ROCm -- the plain plans
+            # included -- while the branched ones of the default mode do not; tests/test_gpu_graph.py holds the default mode)
+            self._ahead = None
+            frame_id = None
+            r = self._run_body(self._frame_key(tensors), tensors, self._frame_body)
         else:
-            ins = {k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()}
-            r = self._with_range_audit(self._frame_key(tensors), lambda: self._frame_body(ins))
+            fid = int(frame_id)
+            stashed = self._ahead if (self._ahead is not None and self._ahead["for"] == fid) else None
+            self._ahead = None
+            main = torch.cuda.current_stream(self.device)
+            if self._ahead_stream is None:
+                self._ahead_stream = torch.cuda.Stream(self.device)      # (same priority as the caller's: a high-priority BL(t+1) costs 13 %, profiles/r04_lookahead_ab.txt)
+            side = self._ahead_stream
+            shape = lambda v: None if v is None else tuple(v.shape)
+
+            def code_ahead(src):
+                tb = {"next_x_bl": next_x_bl}
+                if src is not None:
+                    tb.update(ref_recon=src["recon_bl"].to_nchw(), ref_feature=src["feature_bl"].to_nchw())
+                key = ("p-ahead-bl", src is None, fid & 1) + tuple(shape(v) for v in tb.values())
+                side.wait_stream(main)                     # (the previous frame, the caller's clamp of the DPB; not this frame's EL)
+                with torch.cuda.stream(side):
+                    self._run_body(key, tb, lambda ins: self._ahead_bl_body(ins, (fid & 1) if src is None else None, (fid + 1) & 1))
+
+            if stashed is None:                            # no base layer coded ahead for this frame: the whole frame, then BL(t+1)
+                r = self._run_body(self._frame_key(tensors), tensors, self._frame_body)
+                if next_x_bl is not None:
+                    code_ahead(r)
+            else:
+                if next_x_bl is not None:
+                    code_ahead(None)                       # BL(t+1) first, on the side stream ...
+                te = {"x_el": x_el, "ref_frame_el": ref_frame_el, "ref_feature_el": ref_feature_el}
+                r = self._run_body(("p-ahead-el", fid & 1) + tuple(shape(v) for v in te.values()), te,
+                                   lambda ins: self._ahead_el_body(ins, fid & 1))      # ... EL(t) beside it
+            main.wait_stream(side)
         self.last_issue_s = time.perf_counter() - t_issue        # host time to put the frame on the stream (no GPU wait)
         r = {k: self._own(v) for k, v in r.items()}
         dpb = {"ref_frame_bl": r["recon_bl"].to_nchw(remember=True), "ref_feature_bl": r["feature_bl"].to_nchw(remember=True),
@@ -482,8 +573,11 @@ class LSSVC_extend(_HostModel):
         out = {"dpb": dpb, "mv_hat": r["mv_hat"].to_nchw(), "warp_frame": r["warp_frame"].to_nchw(),
                "encoding_time_EL": 0.0, "decoding_time_EL": 0.0, "encoding_time_BL": 0.0, "decoding_time_BL": 0.0}
         s = self.slots.fetch()
-        out["bit_bl"] = s[0] + s[1] + s[2] + s[3]          # y + z + mv_y + mv_z  (dmc_net.py:473)
+        b = stashed["bits"] if stashed is not None else s[0:4]
+        out["bit_bl"] = b[0] + b[1] + b[2] + b[3]          # y + z + mv_y + mv_z  (dmc_net.py:473)
         out["bit_el"] = s[4] + s[5] + s[6] + s[7]          # y + mv_y + z + mv_z  (LSSVC_net.py:508)
+        if frame_id is not None and next_x_bl is not None:
+            self._ahead = {"for": int(frame_id) + 1, "bits": s[8:12]}
         return out
 
     def encode_decode_extend(self, x_bl, x_el, dpb, output_path_bl, output_path_el):
@@ -591,12 +685,13 @@ class LSSVC_extend(_HostModel):
                         "ref_frame_el": recon_el.to_nchw(remember=True), "ref_feature_el": feature.to_nchw(remember=True)}}
 
     def encode_decode(self, x_bl, x_el, dpb, output_path_bl=None, output_path_el=None,
-                      pic_width=None, pic_height=None, pic_width_bl=None, pic_height_bl=None):
-        """LSSVC.encode_decode (LSSVC_net.py:172-185). output_path_el None <=> estimate mode."""
+                      pic_width=None, pic_height=None, pic_width_bl=None, pic_height_bl=None, next_x_bl=None, frame_id=None):
+        """LSSVC.encode_decode (LSSVC_net.py:172-185). output_path_el None <=> estimate mode (next_x_bl / frame_id: its look-ahead
+        protocol, see forward_one_frame)."""
         if output_path_el is not None:
             return self.encode_decode_extend(x_bl, x_el, dpb, output_path_bl, output_path_el)
         return self.forward_one_frame(x_bl, x_el, dpb["ref_frame_bl"], dpb["ref_frame_el"], dpb["ref_feature_bl"],
-                                      dpb["ref_feature_el"])
+                                      dpb["ref_feature_el"], next_x_bl=next_x_bl, frame_id=frame_id)
 
     def update(self, force=False):
         """LSSVC_extend.update + DMCExtend.update (LSSVC_net_extend.py:17-22, dmc_net_extend.py:49-53)."""

@@ -21,12 +21,14 @@ def _nets(seed, gain):
     return inet, pnet
 
 
-def _code(inet, pnet, x_bl, x_el, H, W, gops, frames):
-    """test.py's loop; returns per frame (bit_bl, bit_el, clones of the four DPB tensors + mv_hat)."""
+def _code(inet, pnet, x_bl, x_el, H, W, gops, frames, lookahead=False):
+    """test.py's loop; returns per frame (bit_bl, bit_el, clones of the four DPB tensors + mv_hat).
+    lookahead: the P-frames name the next frame's base-layer input (LSSVC_extend.forward_one_frame's look-ahead protocol)."""
     rows = []
     for _ in range(gops):
         dpb = None
         for t in range(frames):
+            ahead = dict(next_x_bl=(x_bl[t + 1:t + 2] if t + 1 < frames else None), frame_id=t) if lookahead else {}
             inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
             pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
             if t == 0:
@@ -34,7 +36,7 @@ def _code(inet, pnet, x_bl, x_el, H, W, gops, frames):
                 dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
                 extra = []
             else:
-                r = pnet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], dpb)
+                r = pnet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], dpb, **ahead)
                 dpb = r["dpb"]
                 extra = [r["mv_hat"].clone(), r["warp_frame"].clone()]
             dpb["ref_frame_bl"].clamp_(0, 1)
@@ -68,6 +70,39 @@ def test_graph_replay_is_bit_identical_to_eager(H, W, precision):
                 assert (a is None and b is None) or torch.equal(a, b), i
     finally:
         hip_ops.set_conv_precision(old)
+
+
+@pytest.mark.parametrize("streams", [True, False])
+def test_lookahead_base_layer_is_bit_identical(streams):
+    """BL(t+1) coded beside EL(t) (forward_one_frame's look-ahead protocol): bits and every DPB tensor of every frame equal the plain
+    loop's, eager and replayed from the look-ahead plans, with and without side streams inside the layers."""
+    from lssvc_amd import hip_ops
+    from lssvc_amd.synth import synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic
+    H, W, frames, gops = 128, 256, 6, 3
+    old = hip_ops.MULTI_STREAM
+    try:
+        hip_ops.MULTI_STREAM = streams
+        clip = synth_clip(frames, H, W, seed=5).float() / 255.0
+        x_bl, x_el = imresize_bicubic(clip, (H // 2, W // 2)).clamp_(0, 1).to(DEV), clip.to(DEV)
+        inet, pnet = _nets(3, 0.6)
+        want = _code(inet, pnet, x_bl, x_el, H, W, 1, frames)
+        got = _code(inet, pnet, x_bl, x_el, H, W, 1, frames, lookahead=True)
+        inet.set_graph_mode(True)
+        pnet.set_graph_mode(True)
+        got += _code(inet, pnet, x_bl, x_el, H, W, gops, frames, lookahead=True)     # GOP 0: eager + captures, later: replays
+        plans = [k for k in pnet._plans if str(k[0]).startswith("p-ahead")]         # BL(t+1): behind a whole frame + two parities; EL(t): two parities
+        if streams:
+            assert len(plans) == 5 and all(pnet._plans[k].graph is not None for k in plans), plans
+        else:
+            assert not plans                                                         # single-stream mode codes frame after frame (inter.py)
+        for i, (bb, be, tens) in enumerate(got):
+            wb, we, wt = want[i % frames]
+            assert (bb, be) == (wb, we), (i, bb, wb, be, we)
+            for a, b in zip(tens, wt):
+                assert (a is None and b is None) or torch.equal(a, b), i
+    finally:
+        hip_ops.MULTI_STREAM = old
 
 
 def test_graph_mode_host_time_per_frame():

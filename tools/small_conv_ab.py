@@ -25,7 +25,9 @@ def main():
     ops.set_conv_precision("f16x3")
     dev = torch.device("cuda:0")
     total = 0.0
-    for cin, cout, H, W, s in SHAPES:
+    only = os.environ.get("SMALL_CONV_ONLY")                 # e.g. "0,1,5": indices into SHAPES
+    shapes = [SHAPES[int(i)] for i in only.split(",")] if only else SHAPES
+    for cin, cout, H, W, s in shapes:
         g = torch.Generator().manual_seed(cin * 1000 + cout + H + s)
         w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
         Wt = WeightStore({"c.weight": w, "c.bias": torch.randn(cout, generator=g)}, dev)
