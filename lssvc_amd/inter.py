@@ -530,9 +530,12 @@ class LSSVC_extend(_HostModel):
         t_issue = time.perf_counter()
         stashed = None
         if frame_id is None or not ops.MULTI_STREAM:
-            # (single-stream mode, LSSVC_STREAMS=0, codes the frames one after the other whatever the caller offers: replayed beside
-            # each other, the LINEAR hipGraphs that mode captures corrupted each other's results on this ROCm -- the plain plans
-            # included -- while the branched ones of the default mode do not; tests/test_gpu_graph.py holds the default mode)
+            # (single-stream mode, LSSVC_STREAMS=0, codes the frames one after the other whatever the caller offers: with the
+            # look-ahead plans captured in that mode, replayed graphs -- the plain plans included -- gave wrong results,
+            # deterministically, and the cause was not found in the time there was (not a race: it happens with the two plans
+            # serialised; not an out-of-bounds write or an uninitialised read of the frame's launches: guard zones and NaN-filled
+            # buffers come back clean; a trivial branch in every graph does not cure it). The default mode is held by
+            # tests/test_gpu_graph.py and by bench.py's bit check on every run.)
             self._ahead = None
             frame_id = None
             r = self._run_body(self._frame_key(tensors), tensors, self._frame_body)
