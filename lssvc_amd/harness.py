@@ -182,6 +182,9 @@ def _crop(x, pad):
     return x[:, :, :x.shape[2] - pad[3], :x.shape[3] - pad[1]]
 
 
+LOOKAHEAD = os.environ.get("LSSVC_LOOKAHEAD", "1") == "1"      # estimate mode: BL(t+1) beside EL(t) (code_frames)
+
+
 # ------------------------------------------------------------------------------------------------- one GOP
 def code_frames(i_net, p_net, reader, first_frame, n_frames, gop_size, ratio, device, bin_folder=None, png_folder=None):
     """test.py:182-311 for frames [first_frame, first_frame+n): returns one record per frame. `first_frame` must sit
@@ -196,17 +199,29 @@ def code_frames(i_net, p_net, reader, first_frame, n_frames, gop_size, ratio, de
             os.makedirs(os.path.join(bin_folder, ratio, tag), exist_ok=True)
     prep = _prep(device)
     (h_bl, w_bl), (h_el, w_el) = pad["LR_size"], pad["HR_size"]
-    for frame_idx in range(first_frame, first_frame + n_frames):
+    def prepare(frame_idx):
         planes = reader.read()
         if planes is None:
             raise ValueError("sequence ends before frame %d" % frame_idx)
         # 8-bit planes up; colour conversion, padding, the bicubic base layer and the BL reference planes on the device
         # (csrc/prepost.hip): test.py:185-199
         y8, u8, v8 = (torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True) for a in planes)
-        f_el, (y_el, u_el, v_el) = prep.frame_from_yuv420(y8, u8, v8, (h_elp, w_elp))
+        f_el, yuv_el = prep.frame_from_yuv420(y8, u8, v8, (h_elp, w_elp))
         f_bl = prep.bicubic(f_el, (h_blp, w_blp))
-        y_bl, u_bl, v_bl = prep.rgb_to_yuv420(f_bl, h_bl, w_bl)
-        x_el, x_bl = f_el.to_nchw(), f_bl.to_nchw()
+        return f_el, yuv_el, f_bl, prep.rgb_to_yuv420(f_bl, h_bl, w_bl), f_el.to_nchw(), f_bl.to_nchw()
+
+    # estimate mode: a P-frame's call names the next P-frame's base-layer input, whose base layer is then coded beside this frame's
+    # enhancement layer (LSSVC_extend.forward_one_frame; results unchanged) -- the loop prepares one frame ahead
+    last = first_frame + n_frames - 1
+    ahead = None
+    for frame_idx in range(first_frame, first_frame + n_frames):
+        f_el, (y_el, u_el, v_el), f_bl, (y_bl, u_bl, v_bl), x_el, x_bl = ahead if ahead is not None else prepare(frame_idx)
+        ahead = None
+        look = {}
+        if LOOKAHEAD and bin_folder is None and p_net is not None and frame_idx % gop_size != 0:
+            if frame_idx < last and (frame_idx + 1) % gop_size != 0:
+                ahead = prepare(frame_idx + 1)
+            look = dict(next_x_bl=(ahead[5] if ahead is not None else None), frame_id=frame_idx)
         i_net.set_scale_information(scale, (h_elp, w_elp), (0, 0, 0, 0))
         bins = (None, None)
         if bin_folder is not None:
@@ -221,7 +236,7 @@ def code_frames(i_net, p_net, reader, first_frame, n_frames, gop_size, ratio, de
         else:
             p_net.set_scale_information(scale, (h_elp, w_elp), (0, 0, 0, 0))
             r = p_net.encode_decode(x_bl, x_el, dpb, bins[0], bins[1], pic_width=w_elp, pic_height=h_elp,
-                                    pic_width_bl=w_blp, pic_height_bl=h_blp)
+                                    pic_width_bl=w_blp, pic_height_bl=h_blp, **look)
             dpb = r["dpb"]
             rec["type"] = 1
             rec.update(enc_bl=r.get("encoding_time_BL", 0.0), dec_bl=r.get("decoding_time_BL", 0.0),
