@@ -163,7 +163,8 @@ int lssvc_softmax2_blend(const lssvc_view *a, const lssvc_view *b, const lssvc_v
 
 /* out = a + b (channel-sliced views allowed) -- the residual sums outside convs. */
 int lssvc_add(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, void *stream);
-/* out = in (strided copy: materialises a torch.cat slice). */
+/* out = in (strided copy: materialises a torch.cat slice). `out` may have MORE channels than `in` (same H, W): the channels `in`
+ * lacks are written as zeros -- the zero-padded 4-channel copy of an RGB / flow tensor in one launch. */
 int lssvc_copy(const lssvc_view *in, const lssvc_view *out, void *stream);
 /* out = lrelu(in, slope) (the stand-alone nn.LeakyReLU between blocks, e.g. dmc_net.py:178). */
 int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float slope, void *stream);

@@ -342,14 +342,14 @@ __global__ void softmax2_blend_kernel(V a, V b, V logits, V out, int cg, long lo
     st4(out, (size_t)pix, c, vec, r);
 }
 
-// mode 0: out = a + b ; 1: out = a ; 2: out = lrelu(a)
+// mode 0: out = a + b ; 1: out = a (out may have MORE channels than a: the extra ones are written as zeros) ; 2: out = lrelu(a)
 __global__ void binary_kernel(V a, V b, V out, int mode, float slope, int cg, long long total, int vec) {
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
     if (idx >= (unsigned)total) return;
     const unsigned pix = idx / (unsigned)cg;
     const int g = (int)(idx - pix * (unsigned)cg);
     const int c = g * 4;
-    float4 r = ld4(a, (size_t)pix, c, vec);
+    float4 r = c < a.C ? ld4(a, (size_t)pix, c, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (mode == 0) {
         const float4 q = ld4(b, (size_t)pix, c, vec);
         r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
@@ -540,7 +540,7 @@ extern "C" int lssvc_softmax2_blend(const lssvc_view *a, const lssvc_view *b, co
 static int binary(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, int mode, float slope, void *stream,
                   const char *what) {
     LSSVC_CHECK(view_ok(a) && view_ok(out) && (mode != 0 || view_ok(b)), "%s: bad views", what);
-    LSSVC_CHECK(same_shape(a, out) && (mode != 0 || same_shape(a, b)), "%s: shape mismatch", what);
+    LSSVC_CHECK((mode == 1 ? (same_hw(a, out) && out->C >= a->C) : same_shape(a, out)) && (mode != 0 || same_shape(a, b)), "%s: shape mismatch", what);
     const Items it = items_of(out);
     const int vec = vec4_ok(a) && vec4_ok(out) && (mode != 0 || vec4_ok(b));
     LSSVC_ITEMS_OK(it.total, "binary");

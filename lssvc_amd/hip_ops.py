@@ -367,9 +367,7 @@ PAD_NARROW_INPUTS = _os.environ.get("LSSVC_PAD_NARROW", "1") == "1"
 
 def pad4(t):
     """A 4-channel copy of a 1-3 channel view (extra channels zero). Not cached: the source may be rewritten in place."""
-    wide = T.zeros(t.H, t.W, 4, t.device)
-    copy(t, wide.slice(0, t.C))
-    return wide
+    return copy(t, T.empty(t.H, t.W, 4, t.device))          # one launch: lssvc_copy writes the channels the source lacks as zeros
 
 
 def conv(W, name, inputs, *, stride=1, act=None, slope=0.01, in_act=None, in_slope=0.01, residual=None,

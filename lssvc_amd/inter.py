@@ -86,12 +86,13 @@ class LSSVC_extend(_HostModel):
             est_mv = B.spynet(W, p + ".optic_flow", x, ref_frame)
             # mv_encoder (dmc_net.py:174-188)
             t, e = est_mv, p + ".mv_encoder"
+            # (the LeakyReLU(0.1) behind each ResBlock, dmc_net.py:178/182/186, is applied by the conv that reads the tensor -- its
+            # only reader -- while staging it: one launch less per stage, the same function of the same values)
             for base in (0, 4, 8):
-                t = ops.conv(W, "%s.%d" % (e, base), t, stride=2)
+                t = ops.conv(W, "%s.%d" % (e, base), t, stride=2, **(dict(in_act="lrelu", in_slope=0.1) if base else {}))
                 t = ops.gdn(W, "%s.%d" % (e, base + 1), t, "inter")
                 t = B.res_block(W, "%s.%d" % (e, base + 2), t, start_from_relu=False)
-                t = ops.lrelu(t, 0.1)
-            mv_y = ops.conv(W, e + ".12", t, stride=2)
+            mv_y = ops.conv(W, e + ".12", t, stride=2, in_act="lrelu", in_slope=0.1)
             mv_z = self._prior_encoder(p + ".mv_prior_encoder", mv_y)
             mv_z_hat = mv_z.like()
             ops.factorized_quant_bits(mv_z, W.bit_estimator(p + ".bit_estimator_z_mv"), S, slot_base + 3, z_hat=mv_z_hat)
@@ -327,10 +328,10 @@ class LSSVC_extend(_HostModel):
             t = ops.lrelu(B.res_block(W, e + ".2", t, start_from_relu=False), 0.1)
             e = "mv_encoder.encoder2"
             t = ops.gdn(W, e + ".1", ops.conv(W, e + ".0", [t, mv_ctx], stride=2), "inter")
-            t = ops.lrelu(B.res_block(W, e + ".2", t, start_from_relu=False), 0.1)
-            t = ops.gdn(W, e + ".5", ops.conv(W, e + ".4", t, stride=2), "inter")
-            t = ops.lrelu(B.res_block(W, e + ".6", t, start_from_relu=False), 0.1)
-            mv_y = ops.conv(W, e + ".8", t, stride=2)
+            t = B.res_block(W, e + ".2", t, start_from_relu=False)          # (+ LeakyReLU(0.1): applied by its one reader, as in the BL)
+            t = ops.gdn(W, e + ".5", ops.conv(W, e + ".4", t, stride=2, in_act="lrelu", in_slope=0.1), "inter")
+            t = B.res_block(W, e + ".6", t, start_from_relu=False)
+            mv_y = ops.conv(W, e + ".8", t, stride=2, in_act="lrelu", in_slope=0.1)
             mv_z = self._prior_encoder("mv_prior_encoder", mv_y)
             mv_z_hat = mv_z.like()
             ops.factorized_quant_bits(mv_z, W.bit_estimator("bit_estimator_z_mv"), S, 7, z_hat=mv_z_hat)

@@ -243,6 +243,19 @@ def test_pool_blend_add(hip):
     close(back(hip.cat(parts)), torch.cat([a, y[:, :, :16, :24], x[:, :, :16, :24]], 1), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("c,wide", [(3, 4), (2, 4), (1, 4), (4, 8), (6, 8)])
+def test_copy_widens_with_zero_channels(hip, c, wide):
+    """lssvc_copy into a view with more channels writes the extra ones as zeros (hip_ops.pad4: the 2-3 channel inputs of the f16x3
+    convs in one launch); the destination starts as NaN so that an unwritten element shows."""
+    x = torch.randn(1, c, 17, 23, generator=torch.Generator().manual_seed(c))
+    dst = hip.T(torch.full((17 * 23 * wide,), float("nan"), device=DEV), 17, 23, wide, wide)
+    got = back(hip.copy(nhwc(hip, x), dst))
+    want = torch.cat([x, torch.zeros(1, wide - c, 17, 23)], 1)
+    assert torch.equal(got, want)
+    if c < 4:
+        assert torch.equal(back(hip.pad4(nhwc(hip, x))), torch.cat([x, torch.zeros(1, 4 - c, 17, 23)], 1))
+
+
 def test_layout_roundtrip(hip):
     x = torch.randn(1, 37, 19, 45)
     t = nhwc(hip, x)
