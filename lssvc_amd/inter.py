@@ -6,6 +6,7 @@ Reference: src/models/LSSVC_net.py:12-528 (EL, `forward_one_frame` :445-528),
 src/models/dmc_net.py:159-488 (BL `DMC.get_inter_layer_information` :421-488),
 src/InterModules/lssvc_modules.py, src/InterModules/video_net_component.py.
 """
+import os
 import time
 
 import torch
@@ -17,6 +18,8 @@ from . import bitstream, tables
 from .entropy_coder import SymbolSink, SymbolSource
 from .intra import _HostModel, _channel_indexes, LAPLACE_IDX
 from .weights import strip_module_prefix, validate
+
+EL_BIND = os.environ.get("LSSVC_EL_BIND", "1") == "1"
 
 # (chunk, mask) pairs per step of the 4-step spatial/channel prior (LSSVC_net.py:361-413):
 # MASK_OF_CHUNK[step][chunk] = 2x2 position index, 0:(0,0) 1:(0,1) 2:(1,0) 3:(1,1)
@@ -32,6 +35,7 @@ class LSSVC_extend(_HostModel):
         self._ahead = None             # look-ahead protocol: {"for": frame id, "bits": its four BL bit counts} of the base layer coded ahead
         self._stash = [None, None]     # ... and that base layer's tensors (STASH_KEYS), by frame parity
         self._ahead_stream = None      # the stream BL(t+1) is launched on
+        self._el_out = [None, None]    # EL reconstruction + feature of the look-ahead plans, by frame parity (persistent)
 
     def load_dict(self, pretrained_dict, strict=True):
         """LSSVC.load_dict (LSSVC_net.py:141-149): strip 'module.' and load strictly."""
@@ -251,7 +255,7 @@ class LSSVC_extend(_HostModel):
         c1, c2, c3 = B.context_fusion(W, "context_fusion_net", ctx[0], ctx[1], ctx[2])
         return c1, c2, c3, warpframe
 
-    def _unet(self, p, x):
+    def _unet(self, p, x, out=None):
         """UNet (lssvc_modules.py:295-336)."""
         W = self.W
         x1 = B.depth_conv_block(W, p + ".conv1", x)
@@ -260,7 +264,7 @@ class LSSVC_extend(_HostModel):
         for i in range(4):
             x3 = B.depth_conv_block(W, "%s.context_refine.%d" % (p, i), x3)
         d3 = B.depth_conv_block(W, p + ".up_conv3", [x2, ops.subpel(W, p + ".up3", x3)])
-        return B.depth_conv_block(W, p + ".up_conv2", [x1, ops.subpel(W, p + ".up2", d3)])
+        return B.depth_conv_block(W, p + ".up_conv2", [x1, ops.subpel(W, p + ".up2", d3)], out=out)
 
     def _four_part_prior(self, y, common, sink=None, source=None):
         """LSSVC.forward_four_part_prior (LSSVC_net.py:338-443) / compress_four_part_prior (write=True) /
@@ -287,7 +291,7 @@ class LSSVC_extend(_HostModel):
                 self._push(sink, y_q, s_hat, self._tables["laplace"], LAPLACE_IDX, chunk_of_mask=CHUNK_OF_MASK[step])
         return y_q, y_hat, s_hat
 
-    def _el_codec(self, xe, bl, ref_el, feat_el, sink=None, source=None, fk=None, pre=None):
+    def _el_codec(self, xe, bl, ref_el, feat_el, sink=None, source=None, fk=None, pre=None, out=None):
         """LSSVC enhancement layer; `bl` = base-layer outputs {feature, mv_hat, y_hat} (encoder-side in estimate
         mode, DECODED in write mode, LSSVC_net_extend.py:143-147). Encoder: forward_one_frame
         (LSSVC_net.py:458-508) / compress (LSSVC_net_extend.py:24-84, symbols pushed in the order mv_z, mv_y, z,
@@ -437,8 +441,9 @@ class LSSVC_extend(_HostModel):
         # ReconGeneration (lssvc_modules.py:279-292), called as (recon_image_feature, context1) (LSSVC_net.py:492)
         p = "recon_generation_net"
         f = ops.conv(W, p + ".first_conv", [res, c1])
-        feature = self._unet(p + ".unet_2", self._unet(p + ".unet_1", f))
-        recon_el = ops.conv(W, p + ".recon_conv", feature)
+        out = out or {}                                    # (look-ahead plans: the two results the next frame reads, written in place)
+        feature = self._unet(p + ".unet_2", self._unet(p + ".unet_1", f), out=out.get("feature"))
+        recon_el = ops.conv(W, p + ".recon_conv", feature, out=out.get("recon"))
         return feature, recon_el, mv_hat, warp_frame
 
     # ---------------------------------------------------------------------------------------------
@@ -499,10 +504,20 @@ class LSSVC_extend(_HostModel):
         return {}
 
     def _ahead_el_body(self, t, parity):
-        """EL(t) on the base layer that was coded ahead (self._stash[parity])."""
+        """EL(t) on the base layer that was coded ahead (self._stash[parity]). Its reconstruction and feature -- the next frame's
+        references -- go to persistent buffers by frame parity (self._el_out); when the caller hands exactly those back as this
+        frame's references (test.py's loop does: the DPB), they are read where they are instead of being copied into the plan's
+        inputs (566 MB of feature per 1080p frame)."""
         bl = self._stash[parity]
-        fk, pre = self._fork_el_head(t["x_el"], t["ref_frame_el"], t["ref_feature_el"])
-        feature, recon_el, mv_hat, warp_frame = self._el_codec(t["x_el"], bl, t["ref_frame_el"], t["ref_feature_el"], fk=fk, pre=pre)
+        ref_el, feat_el = t["ref_frame_el"], t["ref_feature_el"]
+        if feat_el is None:                                # bound: the previous frame's outputs, in place
+            ref_el, feat_el = self._el_out[1 - parity]["recon"], self._el_out[1 - parity]["feature"]
+        if self._el_out[parity] is None:                   # (first, eager call of a plan: never inside a capture)
+            assert not torch.cuda.is_current_stream_capturing()
+            self._el_out[parity] = {k: T(torch.empty(v.H * v.W * v.C, dtype=torch.float32, device=self.device), v.H, v.W, v.C, v.C)
+                                    for k, v in (("recon", ref_el), ("feature", feat_el))}
+        fk, pre = self._fork_el_head(t["x_el"], ref_el, feat_el)
+        feature, recon_el, mv_hat, warp_frame = self._el_codec(t["x_el"], bl, ref_el, feat_el, fk=fk, pre=pre, out=self._el_out[parity] if EL_BIND else None)
         fk.close()
         return {"recon_bl": bl["recon"], "feature_bl": bl["feature"], "recon_el": recon_el, "feature_el": feature,
                 "mv_hat": mv_hat, "warp_frame": warp_frame}
@@ -567,6 +582,11 @@ class LSSVC_extend(_HostModel):
                 if next_x_bl is not None:
                     code_ahead(None)                       # BL(t+1) first, on the side stream ...
                 te = {"x_el": x_el, "ref_frame_el": ref_frame_el, "ref_feature_el": ref_feature_el}
+                prev = self._el_out[1 - (fid & 1)]
+                if EL_BIND and prev is not None and all(v.dim() == 4 and v.data_ptr() == prev[k].buf.data_ptr() + 4 * prev[k].off and tuple(v.shape) == (1, prev[k].C, prev[k].H, prev[k].W)
+                                            and v.stride() == (prev[k].H * prev[k].W * prev[k].C, 1, prev[k].W * prev[k].C, prev[k].C)
+                                            for k, v in (("recon", ref_frame_el), ("feature", ref_feature_el))):
+                    te.update(ref_frame_el=None, ref_feature_el=None)       # the previous frame's outputs where they are (_ahead_el_body)
                 r = self._run_body(("p-ahead-el", fid & 1) + tuple(shape(v) for v in te.values()), te,
                                    lambda ins: self._ahead_el_body(ins, fid & 1))      # ... EL(t) beside it
             main.wait_stream(side)

@@ -105,7 +105,7 @@ class _HostModel:
             return t
         return ops.copy(t, T.empty(t.H, t.W, t.C, t.device))
 
-    MAX_PLANS = 8          # I / first-P / steady-P of one size (+1; the look-ahead protocol has four P plans: first, two parities, last): a plan owns a hipGraph memory pool of several GiB at 1080p
+    MAX_PLANS = 10          # I / first-P / steady-P of one size (+1; the look-ahead protocol has four P plans: first, two parities, last): a plan owns a hipGraph memory pool of several GiB at 1080p
 
     def _run_planned(self, key, tensors, body):
         """body(T inputs dict) -> dict of T outputs. First call of a key: eager. Second: capture + replay. Later: replay.

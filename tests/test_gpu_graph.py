@@ -72,8 +72,8 @@ def test_graph_replay_is_bit_identical_to_eager(H, W, precision):
         hip_ops.set_conv_precision(old)
 
 
-@pytest.mark.parametrize("streams", [True, False])
-def test_lookahead_base_layer_is_bit_identical(streams):
+@pytest.mark.parametrize("streams,alias", [(True, False), (True, True), (False, False)])
+def test_lookahead_base_layer_is_bit_identical(streams, alias):
     """BL(t+1) coded beside EL(t) (forward_one_frame's look-ahead protocol): bits and every DPB tensor of every frame equal the plain
     loop's, eager and replayed from the look-ahead plans, with and without side streams inside the layers."""
     from lssvc_amd import hip_ops
@@ -88,12 +88,12 @@ def test_lookahead_base_layer_is_bit_identical(streams):
         inet, pnet = _nets(3, 0.6)
         want = _code(inet, pnet, x_bl, x_el, H, W, 1, frames)
         got = _code(inet, pnet, x_bl, x_el, H, W, 1, frames, lookahead=True)
-        inet.set_graph_mode(True)
-        pnet.set_graph_mode(True)
+        inet.set_graph_mode(True, alias_outputs=alias)      # alias: the DPB the loop hands back IS the look-ahead plans' output
+        pnet.set_graph_mode(True, alias_outputs=alias)      # memory, which the next EL then reads in place instead of loading it
         got += _code(inet, pnet, x_bl, x_el, H, W, gops, frames, lookahead=True)     # GOP 0: eager + captures, later: replays
         plans = [k for k in pnet._plans if str(k[0]).startswith("p-ahead")]         # BL(t+1): behind a whole frame + two parities; EL(t): two parities
-        if streams:
-            assert len(plans) == 5 and all(pnet._plans[k].graph is not None for k in plans), plans
+        if streams:                                                                  # (+ with alias: the first EL plan loads its references, the others are bound)
+            assert len(plans) == (6 if alias else 5) and all(pnet._plans[k].graph is not None for k in plans), plans
         else:
             assert not plans                                                         # single-stream mode codes frame after frame (inter.py)
         for i, (bb, be, tens) in enumerate(got):
