@@ -161,6 +161,11 @@ int lssvc_pool2x2(const lssvc_view *in, const lssvc_view *out, int32_t is_max, v
 int lssvc_softmax2_blend(const lssvc_view *a, const lssvc_view *b, const lssvc_view *logits,
                          const lssvc_view *out, void *stream);
 
+/* One level of ME_Spynet / ME_Spynet_DCVC's coarse-to-fine loop (video_net_component.py:231-246, 308-324) up to the conv stack:
+ * up = 2 * bilinear_x2(flow_lo); out = cat(im1, warp(im2, up), up) as an H x W x 8 view. One launch for what is a resize, a copy
+ * and a flow warp otherwise, with their arithmetic. im1 / im2: H x W x 3, flow_lo: (H/2) x (W/2) x 2 (zeros at the coarsest level). */
+int lssvc_spynet_prep(const lssvc_view *im1, const lssvc_view *im2, const lssvc_view *flow_lo, const lssvc_view *out, void *stream);
+
 /* out = a + b (channel-sliced views allowed) -- the residual sums outside convs. */
 int lssvc_add(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, void *stream);
 /* out = in (strided copy: materialises a torch.cat slice). `out` may have MORE channels than `in` (same H, W): the channels `in`

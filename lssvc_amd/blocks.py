@@ -165,10 +165,8 @@ def spynet(W, p, im1, im2):
     flow = T.zeros(coarse.H // 2, coarse.W // 2, 2, im1.device)
     for lvl in range(levels):
         a, b = l1[levels - 1 - lvl], l2[levels - 1 - lvl]
-        x = T.empty(a.H, a.W, 8, im1.device)          # cat(im1, warp(im2, up), up): 3 + 3 + 2 channels
-        up = ops.resize(flow, flow.H * 2, flow.W * 2, scale=2.0, out=x.slice(6, 8))
-        ops.copy(a, x.slice(0, 3))
-        ops.flow_warp(b, up, out=x.slice(3, 6))
+        x = ops.spynet_prep(a, b, flow, T.empty(a.H, a.W, 8, im1.device))      # cat(im1, warp(im2, up), up), up = 2 * upsampled flow
+        up = x.slice(6, 8)
         m = "%s.moduleBasic.%d" % (p, lvl)
         t = ops.conv(W, m + ".conv1", x, act="relu")
         t = ops.conv(W, m + ".conv2", t, act="relu")

@@ -296,6 +296,43 @@ __global__ void flow_warp_kernel(V in, V flow, V out, int cg, long long total, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// One SpyNet level's network input in ONE launch (ME_Spynet.forward's loop body, video_net_component.py:231-246 / 308-324):
+//   up  = 2 * bilinear_x2(flow_lo)                      -> out[6:8]   (resize_bilinear_kernel's arithmetic, post = 2)
+//   out[3:6] = warp(im2, up)   (flow_warp_kernel's)     out[0:3] = im1
+// was three launches (resize, copy, warp) per level, 8 levels per P-frame. One thread per pixel; `up` is used as computed, which
+// is what the warp launch read back from memory: results are bit-identical to the three launches (tests/test_gpu_ops.py).
+__global__ void spynet_prep_kernel(V im1, V im2, V flow, V out, float sy, float sx, long long total) {
+    const unsigned pix = blockIdx.x * 256u + threadIdx.x;
+    if (pix >= (unsigned)total) return;
+    const int y = (int)(pix / (unsigned)out.W), x = (int)(pix - (unsigned)y * (unsigned)out.W);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    src_index(sy, y, flow.H, y0, y1, hy0, hy1);
+    src_index(sx, x, flow.W, x0, x1, wx0, wx1);
+    const float *a = flow.p + ((size_t)y0 * flow.W + x0) * flow.ld, *b = flow.p + ((size_t)y0 * flow.W + x1) * flow.ld;
+    const float *d = flow.p + ((size_t)y1 * flow.W + x0) * flow.ld, *e = flow.p + ((size_t)y1 * flow.W + x1) * flow.ld;
+    float up[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float top = fmaf(b[k], wx1, a[k] * wx0);
+        const float bot = fmaf(e[k], wx1, d[k] * wx0);
+        up[k] = fmaf(bot, hy1, top * hy0) * 2.0f;
+    }
+    float *o = out.p + (size_t)pix * out.ld;
+    const float *s1 = im1.p + (size_t)pix * im1.ld;
+    const Bilin w = warp_coords(x, y, up[0], up[1], im2.W, im2.H);
+    const float *nw = im2.p + ((size_t)w.y0 * im2.W + w.x0) * im2.ld, *ne = im2.p + ((size_t)w.y0 * im2.W + w.x1) * im2.ld;
+    const float *sw = im2.p + ((size_t)w.y1 * im2.W + w.x0) * im2.ld, *se = im2.p + ((size_t)w.y1 * im2.W + w.x1) * im2.ld;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = s1[k];
+        o[3 + k] = nw[k] * w.nw + ne[k] * w.ne + sw[k] * w.sw + se[k] * w.se;
+    }
+    o[6] = up[0];
+    o[7] = up[1];
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ void pool2x2_kernel(V in, V out, int is_max, int cg, long long total, int vin, int vout) {
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
     if (idx >= (unsigned)total) return;
@@ -512,6 +549,18 @@ extern "C" int lssvc_flow_warp(const lssvc_view *in, const lssvc_view *flow, con
     hipLaunchKernelGGL(flow_warp_kernel, dim3(blocks_for(it.total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(flow),
                        mk(out), it.cg, it.total, (int)vec4_ok(in), (int)vec4_ok(out));
     return launch_status("flow_warp");
+}
+
+extern "C" int lssvc_spynet_prep(const lssvc_view *im1, const lssvc_view *im2, const lssvc_view *flow_lo, const lssvc_view *out, void *stream) {
+    LSSVC_CHECK(view_ok(im1) && view_ok(im2) && view_ok(flow_lo) && view_ok(out), "spynet_prep: bad views");
+    LSSVC_CHECK(im1->C == 3 && same_shape(im1, im2) && same_hw(im1, out) && out->C == 8 && flow_lo->C == 2 && im1->H > 1 && im1->W > 1,
+                "spynet_prep: im1 %dx%dx%d im2 %dx%dx%d flow %dx%dx%d out %dx%dx%d", im1->H, im1->W, im1->C, im2->H, im2->W, im2->C,
+                flow_lo->H, flow_lo->W, flow_lo->C, out->H, out->W, out->C);
+    const long long total = (long long)out->H * out->W;
+    LSSVC_ITEMS_OK(total, "spynet_prep");
+    hipLaunchKernelGGL(spynet_prep_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mk(im1), mk(im2), mk(flow_lo), mk(out),
+                       (float)flow_lo->H / (float)out->H, (float)flow_lo->W / (float)out->W, total);
+    return launch_status("spynet_prep");
 }
 
 extern "C" int lssvc_pool2x2(const lssvc_view *in, const lssvc_view *out, int32_t is_max, void *stream) {

@@ -561,6 +561,12 @@ def flow_warp(x, flow, out=None):
     return out
 
 
+def spynet_prep(im1, im2, flow_lo, out):
+    """out (H x W x 8) = cat(im1, warp(im2, up), up) with up = 2 * bilinear_x2(flow_lo): one SpyNet level's input in one launch."""
+    check(lib.lssvc_spynet_prep(im1.ref, im2.ref, flow_lo.ref, out.ref, stream_ptr()))
+    return out
+
+
 def pool2x2(x, is_max, out=None):
     if out is None:
         out = T.empty(x.H // 2, x.W // 2, x.C, x.device)

@@ -256,6 +256,21 @@ def test_copy_widens_with_zero_channels(hip, c, wide):
         assert torch.equal(back(hip.pad4(nhwc(hip, x))), torch.cat([x, torch.zeros(1, 4 - c, 17, 23)], 1))
 
 
+@pytest.mark.parametrize("H,W,mag", [(16, 24, 0.0), (36, 60, 3.0), (72, 120, 9.0), (34, 46, 1.5)])
+def test_spynet_prep_equals_resize_copy_warp(hip, H, W, mag):
+    """lssvc_spynet_prep (one SpyNet level's input in one launch) against the three launches it replaces, bit for bit."""
+    g = torch.Generator().manual_seed(H + W)
+    im1, im2 = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 3, H, W, generator=g)
+    flow = torch.randn(1, 2, H // 2, W // 2, generator=g) * mag
+    a, b, f = nhwc(hip, im1), nhwc(hip, im2), nhwc(hip, flow)
+    want = hip.T(torch.full((H * W * 8,), float("nan"), device=DEV), H, W, 8, 8)
+    up = hip.resize(f, H, W, scale=2.0, out=want.slice(6, 8))
+    hip.copy(a, want.slice(0, 3))
+    hip.flow_warp(b, up, out=want.slice(3, 6))
+    got = hip.spynet_prep(a, b, f, hip.T(torch.full((H * W * 8,), float("nan"), device=DEV), H, W, 8, 8))
+    assert torch.equal(back(got), back(want))
+
+
 def test_layout_roundtrip(hip):
     x = torch.randn(1, 37, 19, 45)
     t = nhwc(hip, x)
