@@ -166,6 +166,10 @@ int lssvc_softmax2_blend(const lssvc_view *a, const lssvc_view *b, const lssvc_v
  * and a flow warp otherwise, with their arithmetic. im1 / im2: H x W x 3, flow_lo: (H/2) x (W/2) x 2 (zeros at the coarsest level). */
 int lssvc_spynet_prep(const lssvc_view *im1, const lssvc_view *im2, const lssvc_view *flow_lo, const lssvc_view *out, void *stream);
 
+/* l1, l2, l3 = F.avg_pool2d(kernel 2, stride 2) applied once, twice and three times to `in` (ME_Spynet's image pyramid,
+ * video_net_component.py:225-229) in one launch, with lssvc_pool2x2's arithmetic level by level. in: H x W x C with H, W % 8 == 0. */
+int lssvc_avgpool_pyramid3(const lssvc_view *in, const lssvc_view *l1, const lssvc_view *l2, const lssvc_view *l3, void *stream);
+
 /* out = a + b (channel-sliced views allowed) -- the residual sums outside convs. */
 int lssvc_add(const lssvc_view *a, const lssvc_view *b, const lssvc_view *out, void *stream);
 /* out = in (strided copy: materialises a torch.cat slice). `out` may have MORE channels than `in` (same H, W): the channels `in`

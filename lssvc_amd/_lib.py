@@ -85,6 +85,7 @@ SIGNATURES = {
     "lssvc_pool2x2": (C.c_int, [VP, VP, C.c_int32, C.c_void_p]),
     "lssvc_softmax2_blend": (C.c_int, [VP, VP, VP, VP, C.c_void_p]),
     "lssvc_spynet_prep": (C.c_int, [VP, VP, VP, VP, C.c_void_p]),
+    "lssvc_avgpool_pyramid3": (C.c_int, [VP, VP, VP, VP, C.c_void_p]),
     "lssvc_add": (C.c_int, [VP, VP, VP, C.c_void_p]),
     "lssvc_copy": (C.c_int, [VP, VP, C.c_void_p]),
     "lssvc_lrelu": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),

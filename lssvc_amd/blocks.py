@@ -157,10 +157,7 @@ def recon_generation(W, p, res, ctx1):
 def spynet(W, p, im1, im2):
     """ME_Spynet / ME_Spynet_DCVC (video_net_component.py:213-248,292-326)."""
     levels = 4
-    l1, l2 = [im1], [im2]
-    for i in range(levels - 1):
-        l1.append(ops.pool2x2(l1[i], is_max=False))
-        l2.append(ops.pool2x2(l2[i], is_max=False))
+    l1, l2 = ops.avgpool_pyramid3(im1), ops.avgpool_pyramid3(im2)      # the two image pyramids: one launch each
     coarse = l2[levels - 1]
     flow = T.zeros(coarse.H // 2, coarse.W // 2, 2, im1.device)
     for lvl in range(levels):

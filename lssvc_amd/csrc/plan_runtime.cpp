@@ -100,7 +100,7 @@ struct Launch {
 enum Fn {
     FN_WAIT, FN_CONV2D, FN_CONV1X1_DW, FN_FFN, FN_DWCONV, FN_RESIZE, FN_WARP, FN_POOL, FN_SOFTMAX2, FN_ADD, FN_COPY, FN_LRELU,
     FN_OFFSET_DIVERSITY, FN_NCHW_TO_NHWC, FN_NHWC_TO_NCHW, FN_LAPLACE_QUANT_BITS, FN_FOUR_PART_STEP, FN_LAPLACE_BITS,
-    FN_FACTORIZED, FN_GAUSSIAN, FN_BOTTLENECK, FN_FILL_ZERO, FN_CLAMP, FN_EXPORT_I16, FN_IMPORT_I16, FN_PAD_CROP, FN_SPYNET_PREP,
+    FN_FACTORIZED, FN_GAUSSIAN, FN_BOTTLENECK, FN_FILL_ZERO, FN_CLAMP, FN_EXPORT_I16, FN_IMPORT_I16, FN_PAD_CROP, FN_SPYNET_PREP, FN_AVGPOOL_PYRAMID3,
     FN_H_D2H, FN_H_H2D, FN_H_ENCODE, FN_H_FLUSH, FN_H_SET_STREAM, FN_H_DECODE, FN_H_DECODE_CH, FN_H_D2H_ASYNC, FN_H_D2H_WAIT, FN_COUNT
 };
 const char *const kFnNames[FN_COUNT] = {
@@ -108,7 +108,7 @@ const char *const kFnNames[FN_COUNT] = {
     "lssvc_flow_warp", "lssvc_pool2x2", "lssvc_softmax2_blend", "lssvc_add", "lssvc_copy", "lssvc_lrelu", "lssvc_offset_diversity",
     "lssvc_nchw_to_nhwc", "lssvc_nhwc_to_nchw", "lssvc_laplace_quant_bits", "lssvc_four_part_step", "lssvc_laplace_bits",
     "lssvc_factorized_quant_bits", "lssvc_gaussian_conditional", "lssvc_entropy_bottleneck", "lssvc_fill_zero", "lssvc_clamp_inplace",
-    "lssvc_export_symbols_i16", "lssvc_import_symbols_i16", "lssvc_pad_crop", "lssvc_spynet_prep",
+    "lssvc_export_symbols_i16", "lssvc_import_symbols_i16", "lssvc_pad_crop", "lssvc_spynet_prep", "lssvc_avgpool_pyramid3",
     "__d2h__", "__h2d__", "__encode__", "__flush__", "__set_stream__", "__decode__", "__decode_ch__", "__d2h_async__", "__d2h_wait__"};
 
 // argument shapes of every replayed entry point, checked when a plan is loaded (a truncated or mismatched file must be a clean
@@ -116,7 +116,7 @@ const char *const kFnNames[FN_COUNT] = {
 // f / i / l = float / int32 / int64, A = int32 array or NULL, s = the stream slot, w = stream index of a wait
 const char *const kFnArgs[FN_COUNT] = {
     "w", "Cs", "CPPs", "Fs", "VPPVs", "VVfs", "VVVs", "VVis", "VVVVs", "VVVs", "VVs", "VVfs", "VVVPPVs", "PVs", "VPs", "VVVVVPPs", "VVVAVVVs", "VVPPs",
-    "VPVPPs", "VVVVVPPs", "VPVVPPs", "Pls", "Plffs", "VVAfffiPPPs", "PVPAVs", "VViis", "VVVVs",
+    "VPVPPs", "VVVVVPPs", "VPVVPPs", "Pls", "Plffs", "VVAfffiPPPs", "PVPAVs", "VViis", "VVVVs", "VVVVs",
     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 struct Table {                           // one entropy_coder.Tables: quantised CDF rows + used lengths + symbol offsets
@@ -584,6 +584,7 @@ int replay(Plan &p, hipStream_t main) {
             break;
         case FN_PAD_CROP: rc = lssvc_pad_crop(V(0), V(1), I(2), I(3), st); break;
         case FN_SPYNET_PREP: rc = lssvc_spynet_prep(V(0), V(1), V(2), V(3), st); break;
+        case FN_AVGPOOL_PYRAMID3: rc = lssvc_avgpool_pyramid3(V(0), V(1), V(2), V(3), st); break;
         default:
             if (l.id >= FN_H_D2H) {
                 rc = host_step(p, l, main);

@@ -358,6 +358,36 @@ __global__ void pool2x2_kernel(V in, V out, int is_max, int cg, long long total,
     st4(out, (size_t)pix, c, vout, r);
 }
 
+// Three levels of 2x2 average pooling in one launch (SpyNet's image pyramids: avg_pool2d applied three times,
+// video_net_component.py:225-229): one thread per pixel and channel of the COARSEST level walks its 8x8 input block level by
+// level -- each level the running sum in window order, then / 4, exactly pool2x2_kernel's arithmetic on the level below, so the
+// three outputs are bit-identical to three launches. Needs H % 8 == 0 and W % 8 == 0 (else the caller pools level by level).
+__global__ void avgpool_pyramid3_kernel(V in, V l1, V l2, V l3, long long total) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)in.C;
+    const int c = (int)(idx - pix * (unsigned)in.C);
+    const int y3 = (int)(pix / (unsigned)l3.W), x3 = (int)(pix - (unsigned)y3 * (unsigned)l3.W);
+    float s3 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                      // level-2 pixels of this level-3 pixel, in window order
+        const int y2 = 2 * y3 + (q >> 1), x2 = 2 * x3 + (q & 1);
+        float s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y1 = 2 * y2 + (r >> 1), x1 = 2 * x2 + (r & 1);
+            const float *p0 = in.p + ((size_t)(2 * y1) * in.W + 2 * x1) * in.ld + c;
+            const float v1 = (p0[0] + p0[in.ld] + p0[(size_t)in.W * in.ld] + p0[((size_t)in.W + 1) * in.ld]) / 4.f;
+            l1.p[((size_t)y1 * l1.W + x1) * l1.ld + c] = v1;
+            s2 += v1;
+        }
+        const float v2 = s2 / 4.f;
+        l2.p[((size_t)y2 * l2.W + x2) * l2.ld + c] = v2;
+        s3 += v2;
+    }
+    l3.p[(size_t)pix * l3.ld + c] = s3 / 4.f;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void softmax2_blend_kernel(V a, V b, V logits, V out, int cg, long long total, int vec) {
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // 32-bit index arithmetic (the host refuses totals >= 2^31)
@@ -561,6 +591,17 @@ extern "C" int lssvc_spynet_prep(const lssvc_view *im1, const lssvc_view *im2, c
     hipLaunchKernelGGL(spynet_prep_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mk(im1), mk(im2), mk(flow_lo), mk(out),
                        (float)flow_lo->H / (float)out->H, (float)flow_lo->W / (float)out->W, total);
     return launch_status("spynet_prep");
+}
+
+extern "C" int lssvc_avgpool_pyramid3(const lssvc_view *in, const lssvc_view *l1, const lssvc_view *l2, const lssvc_view *l3, void *stream) {
+    LSSVC_CHECK(view_ok(in) && view_ok(l1) && view_ok(l2) && view_ok(l3), "avgpool_pyramid3: bad views");
+    LSSVC_CHECK(in->H % 8 == 0 && in->W % 8 == 0 && l1->H == in->H / 2 && l1->W == in->W / 2 && l2->H == in->H / 4 && l2->W == in->W / 4 &&
+                l3->H == in->H / 8 && l3->W == in->W / 8 && l1->C == in->C && l2->C == in->C && l3->C == in->C,
+                "avgpool_pyramid3: in %dx%dx%d levels %dx%d %dx%d %dx%d", in->H, in->W, in->C, l1->H, l1->W, l2->H, l2->W, l3->H, l3->W);
+    const long long total = (long long)l3->H * l3->W * l3->C;
+    LSSVC_ITEMS_OK(total, "avgpool_pyramid3");
+    hipLaunchKernelGGL(avgpool_pyramid3_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(l1), mk(l2), mk(l3), total);
+    return launch_status("avgpool_pyramid3");
 }
 
 extern "C" int lssvc_pool2x2(const lssvc_view *in, const lssvc_view *out, int32_t is_max, void *stream) {

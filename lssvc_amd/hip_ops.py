@@ -567,6 +567,18 @@ def spynet_prep(im1, im2, flow_lo, out):
     return out
 
 
+def avgpool_pyramid3(x):
+    """[x, avg_pool(x), avg_pool^2(x), avg_pool^3(x)]: one launch when H, W are multiples of 8, else level by level."""
+    if x.H % 8 or x.W % 8:
+        out = [x]
+        for _ in range(3):
+            out.append(pool2x2(out[-1], is_max=False))
+        return out
+    lv = [T.empty(x.H >> k, x.W >> k, x.C, x.device) for k in (1, 2, 3)]
+    check(lib.lssvc_avgpool_pyramid3(x.ref, lv[0].ref, lv[1].ref, lv[2].ref, stream_ptr()))
+    return [x] + lv
+
+
 def pool2x2(x, is_max, out=None):
     if out is None:
         out = T.empty(x.H // 2, x.W // 2, x.C, x.device)

@@ -271,6 +271,19 @@ def test_spynet_prep_equals_resize_copy_warp(hip, H, W, mag):
     assert torch.equal(back(got), back(want))
 
 
+@pytest.mark.parametrize("c,H,W", [(3, 64, 96), (3, 72, 120), (5, 32, 40), (3, 36, 60)])
+def test_avgpool_pyramid_equals_three_pools(hip, c, H, W):
+    """lssvc_avgpool_pyramid3 against three lssvc_pool2x2 launches, bit for bit (36x60: not a multiple of 8, the level-by-level path)."""
+    x = nhwc(hip, torch.rand(1, c, H, W, generator=torch.Generator().manual_seed(H)))
+    got = hip.avgpool_pyramid3(x)
+    want = [x]
+    for _ in range(3):
+        want.append(hip.pool2x2(want[-1], is_max=False))
+    for a, b in zip(got[1:], want[1:]):
+        assert torch.equal(back(a), back(b))
+    close(back(got[1]), F.avg_pool2d(back(x), 2, 2), rtol=1e-6, atol=1e-7)
+
+
 def test_layout_roundtrip(hip):
     x = torch.randn(1, 37, 19, 45)
     t = nhwc(hip, x)
