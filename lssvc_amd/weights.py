@@ -70,6 +70,7 @@ class WeightStore:
         """A device copy of an ad-hoc host tensor that is NOT a function of the checkpoint alone (the bottleneck medians of
         update()'s tables): registered without a recipe, so a compiled plan stores its bytes."""
         host = t.contiguous()
+        assert not torch.cuda.is_current_stream_capturing(), "a weight tensor would be uploaded inside a hipGraph capture"
         dev = host.to(self.device)
         self.regions[dev.data_ptr()] = (dev.numel() * dev.element_size(), host)
         return dev
@@ -105,6 +106,9 @@ class WeightStore:
         check(lib.lssvc_prepare_weights(arr, n, C.byref(spec), C.byref(nb), nbytes, scalars, dims, ptrs))
         recipe = (kind, name, name2, tuple(int(c) for c in splits), int(flag))
         devs = []
+        # (a layer variant first used inside a capture would get its weights from the graph's private pool through a captured copy of
+        # pageable memory: every plan's first call is eager precisely so that this never happens -- fail loudly if it ever does)
+        assert not torch.cuda.is_current_stream_capturing(), "weights of %s would be prepared inside a hipGraph capture" % name
         for i, h in enumerate(hosts):
             dev = h.to(self.device)
             self.regions[dev.data_ptr()] = (dev.numel(), h)
