@@ -60,6 +60,9 @@ class WeightStore:
         self.force_f32 = set()          # layers the fp16 range audit moved to the exact fp32 conv kernel (hip_ops.RangeAudit)
         self._table = None              # the checkpoint as a C array of lssvc_tensor (built on first use)
 
+    def _capturing(self):
+        return torch.device(self.device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+
     def has(self, key):
         return key in self.sd
 
@@ -70,7 +73,7 @@ class WeightStore:
         """A device copy of an ad-hoc host tensor that is NOT a function of the checkpoint alone (the bottleneck medians of
         update()'s tables): registered without a recipe, so a compiled plan stores its bytes."""
         host = t.contiguous()
-        assert not torch.cuda.is_current_stream_capturing(), "a weight tensor would be uploaded inside a hipGraph capture"
+        assert not self._capturing(), "a weight tensor would be uploaded inside a hipGraph capture"
         dev = host.to(self.device)
         self.regions[dev.data_ptr()] = (dev.numel() * dev.element_size(), host)
         return dev
@@ -108,7 +111,7 @@ class WeightStore:
         devs = []
         # (a layer variant first used inside a capture would get its weights from the graph's private pool through a captured copy of
         # pageable memory: every plan's first call is eager precisely so that this never happens -- fail loudly if it ever does)
-        assert not torch.cuda.is_current_stream_capturing(), "weights of %s would be prepared inside a hipGraph capture" % name
+        assert not self._capturing(), "weights of %s would be prepared inside a hipGraph capture" % name
         for i, h in enumerate(hosts):
             dev = h.to(self.device)
             self.regions[dev.data_ptr()] = (dev.numel(), h)
