@@ -472,7 +472,7 @@ class LSSVC_extend(_HostModel):
     # the enhancement layer needs its own previous frame and the base layer of the SAME frame (LSSVC_net.py:445-528). So BL(t+1) and
     # EL(t) are independent, and a caller that can name the next frame (test.py's loop can: the frames are all there) may have them
     # in flight together: same launches, same order inside either layer, bit-identical results -- but the small-map launches and the
-    # tails of the big ones of one layer now fill with the other layer's work (DESIGN section 8). They are TWO frame plans (two
+    # tails of the big ones of one layer now fill with the other layer's work (DESIGN section 6.1). They are TWO frame plans (two
     # hipGraphs), BL(t+1) launched on a second stream and EL(t) on the caller's; forking BL(t+1)'s own side chains from a branch of
     # one captured graph -- a fork inside a fork -- crashes hipGraph capture on this ROCm. BL(t+1) reads frame t's BL reconstruction
     # clamped to [0,1] -- what test.py:249-250 makes of the DPB before the next frame; a caller of this mode promises that clamp --
