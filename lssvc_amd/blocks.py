@@ -105,42 +105,57 @@ def context_fusion(W, p, t1, t2, t3, outs=(None, None, None)):
     return o1, o2, o3
 
 
-def res_encoder_gdn(W, p, x, c1, c2, c3, flavour):
+def context_homes(W, p_codec, H2, W2, c2_channels, c3_channels, device):
+    """The wide buffers the bottleneck ResBlocks of a contextual encoder / decoder pair read -- cat(transform part, context) at 1/2 and
+    1/4 resolution -- allocated ONCE per frame with the context living in its slice from the moment it is made: (wide2, wide3,
+    context2 view, context3 view). Hand the views to context_fusion(outs=...) and the wides to res_encoder_gdn / res_decoder_gdn
+    (`homes=`): the encoder and then the decoder fill the transform part, nobody copies the context (two copies each per P-frame
+    layer before, 141 + 53 MB at 1080p). p_codec: the encoder's prefix, for its conv1 / conv2 output widths."""
+    n2, n3 = W.raw(p_codec + ".conv1.weight").shape[0], W.raw(p_codec + ".conv2.weight").shape[0]
+    w2, w3 = T.empty(H2, W2, n2 + c2_channels, device), T.empty(H2 // 2, W2 // 2, n3 + c3_channels, device)
+    return w2, w3, w2.slice(n2, n2 + c2_channels), w3.slice(n3, n3 + c3_channels)
+
+
+def _wide(homes, k, t, c, dev):
+    """The cat(t, c) buffer of bottleneck k: the frame's resident one (context already in place) or a fresh one + a copy of c."""
+    n = t.C
+    if homes is not None:
+        wide = homes[k]
+        assert wide.C == n + c.C and c.buf is wide.buf and c.off == wide.off + n, "context %d does not live in its wide buffer" % k
+        return wide, n
+    wide = T.empty(t.H, t.W, n + c.C, dev)
+    ops.copy(c, wide.slice(n, n + c.C))
+    return wide, n
+
+
+def res_encoder_gdn(W, p, x, c1, c2, c3, flavour, homes=None):
     """Contextual analysis transform with GDN: Intra ResEncoder (layers.py:342-367) and DMC ResEncoder
     (dmc_net.py:65-90). The concat that feeds each bottleneck ResBlock is materialised in place: the GDN
-    writes its half of the wide buffer, the context is copied into the other half."""
+    writes its half of the wide buffer, the context is copied into the other half -- or already lives there (`homes`)."""
     dev = x.device
     t = ops.conv(W, p + ".conv1", [x, c1], stride=2)
-    n = t.C
-    wide = T.empty(t.H, t.W, n + c2.C, dev)
+    wide, n = _wide(homes, 0, t, c2, dev)
     ops.gdn(W, p + ".gdn1", t, flavour, out=wide.slice(0, n))
-    ops.copy(c2, wide.slice(n, n + c2.C))
     f = res_block(W, p + ".res1", wide, slope=0.1, start_from_relu=False, end_with_relu=True)
     t = ops.conv(W, p + ".conv2", f, stride=2)
-    n = t.C
-    wide = T.empty(t.H, t.W, n + c3.C, dev)
+    wide, n = _wide(homes, 1, t, c3, dev)
     ops.gdn(W, p + ".gdn2", t, flavour, out=wide.slice(0, n))
-    ops.copy(c3, wide.slice(n, n + c3.C))
     f = res_block(W, p + ".res2", wide, slope=0.1, start_from_relu=False, end_with_relu=True)
     t = ops.gdn(W, p + ".gdn3", ops.conv(W, p + ".conv3", f, stride=2), flavour)
     return ops.conv(W, p + ".conv4", t, stride=2)
 
 
-def res_decoder_gdn(W, p, y_hat, c2, c3, flavour):
+def res_decoder_gdn(W, p, y_hat, c2, c3, flavour, homes=None):
     """Contextual synthesis transform with IGDN (layers.py:370-395, dmc_net.py:93-118)."""
     dev = y_hat.device
     t = ops.gdn(W, p + ".gdn1", ops.subpel(W, p + ".up1", y_hat), flavour, inverse=True)
     t = ops.subpel(W, p + ".up2", t)
-    n = t.C
-    wide = T.empty(t.H, t.W, n + c3.C, dev)
+    wide, n = _wide(homes, 1, t, c3, dev)
     ops.gdn(W, p + ".gdn2", t, flavour, inverse=True, out=wide.slice(0, n))
-    ops.copy(c3, wide.slice(n, n + c3.C))
     f = res_block(W, p + ".res1", wide, slope=0.1, start_from_relu=False, end_with_relu=True)
     t = ops.subpel(W, p + ".up3", f)
-    n = t.C
-    wide = T.empty(t.H, t.W, n + c2.C, dev)
+    wide, n = _wide(homes, 0, t, c2, dev)
     ops.gdn(W, p + ".gdn3", t, flavour, inverse=True, out=wide.slice(0, n))
-    ops.copy(c2, wide.slice(n, n + c2.C))
     f = res_block(W, p + ".res2", wide, slope=0.1, start_from_relu=False, end_with_relu=True)
     return ops.subpel(W, p + ".up4", f)
 

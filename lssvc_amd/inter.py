@@ -130,8 +130,11 @@ class LSSVC_extend(_HostModel):
         mv2 = ops.resize(mv_hat, mv_hat.H // 2, mv_hat.W // 2, scale=0.5)
         mv3 = ops.resize(mv2, mv2.H // 2, mv2.W // 2, scale=0.5)
         fk.join(1)
-        c1, c2, c3 = B.context_fusion(W, p + ".context_fusion_net", ops.flow_warp(r1, mv_hat), ops.flow_warp(r2, mv2),
-                                      ops.flow_warp(r3, mv3))
+        cf = p + ".context_fusion_net"
+        homes = B.context_homes(W, p + ".res_encoder", ref_frame.H // 2, ref_frame.W // 2, W.raw(cf + ".conv2_out.weight").shape[0],
+                                W.raw(cf + ".conv3_out.weight").shape[0], self.device)      # contexts 2 / 3 are made where the bottlenecks read them
+        c1, c2, c3 = B.context_fusion(W, cf, ops.flow_warp(r1, mv_hat), ops.flow_warp(r2, mv2), ops.flow_warp(r3, mv3),
+                                      outs=(None, homes[2], homes[3]))
 
         with fk.branch(1):                      # temporal prior (dmc_net.py:121-140): contexts only, beside encoder + hyper codec
             q = p + ".temporal_prior_encoder"
@@ -140,7 +143,7 @@ class LSSVC_extend(_HostModel):
             t = ops.gdn(W, q + ".gdn3", ops.conv(W, q + ".conv3", [t, c3], stride=2), "inter")
             temporal = ops.conv(W, q + ".conv4", t, stride=2)
         if not decoding:
-            y = B.res_encoder_gdn(W, p + ".res_encoder", x, c1, c2, c3, "inter")
+            y = B.res_encoder_gdn(W, p + ".res_encoder", x, c1, c2, c3, "inter", homes=homes)
             z = self._prior_encoder(p + ".res_prior_encoder", y)
             z_hat = z.like()
             ops.factorized_quant_bits(z, W.bit_estimator(p + ".bit_estimator_z"), S, slot_base + 1, z_hat=z_hat)
@@ -168,7 +171,7 @@ class LSSVC_extend(_HostModel):
         else:
             y_hat = self._pull_laplace(source, scales, means)
 
-        res = B.res_decoder_gdn(W, p + ".res_decoder", y_hat, c2, c3, "inter")
+        res = B.res_decoder_gdn(W, p + ".res_decoder", y_hat, c2, c3, "inter", homes=homes)
         feature, recon = B.recon_generation(W, p + ".recon_generation_net", res, c1)
         return {"recon": recon, "feature": feature, "y_hat": y_hat, "mv_hat": mv_hat}
 
@@ -237,7 +240,7 @@ class LSSVC_extend(_HostModel):
         c2, c3 = ops.flow_warp(r2, mv2), ops.flow_warp(r3, mv3)
         return B.context_fusion(W, "context_fusion_net", c1, c2, c3), warpframe
 
-    def _el_context(self, spat, mv, ref, ref_pyr):
+    def _el_context(self, spat, mv, ref, ref_pyr, outs=(None, None, None)):
         """LSSVC.hybrid_temporal_layer_context_fusion (LSSVC_net.py:246-259); spat = the texture pyramid of the up-sampled
         base-layer feature (`texture_extractor(texture_resampler(texture_bl))`), ref_pyr = _ref_pyramid(...)."""
         W = self.W
@@ -252,7 +255,7 @@ class LSSVC_extend(_HostModel):
                 ctx.append(ops.softmax2_blend(temp[i], spat[i], logits))
         else:
             ctx = list(temp)
-        c1, c2, c3 = B.context_fusion(W, "context_fusion_net", ctx[0], ctx[1], ctx[2])
+        c1, c2, c3 = B.context_fusion(W, "context_fusion_net", ctx[0], ctx[1], ctx[2], outs=outs)
         return c1, c2, c3, warpframe
 
     def _unet(self, p, x, out=None):
@@ -378,7 +381,11 @@ class LSSVC_extend(_HostModel):
         else:
             ref_pyr = self._ref_pyramid(ref_el, feat_el)
         fk.join(1)
-        c1, c2, c3, warp_frame = self._el_context(spat, mv_hat, ref_el, ref_pyr)
+        # contexts 2 / 3 are made where the bottleneck ResBlocks of the residual encoder and decoder read them: cat(64, context2) at
+        # 1/2 and cat(96, context3) at 1/4 resolution, one buffer each for the frame (B.context_homes: no concat copies)
+        homes = B.context_homes(W, "res_encoder", H // 2, Wd // 2, W.raw("context_fusion_net.conv2_out.weight").shape[0],
+                                W.raw("context_fusion_net.conv3_out.weight").shape[0], self.device)
+        c1, c2, c3, warp_frame = self._el_context(spat, mv_hat, ref_el, ref_pyr, outs=(None, homes[2], homes[3]))
 
         with fk.branch(1):        # temporal prior (LSSVC_net.py:75-79): context3 only, beside the encoder and the hyper codec
             q = "temporal_prior_encoder"
@@ -388,13 +395,11 @@ class LSSVC_extend(_HostModel):
         if not decoding:
             # ResEncoder without GDN (lssvc_modules.py:235-254); the concat feeding each ResBlock is built in place
             p = "res_encoder"
-            t = T.empty(H // 2, Wd // 2, 64 + c2.C, self.device)
+            t, u = homes[0], homes[1]
+            assert t.C == 64 + c2.C and u.C == 96 + c3.C
             ops.conv(W, p + ".conv1", [xe, c1], stride=2, out=t.slice(0, 64))
-            ops.copy(c2, t.slice(64, t.C))
             t = B.res_block(W, p + ".res1", t, slope=0.1, end_with_relu=True)
-            u = T.empty(H // 4, Wd // 4, 96 + c3.C, self.device)
             ops.conv(W, p + ".conv2", t, stride=2, out=u.slice(0, 96))
-            ops.copy(c3, u.slice(96, u.C))
             u = B.res_block(W, p + ".res2", u, slope=0.1, end_with_relu=True)
             y = ops.conv(W, p + ".conv4", ops.conv(W, p + ".conv3", u, stride=2), stride=2)
             z = self._prior_encoder("res_prior_encoder", y)
@@ -428,13 +433,11 @@ class LSSVC_extend(_HostModel):
         # ResDecoder (lssvc_modules.py:257-276)
         p = "res_decoder"
         t = ops.subpel(W, p + ".up1", y_hat)
-        u = T.empty(H // 4, Wd // 4, 96 + c3.C, self.device)
+        u = homes[1]                                        # (the encoder's parts of the two buffers are dead by now: y came from them)
         ops.subpel(W, p + ".up2", t, out=u.slice(0, 96))
-        ops.copy(c3, u.slice(96, u.C))
         u = B.res_block(W, p + ".res1", u, slope=0.1, end_with_relu=True)
-        t = T.empty(H // 2, Wd // 2, 64 + c2.C, self.device)
+        t = homes[0]
         ops.subpel(W, p + ".up3", u, out=t.slice(0, 64))
-        ops.copy(c2, t.slice(64, t.C))
         t = B.res_block(W, p + ".res2", t, slope=0.1, end_with_relu=True)
         res = ops.subpel(W, p + ".up4", t)
 
