@@ -235,10 +235,10 @@ def _gpu_gop_symbol_aware(n, H, W, seed, gain, scale=2.0, bl=None):
 
 @pytest.mark.parametrize("seed", [7, pytest.param(8, marks=pytest.mark.slow), pytest.param(9, marks=pytest.mark.slow)])
 def test_gop_drift_symbol_aware(seed, precision):
-    """The GOP of test_gop_drift_vs_oracle on three more seeds, with ties handled instead of avoided: 12 frames on seed 7 by
-    default, the full 32 on seeds 8 and 9, which are marked slow (each is 32 oracle frames of CPU work;
-    profiles/r04_slow_gpu_tests.txt holds their run)."""
-    _gpu_gop_symbol_aware(12 if seed == 7 else 32, 128, 128, seed, 0.55)
+    """The GOP of test_gop_drift_vs_oracle on three more seeds, with ties handled instead of avoided: 8 frames on seed 7 by
+    default (the oracle's CPU seconds set the pace: the default suite has to stay well inside the driver's 15 minutes), the full 32 on
+    seeds 8 and 9, which are marked slow (each is 32 oracle frames of CPU work; profiles/r04_slow_gpu_tests.txt holds their run)."""
+    _gpu_gop_symbol_aware(8 if seed == 7 else 32, 128, 128, seed, 0.55)
 
 
 def test_gop_drift_vs_oracle(precision):
@@ -257,7 +257,7 @@ def test_frames_384x640_vs_oracle(precision):
     _gpu_gop_against_oracle(3, 384, 640, 3, 0.55, want_kernels=want)
 
 
-@pytest.mark.parametrize("seed", [7, 8, 9])
+@pytest.mark.parametrize("seed", [7, 8, pytest.param(9, marks=pytest.mark.slow)])
 @pytest.mark.parametrize("ph,pw,scale,frames", [
     (240, 416, 2.0, 3),
     # the oracle's CPU seconds, not the GPU's, make these long (45 - 80 s each on a 16-core host share): --runslow / LSSVC_SLOW=1
