@@ -61,7 +61,7 @@ class FramePlan:
             assert tuple(x.shape) == (1, dst.C, dst.H, dst.W) and x.dtype == torch.float32 and x.is_cuda, (k, tuple(x.shape))
             c, h, w = dst.C, dst.H, dst.W
             if c > 1 and x.stride() == (h * w * c, 1, w * c, c):
-                dst.buf.copy_(x.permute(0, 2, 3, 1).reshape(-1))              # channels_last (our own outputs): flat copy
+                dst.buf.view(-1)[dst.off:dst.off + c * h * w].copy_(x.permute(0, 2, 3, 1).reshape(-1))      # channels_last (our own outputs): flat copy
             else:
                 x = x.contiguous()
                 check(lib.lssvc_nchw_to_nhwc(C.c_void_p(x.data_ptr()), dst.ref, ops.stream_ptr()))
