@@ -489,9 +489,6 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     }
 
     // ======================================================================================= CONSUMER waves
-#ifdef LSSVC_P3_SETPRIO
-    __builtin_amdgcn_s_setprio(LSSVC_P3_SETPRIO);          // experiment: the MFMA-issuing waves ahead of the producers at the issue arbiter
-#endif
     const int li = lane & 15;
     const int lg = lane >> 4;
     const int tsel = lg >> 1;
