@@ -44,6 +44,15 @@ enum { LSSVC_EPI_NONE = 0, LSSVC_EPI_X_MUL_RSQRT = 1, LSSVC_EPI_X_MUL_SQRT = 2, 
  * v_mfma_f32_16x16x32_f16 -- fp32-class accuracy (holds the 1e-5 bpp / 1e-4 dB bars; plain fp16 does not) at
  * 3/8 of the fp32-MFMA pipe cycles x 16x the rate. Used for 3x3 / 7x7 stride-1 layers; others stay F32. */
 enum { LSSVC_PREC_F32 = 0, LSSVC_PREC_F16X3 = 1 };
+/* Flags OR-ed into lssvc_conv_desc.precision beside LSSVC_PREC_F16X3 (round 5): PRE-SPLIT activation tensors. A pre-split view
+ * holds, per pixel and 16-channel chunk, 64 bytes: [hi: 16 x fp16 | lo: 16 x fp16] with hi = fp16(x), lo = fp16(x - hi) of the
+ * saturated value x -- what every f16x3 conv makes of its fp32 input while staging it -- so it takes the bytes of the fp32 tensor
+ * (ptr 64-byte aligned, ld %% 16 == 0 in 4-byte units, channels >= C of the last chunk zero; 16-channel slices of it are views
+ * again). SPLIT_IN: every input of the conv is pre-split, with the conv's input activation ALREADY APPLIED by whoever wrote it
+ * (in_act must be NONE): the persistent 3x3 kernels then move their halo patches global -> LDS by DMA, no conversion in the
+ * kernel. Same hi / lo values either way: results are bit-identical to the fp32-input form. */
+#define LSSVC_PREC_MASK 0xff
+#define LSSVC_PREC_SPLIT_IN 0x100
 
 #define LSSVC_CONV_MAX_INPUTS 3
 #define LSSVC_CONV_CK 8 /* input channels per K-chunk; each input segment is zero-padded to a multiple */
@@ -180,6 +189,10 @@ int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float slope, void *
 /* out = F.pad(in, (left, right, top, bottom), value 0), negative entries cropping; right / bottom follow from out's size
  * (get_depadded_feature: IntraSS.py:124-135, LSSVC_net.py:271-282). Writes every element of `out`. */
 int lssvc_pad_crop(const lssvc_view *in, const lssvc_view *out, int32_t left, int32_t top, void *stream);
+/* fp32 NHWC view -> PRE-SPLIT view of the same shape (see LSSVC_PREC_SPLIT_IN): out = split(clamp(act(in), +-65504)), act = none or
+ * LeakyReLU(in_slope) -- the staging arithmetic of the f16x3 convs (the reference has no counterpart: its convs read fp32,
+ * layers.py:36-57). For tensors that a conv kernel did not write pre-split itself (resampled / warped / boundary tensors). */
+int lssvc_presplit(const lssvc_view *in, const lssvc_view *out, int32_t in_act, float in_slope, void *stream);
 /* Zero `nbytes` of device memory / clamp n floats in place (what torch.zeros and the caller's `clamp_(0, 1)` of the
  * reconstructions, test.py:249-250, are for a caller without PyTorch; compiled frame plans record these as launches). */
 int lssvc_fill_zero(void *ptr, int64_t nbytes, void *stream);

@@ -19,6 +19,7 @@ CONV_CK = 8
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 INACT_NONE, INACT_LRELU, INACT_SQUARE = 0, 1, 2
 PREC_F32, PREC_F16X3 = 0, 1
+PREC_MASK, PREC_SPLIT_IN = 0xff, 0x100
 EPI_NONE, EPI_X_MUL_RSQRT, EPI_X_MUL_SQRT, EPI_X_DIV_SQRT = 0, 1, 2, 3
 
 
@@ -89,6 +90,7 @@ SIGNATURES = {
     "lssvc_add": (C.c_int, [VP, VP, VP, C.c_void_p]),
     "lssvc_copy": (C.c_int, [VP, VP, C.c_void_p]),
     "lssvc_lrelu": (C.c_int, [VP, VP, C.c_float, C.c_void_p]),
+    "lssvc_presplit": (C.c_int, [VP, VP, C.c_int32, C.c_float, C.c_void_p]),
     "lssvc_pad_crop": (C.c_int, [VP, VP, C.c_int32, C.c_int32, C.c_void_p]),
     "lssvc_absmax": (C.c_int, [VP, C.c_void_p, C.c_void_p]),
     "lssvc_fill_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),

@@ -92,9 +92,17 @@ struct P3Phase {
 // as before) and go straight on to the next tile; each producer wave then moves one consumer wave's rows to global memory
 // (adding the residuals, plain or pixel-shuffle store) with the NEXT fill's patch loads already in flight, and only after all
 // four have drained is the pair refilled. Same arithmetic per element as the direct epilogue: results are bit-identical.
-template <int MF, bool INACT, bool STAMP = false, bool STAGE = false, int S = 1>
+// SPLIT (round 5): the inputs are PRE-SPLIT tensors (lssvc_hip.h: LSSVC_PREC_SPLIT_IN) -- per pixel and 16-channel chunk 64 bytes,
+// [hi: 16 x fp16 | lo: 16 x fp16], written by the producing layer's epilogue (or lssvc_presplit) with the input activation already
+// applied; same bytes per element as fp32. The patch then goes global -> LDS by LDS-DMA like the weights: no patch registers, no
+// conversion, no ds_write in the producer waves; every 16-byte unit of the LDS image [plane][patch pixel][16 halfs] is fetched by
+// one lane from wherever it lives (zero padding: from a 64-byte block of zeros), so the LDS layout the consumers read is unchanged.
+__device__ __attribute__((aligned(64))) unsigned g_p3_zero_block[16];      // zero-initialised
+
+template <int MF, bool INACT, bool STAMP = false, bool STAGE = false, int S = 1, bool SPLIT = false>
 __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP p) {
     static_assert(!(STAGE && S != 1), "the staged epilogue is laid out for stride 1");
+    static_assert(!(SPLIT && INACT), "a pre-split input carries its activation already");
     using G = P3Geom<MF, S>;
     constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP, NP = G::NP;
     constexpr int SR = STAGE ? G::SR : 0;
@@ -195,11 +203,31 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         // slots are what they compete for with the consumers' MFMAs): input pixel of every staged float4 item (-1 = zero
         // padding / past the patch) and the lane offsets of the weight DMA inside one chunk's [hi | lo] image. The patch of
         // phase k+2 is loaded while the weights of phase k+1 are staged, so the two halves are cached per tile separately.
-        int ppix[NP], woff[G::NDMA];
+        // SPLIT: 16-byte units of one plane / both planes of the LDS patch image, wave-level DMA instructions, per producer wave
+        constexpr int UPP = G::PH * PW * 2, UT = 2 * UPP, P_INSTR = (UT + 63) / 64, NPDMA = (P_INSTR + G::NPROD - 1) / G::NPROD;
+        int ppix[NP], woff[G::NDMA], pcode[SPLIT ? NPDMA : 1];
         int pgeom_it = -1, wgeom_it = -1;
         auto patch_geometry = [&](int it) {
             int oy0, ox0, m0;
             tile_origin(it, oy0, ox0, m0);
+            if constexpr (SPLIT) {
+                // unit u of the LDS image = (plane, patch position, half of the 16 channels) -> (input pixel << 2 | plane * 2 + half),
+                // -1 for zero padding and for the lanes past the image in the last instruction
+#pragma unroll
+                for (int t = 0; t < NPDMA; ++t) {
+                    const int u = (pw + G::NPROD * t) * 64 + lane;
+                    const int plane = u >= UPP ? 1 : 0;
+                    const int r = u - plane * UPP;
+                    const int ppos = r >> 1, half = r & 1;
+                    const int py = ppos / PW, pxs = ppos - py * PW;
+                    const int px = S == 2 ? (pxs < G::PWE ? 2 * pxs : 2 * (pxs - G::PWE) + 1) : pxs;      // stride 2: de-interleaved columns
+                    const int gy = oy0 * S - p.pad_t + py, gx = ox0 * S - p.pad_l + px;
+                    const bool ok = u < UT && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+                    pcode[t] = ok ? (((gy * Win + gx) << 2) | (plane * 2 + half)) : -1;
+                }
+                pgeom_it = it;
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int idx = lt + i * kP3ProducerThreads;
@@ -247,6 +275,29 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 }
             }
             if (STAMP) s_dma += __builtin_amdgcn_s_memtime() - ts;
+        };
+        // SPLIT: patch of phase `ph` -> LDS buffer `buf`, by DMA
+        auto dma_patch = [&](const P3Phase &ph, int buf) {
+            if constexpr (SPLIT) {
+                long long ts = 0;
+                if (STAMP) ts = __builtin_amdgcn_s_memtime();
+                if (ph.it != pgeom_it) patch_geometry(ph.it);
+                const V X = p.in[ph.k.seg];
+                const unsigned char *base = reinterpret_cast<const unsigned char *>(X.p + ph.k.c0);      // this chunk's 64 bytes of pixel 0
+                const size_t pitch = (size_t)X.ld * 4;
+                unsigned char *dst = reinterpret_cast<unsigned char *>(patch_buf(buf));
+#pragma unroll
+                for (int t = 0; t < NPDMA; ++t) {
+                    const int j = pw + G::NPROD * t;
+                    if (j >= P_INSTR) break;
+                    const unsigned char *src = pcode[t] >= 0 ? base + (size_t)(pcode[t] >> 2) * pitch + (size_t)((pcode[t] & 3) * 16)
+                                                             : reinterpret_cast<const unsigned char *>(g_p3_zero_block);
+                    if (j * 64 + lane < UT)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                         (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+                }
+                if (STAMP) s_ld += __builtin_amdgcn_s_memtime() - ts;
+            }
         };
         // patch of phase `ph` -> registers (fp32, as loaded)
         float4 preg[NP];
@@ -431,9 +482,17 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         // flight slowed the epilogue's stores; 64->64 @1080p 428 -> 458 us.)
         const int total = n_it * phases_per_tile;
         P3Phase ph{0, KState{0, 0, 0, 0}};
+        // the patch part of a fill: through registers (load, convert, ds_write) or, SPLIT, by DMA
+        auto fill_patch = [&](const P3Phase &f, int buf) __attribute__((always_inline)) {
+            if constexpr (SPLIT) {
+                dma_patch(f, buf);
+            } else {
+                load_patch(f);
+                store_patch(buf);
+            }
+        };
         stage_weights(ph, 0);
-        load_patch(ph);
-        store_patch(0);
+        fill_patch(ph, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of this wave has landed
         __syncthreads();                                   // (A) phase 0 is in buffer 0
         int drained = 0;                                   // STAGE: tiles this wave has taken out of the LDS
@@ -456,14 +515,29 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the parked rows have returned
                 ++drained;
                 signal(sync_s + 12 + pw, drained);
-                load_patch(ph);                                        // (after the residuals have been added: 80 registers fewer in flight)
+                if constexpr (!SPLIT) load_patch(ph);                  // (after the residuals have been added: 80 registers fewer in flight)
                 wait_for(sync_s + 12, drained);
                 stage_weights(ph, (k + 1) & 1);
-                store_patch((k + 1) & 1);
+                if constexpr (SPLIT) dma_patch(ph, (k + 1) & 1);
+                else store_patch((k + 1) & 1);
+            } else if (STAMP && (p.debug & 7)) {
+                // ablations of the stamp build (LSSVC_CONV_DEBUG = 256 + bits; results are wrong): 1 no patch traffic after the first
+                // fill, 2 no weight DMA after the first fill, 4 patch loads only (no conversion, no LDS stores)
+                if (!(p.debug & 2)) stage_weights(ph, (k + 1) & 1);
+                if (!(p.debug & 1)) {
+                    if constexpr (SPLIT) {
+                        dma_patch(ph, (k + 1) & 1);
+                    } else {
+                        load_patch(ph);
+                        if (!(p.debug & 4)) store_patch((k + 1) & 1);
+                        else
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(preg[i].x), "v"(preg[i].y), "v"(preg[i].z), "v"(preg[i].w));
+                    }
+                }
             } else {
                 stage_weights(ph, (k + 1) & 1);
-                load_patch(ph);
-                store_patch((k + 1) & 1);
+                fill_patch(ph, (k + 1) & 1);
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMA has landed, its LDS stores are done
             signal(sync_s + pw, k + 1);
@@ -720,7 +794,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     }
 }
 
-template <int MF, bool INACT, int S = 1>
+template <int MF, bool INACT, int S = 1, bool SPLIT = false>
 static int launch_p3(const ConvP &p, hipStream_t st) {
     using G = P3Geom<MF, S>;
     const int cus = device_cus();
@@ -731,7 +805,7 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
     const size_t lds = (size_t)G::LDS_BYTES + (size_t)q.m_tiles * G::TM * sizeof(float) + 32 + 2 * kP3ProducerThreads * 8;      // + bias vector + hand-off slots + trash slots
     if (lds > 160 * 1024) return fail("conv2d(f16x3p): %zu bytes of LDS", lds);
     static LdsGrant grant;
-    if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, INACT, false, false, S>), lds)) return 1;
+    if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, INACT, false, false, S, SPLIT>), lds)) return 1;
     const long long ntiles = (long long)q.tiles_x * q.tiles_y * q.m_tiles;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return fail("conv2d(f16x3p): bad tile count %lld", ntiles);
     if (p.w16_plane * 2 > 0x7fffffffLL) return fail("conv2d(f16x3p): weight image too large for 32-bit lane offsets");
@@ -739,8 +813,25 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
     if (const int forced = option_get(OPT_P3_BLOCKS); forced > 0) blocks = forced;      // experiments (tools/p3_scaling.py)
     if (blocks > ntiles) blocks = ntiles;
     if constexpr (S != 1) {
-        hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, INACT, false, false, S>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
+        hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, INACT, false, false, S, SPLIT>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
         return launch_status("conv2d(f16x3p, stride 2)");
+    } else if constexpr (SPLIT) {
+        auto elems = [](const V &v) { return v.p ? (unsigned long long)v.H * v.W * v.ld : 0ull; };
+        const bool small32 = elems(p.out) < (1ull << 32) && elems(p.res) < (1ull << 32) && elems(p.res2) < (1ull << 32);
+        if (MF >= 3 && option_get(OPT_P3_STAGE) && small32 && (size_t)q.m_tiles * G::TM * sizeof(float) <= (size_t)G::BIAS_MAX) {
+            static LdsGrant grant_g;
+            if (grant_g.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, false, false, true, 1, true>), G::TOTAL)) return 1;
+            hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, false, false, true, 1, true>), dim3((unsigned)blocks), dim3(kP3Threads), G::TOTAL, st, q);
+            return launch_status("conv2d(f16x3p, split in, staged)");
+        }
+        if (MF == 4 && (p.debug & 256)) {             // diagnostic: in-kernel stamps (tools/p3_stamps.py)
+            static LdsGrant grant_s;
+            if (grant_s.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<4, false, true, false, 1, true>), lds)) return 1;
+            hipLaunchKernelGGL((conv3_f16x3p_kernel<4, false, true, false, 1, true>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
+            return launch_status("conv2d(f16x3p, split in, stamps)");
+        }
+        hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, false, false, false, 1, true>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
+        return launch_status("conv2d(f16x3p, split in)");
     } else {
     if (MF == 4 && !INACT && (p.debug & 256) && option_get(OPT_P3_STAGE) && (size_t)q.m_tiles * G::TM * sizeof(float) <= (size_t)G::BIAS_MAX) {
         static LdsGrant grant_ss;
@@ -775,6 +866,8 @@ static int p3_pick_mf(int frags) {
     return frags >= 4 ? 4 : frags;
 }
 
+int p3_pick_mf_public(int frags) { return p3_pick_mf(frags); }
+
 // Worth it once every CU gets at least one 32x16 tile (measured on the bench workload: thresholds 256 / 512 / 1024 /
 // 2048 tiles give 14.0 / 13.9 / 13.6 / 13.5 frames/s).
 bool conv3_f16x3p_wanted(const ConvP &p) {
@@ -801,7 +894,12 @@ bool conv3s2_f16x3p_wanted(const ConvP &p) {
 int dispatch_conv3s2_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
     const int mf = p3_pick_mf(p.M_pad / 16);
     const bool inact = p.in_act == LSSVC_INACT_LRELU;
-    snprintf(kernel_name, 96, "conv3s2_f16x3p_kernel<%d, %s>", mf, inact ? "true" : "false");
+    snprintf(kernel_name, 96, "conv3s2_f16x3p_kernel<%d, %s>%s", mf, inact ? "true" : "false", p.in_split ? " split" : "");
+    if (p.in_split) {
+        if (mf == 4) return launch_p3<4, false, 2, true>(p, st);
+        if (mf == 3) return launch_p3<3, false, 2, true>(p, st);
+        return fail("conv2d(f16x3p, stride 2, split in): no kernel for MF=%d", mf);
+    }
     if (mf == 4) return inact ? launch_p3<4, true, 2>(p, st) : launch_p3<4, false, 2>(p, st);
     if (mf == 3) return inact ? launch_p3<3, true, 2>(p, st) : launch_p3<3, false, 2>(p, st);
     return fail("conv2d(f16x3p, stride 2): no kernel for MF=%d", mf);
@@ -810,7 +908,13 @@ int dispatch_conv3s2_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
     const int mf = p3_pick_mf(p.M_pad / 16);
     const bool inact = p.in_act == LSSVC_INACT_LRELU;
-    snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s>", mf, inact ? "true" : "false");
+    snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s>%s", mf, inact ? "true" : "false", p.in_split ? " split" : "");
+    if (p.in_split) {
+#define LSSVC_P3_CASE(m) \
+    if (mf == m) return launch_p3<m, false, 1, true>(p, st);
+        LSSVC_P3_CASE(4) LSSVC_P3_CASE(3) LSSVC_P3_CASE(2) LSSVC_P3_CASE(1)
+#undef LSSVC_P3_CASE
+    }
 #define LSSVC_P3_CASE(m) \
     if (mf == m) return inact ? launch_p3<m, true>(p, st) : launch_p3<m, false>(p, st);
     LSSVC_P3_CASE(4) LSSVC_P3_CASE(3) LSSVC_P3_CASE(2) LSSVC_P3_CASE(1)

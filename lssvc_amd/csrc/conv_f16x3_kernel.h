@@ -314,6 +314,7 @@ extern template int dispatch_tile_f16x3_s2<3>(const ConvP &, int, int, hipStream
 bool conv3_f16x3p_wanted(const ConvP &p);
 int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
 bool conv3s2_f16x3p_wanted(const ConvP &p);      // ... its stride-2 form (8x16-pixel output tiles)
+int p3_pick_mf_public(int frags);                // channel fragments per tile the persistent 3x3 kernels pick
 int dispatch_conv3s2_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name);
 // ... and the 7x7 counterpart (conv7_f16x3p.hip)
 bool conv7_f16x3p_wanted(const ConvP &p);

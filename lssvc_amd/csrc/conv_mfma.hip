@@ -187,7 +187,8 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
     char *kname = last_kernel_name();
     bool vec = true;
     for (int i = 0; i < p.n_in; ++i) vec = vec && p.in_vec[i];
-    if (d->precision == LSSVC_PREC_F16X3) {
+    LSSVC_CHECK((d->precision & ~(LSSVC_PREC_MASK | LSSVC_PREC_SPLIT_IN)) == 0, "conv2d: precision 0x%x", d->precision);
+    if ((d->precision & LSSVC_PREC_MASK) == LSSVC_PREC_F16X3) {
         // fp16-MFMA 3-term split: built for the MFMA-bound layers (3x3 / 7x7, stride 1, 16-byte addressable inputs);
         // everything else (1x1, strided, 2..3-channel inputs, GDN) stays on the exact-fp32 kernel
         LSSVC_CHECK(d->weight16 != nullptr, "conv2d: precision f16x3 needs weight16");
@@ -197,6 +198,18 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         p.w16 = d->weight16;
         p.w16_unscale = d->weight16_unscale != 0.0f ? d->weight16_unscale : 1.0f;
         p.w16_plane = chunks16 * ks * ks * (long long)p.M_pad * 16;
+        if (d->precision & LSSVC_PREC_SPLIT_IN) {
+            // pre-split inputs: only the persistent 3x3 kernels read them (there is no fallback that would silently convert)
+            LSSVC_CHECK(ks == 3 && d->in_act == LSSVC_INACT_NONE, "conv2d: pre-split inputs need a 3x3 conv without input activation (k=%d in_act=%d)", ks, d->in_act);
+            for (int i = 0; i < d->n_in; ++i)
+                LSSVC_CHECK(d->in[i].ld % 16 == 0 && d->in[i].ld >= (d->in[i].C + 15) / 16 * 16 && (reinterpret_cast<uintptr_t>(d->in[i].ptr) & 63) == 0,
+                            "conv2d: input %d is not a pre-split view (C=%d ld=%d)", i, d->in[i].C, d->in[i].ld);
+            p.in_split = 1;
+            LSSVC_CHECK(option_get(sd == 1 ? OPT_P3_ON : OPT_P3_S2) && p.fast_epi, "conv2d: pre-split inputs need the persistent 3x3 kernel (fused fast epilogue)");
+            if (sd == 1) return dispatch_conv3_f16x3p(p, st, kname);
+            LSSVC_CHECK(p3_pick_mf_public(p.M_pad / 16) >= 3, "conv2d: stride-2 conv with pre-split inputs needs >= 48 output channels");
+            return dispatch_conv3s2_f16x3p(p, st, kname);
+        }
         if (vec && sd == 1 && ks == 3 && d->in_act != LSSVC_INACT_SQUARE && conv3_f16x3p_wanted(p))
             return dispatch_conv3_f16x3p(p, st, kname);
         static const int s2_on = getenv("LSSVC_F16X3_S2") ? atoi(getenv("LSSVC_F16X3_S2")) : 1;

@@ -37,6 +37,8 @@ struct ConvP {
     int debug;       // perf-ablation switches (env LSSVC_CONV_DEBUG; results are WRONG when set): 1 skip prefetch loads, 2 skip LDS stores, 4 skip barriers, 8 no stagger, 16 skip LDS fragment reads, 32 skip the epilogue, 64 skip the fp32 -> fp16 split (K-sliced 1x1), 256 in-kernel stamps
     int out_vec, res_vec, gdn_vec;
     int fast_epi;    // host: Cout % 4 == 0, 16-byte addressable out / residual, no pixel shuffle, no GDN -> straight-line epilogue
+    int in_split;    // every input is a PRE-SPLIT tensor (LSSVC_PREC_SPLIT_IN): [pixel][16-channel chunk][hi x16 | lo x16] fp16, activation applied
+    int out_split;   // the output is written pre-split (LSSVC_PREC_SPLIT_OUT), after out_act
 };
 
 constexpr int CP = 12;  // LDS row pitch in floats (CK=8 + 4 pad)

@@ -648,6 +648,45 @@ extern "C" int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float sl
     return binary(in, nullptr, out, 2, slope, stream, "lrelu");
 }
 
+// fp32 NHWC -> PRE-SPLIT layout (lssvc_hip.h, LSSVC_PREC_SPLIT_IN): per pixel and 16-channel chunk 64 bytes, [hi: 16 x fp16 | lo: 16 x
+// fp16] of act(x) saturated at +-65504 -- exactly what the f16x3 conv kernels make of an fp32 input while staging it (conv_f16x3_kernel.h
+// store_patch, conv3_f16x3p.hip store_patch). One thread = one pixel x one 4-channel quad of the padded channel range; channels >= C of the
+// last chunk are written as zeros.
+typedef _Float16 ps_f16x4 __attribute__((ext_vector_type(4)));
+__global__ void presplit_kernel(V in, V out, int in_act, float slope, int qpp, long long total, int vec) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)total) return;
+    const unsigned pix = idx / (unsigned)qpp;
+    const int c = (int)(idx - pix * (unsigned)qpp) * 4;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < in.C) r = ld4(in, (size_t)pix, c, vec);
+    float v[4] = {r.x, r.y, r.z, r.w};
+    ps_f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = v[j];
+        if (in_act == LSSVC_INACT_LRELU) x = fmaxf(x, slope * x);                  // 0 <= slope <= 1 (checked by the host): exact
+        x = fminf(fmaxf(x, -65504.f), 65504.f);
+        h[j] = (_Float16)x;
+        l[j] = (_Float16)(x - (float)h[j]);
+    }
+    _Float16 *o = reinterpret_cast<_Float16 *>(out.p + (size_t)pix * out.ld + (c >> 4) * 16) + (c & 15);
+    *reinterpret_cast<ps_f16x4 *>(o) = h;
+    *reinterpret_cast<ps_f16x4 *>(o + 16) = l;
+}
+extern "C" int lssvc_presplit(const lssvc_view *in, const lssvc_view *out, int32_t in_act, float in_slope, void *stream) {
+    LSSVC_CHECK(view_ok(in) && view_ok(out) && same_shape(in, out), "presplit: bad views");
+    LSSVC_CHECK(in_act == LSSVC_INACT_NONE || (in_act == LSSVC_INACT_LRELU && in_slope >= 0.0f && in_slope <= 1.0f), "presplit: in_act %d slope %g", in_act, in_slope);
+    LSSVC_CHECK(out->ld % 16 == 0 && out->ld >= (out->C + 15) / 16 * 16 && (reinterpret_cast<uintptr_t>(out->ptr) & 63) == 0,
+                "presplit: the pre-split view needs a 64-byte aligned base and a pixel pitch that is a multiple of 16 and covers its padded chunks (C=%d ld=%d)", out->C, out->ld);
+    const int qpp = (out->C + 15) / 16 * 4;
+    const long long total = (long long)out->H * out->W * qpp;
+    LSSVC_ITEMS_OK(total, "presplit");
+    hipLaunchKernelGGL(presplit_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(out), (int)in_act, in_slope, qpp,
+                       total, (int)vec4_ok(in));
+    return launch_status("presplit");
+}
+
 // F.pad(x, (left, right, top, bottom), value 0) with negative entries cropping, as ONE launch that writes every element of
 // `out` (source pixel (y - top, x - left) where it exists, zero elsewhere): get_depadded_feature, IntraSS.py:124-135.
 __global__ void pad_crop_kernel(V in, V out, int left, int top, int cg, long long total, int vec) {

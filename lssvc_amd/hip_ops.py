@@ -203,10 +203,11 @@ PLAN_RECORDER = None          # plan_compiler.Recorder while a frame plan is bei
 
 class T:
     """An H x W x C fp32 view (batch 1) with pixel pitch `ld` into a flat torch buffer."""
-    __slots__ = ("buf", "H", "W", "C", "ld", "off", "_v")
+    __slots__ = ("buf", "H", "W", "C", "ld", "off", "_v", "split")
 
-    def __init__(self, buf, H, W, Cc, ld, off=0):
+    def __init__(self, buf, H, W, Cc, ld, off=0, split=False):
         self.buf, self.H, self.W, self.C, self.ld, self.off = buf, H, W, Cc, ld, off
+        self.split = split        # True: a PRE-SPLIT tensor (lssvc_hip.h LSSVC_PREC_SPLIT_IN): fp16 hi | lo per 16-channel chunk, only 3x3 f16x3 convs read it
         self._v = View(buf.data_ptr() + 4 * off, H, W, Cc, ld)
 
     @staticmethod
@@ -339,6 +340,9 @@ def _conv_launch(inputs, prepared, KH, KW, stride, pad_t, pad_l, out, *, in_act=
         return out
     if w16 is not None:
         d.precision, d.weight16, d.weight16_unscale = _lib.PREC_F16X3, w16[0].data_ptr(), w16[1]
+    if any(t.split for t in inputs):
+        assert w16 is not None and all(t.split for t in inputs) and in_act is None, "pre-split inputs: f16x3 conv, all inputs, no input activation"
+        d.precision |= _lib.PREC_SPLIT_IN
     if OP_LOG is None:
         check(lib.lssvc_conv2d(C.byref(d), stream_ptr()))
         return out
@@ -627,6 +631,18 @@ def cat(parts):
     for p in parts:
         copy(p, out.slice(a, a + p.C))
         a += p.C
+    return out
+
+
+def presplit(x, in_act=None, in_slope=0.01, out=None):
+    """fp32 view -> pre-split view (fp16 hi | lo per 16-channel chunk, the input activation applied): lssvc_presplit."""
+    if out is None:
+        cp = (x.C + 15) // 16 * 16
+        if ARENA is not None:
+            out = T(ARENA.alloc_f32(x.H * x.W * cp), x.H, x.W, x.C, cp, split=True)
+        else:
+            out = T(torch.empty(x.H * x.W * cp, dtype=torch.float32, device=x.device), x.H, x.W, x.C, cp, split=True)
+    check(lib.lssvc_presplit(x.ref, out.ref, _INACT[in_act], in_slope, stream_ptr()))
     return out
 
 

@@ -23,6 +23,9 @@ def main():
         b = torch.randn(cout, generator=g)
         Wt = WeightStore({"c.weight": w, "c.bias": b}, dev)
         x = ops.T(torch.randn(H * W * cin, device=dev), H, W, cin, cin)
+        split = os.environ.get("P3_SPLIT", "0") == "1"       # pre-split input: the patch by LDS-DMA (round 5)
+        if split:
+            x = ops.presplit(x)
         stamps = torch.zeros(2 * 256 * 4 * 8, dtype=torch.int64, device=dev)      # consumer records, then producer records
         out = ops.T.empty(H, W, cout, dev)
         import ctypes as C
@@ -39,10 +42,16 @@ def main():
         d.act, d.slope, d.out_scale, d.pixel_shuffle = 0, 0.01, 1.0, 0
         d.residual = _lib.View(None, 0, 0, 0, 0)
         d.out = out.v
-        d.precision, d.weight16, d.weight16_unscale = _lib.PREC_F16X3, w16[0].data_ptr(), w16[1]
-        for _ in range(30):                       # warm the clock governor with back-to-back launches
+        d.precision, d.weight16, d.weight16_unscale = _lib.PREC_F16X3 | (_lib.PREC_SPLIT_IN if split else 0), w16[0].data_ptr(), w16[1]
+        for _ in range(200):                      # warm the clock governor with back-to-back launches
             _lib.check(_lib.lib.lssvc_conv2d(C.byref(d), ops.stream_ptr()))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            _lib.check(_lib.lib.lssvc_conv2d(C.byref(d), ops.stream_ptr()))
+        e1.record()
         torch.cuda.synchronize()
+        wall_us = e0.elapsed_time(e1) / 30 * 1e3
         allrec = stamps.view(-1, 8).cpu().double()
         s = allrec[:1024]
         s = s[s[:, 5] > 0]
@@ -51,8 +60,8 @@ def main():
         comp, bar, epi, cyc, real, phases, tiles = (s[:, i].median().item() for i in range(7))
         zero = s[:, 7].median().item()
         clock = cyc / real * 100.0                 # s_memrealtime ticks at 100 MHz
-        print("%s (%s): per consumer wave, median over %d waves: %d phases / %d tiles; total %.0f cycles at %.0f MHz" %
-              (name, _lib.lib.lssvc_conv2d_last_kernel().decode(), s.shape[0], phases, tiles, cyc, clock))
+        print("%s (%s) LSSVC_CONV_DEBUG=%s: %.1f us per launch; per consumer wave, median over %d waves: %d phases / %d tiles; total %.0f cycles at %.0f MHz" %
+              (name, _lib.lib.lssvc_conv2d_last_kernel().decode(), os.environ["LSSVC_CONV_DEBUG"], wall_us, s.shape[0], phases, tiles, cyc, clock))
         print("   compute %5.1f %% (%.0f cyc/phase; 336 MFMAs = 5376 issue cycles)   barrier wait %5.1f %% (%.0f cyc/phase)   "
               "epilogue %5.1f %% (%.0f cyc/tile, of which zeroing the accumulators %.0f)" % (100 * comp / cyc, comp / phases, 100 * bar / cyc, bar / phases,
                                                     100 * epi / cyc, epi / max(tiles, 1), zero / max(tiles, 1)))
