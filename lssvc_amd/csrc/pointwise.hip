@@ -6,6 +6,7 @@
 //
 // Compiled with -ffp-contract=off: the reference evaluates these as separate ATen ops (mul, add, ...),
 // so no FMA contraction is allowed if results are to track the fp32 CPU oracle.
+#include <cstdlib>
 #include "common.h"
 
 namespace lssvc {
@@ -734,10 +735,29 @@ __global__ void clamp_flat_kernel(float *x, float lo, float hi, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = fminf(fmaxf(x[i], lo), hi);
 }
 
+// Zero fill as a KERNEL launch, not hipMemsetAsync (round 5): inside a stream capture a memset becomes a memset NODE of the hipGraph
+// (DESIGN section 6.1 for what that did to replayed frame plans); a kernel node is ordered like every other launch of the frame.
+__global__ void fill_zero_kernel(unsigned char *p, long long nbytes) {
+    const long long head = ((16 - (long long)(reinterpret_cast<uintptr_t>(p) & 15)) & 15) < nbytes ? ((16 - (long long)(reinterpret_cast<uintptr_t>(p) & 15)) & 15) : nbytes;
+    const long long n16 = (nbytes - head) / 16;
+    uint4 *q = reinterpret_cast<uint4 *>(p + head);
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    for (long long i = tid; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = tid; i < head; i += stride) p[i] = 0;
+    for (long long i = head + n16 * 16 + tid; i < nbytes; i += stride) p[i] = 0;
+}
 extern "C" int lssvc_fill_zero(void *ptr, int64_t nbytes, void *stream) {
     LSSVC_CHECK(ptr && nbytes >= 0, "fill_zero: bad arguments");
-    if (nbytes) LSSVC_HIP(hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream));
-    return 0;
+    if (nbytes == 0) return 0;
+    static const int use_memset = getenv("LSSVC_FILL_MEMSET") ? atoi(getenv("LSSVC_FILL_MEMSET")) : 0;      // the round-4 form, for the record
+    if (use_memset) {
+        LSSVC_HIP(hipMemsetAsync(ptr, 0, (size_t)nbytes, (hipStream_t)stream));
+        return 0;
+    }
+    const long long blocks = (nbytes / 16 + 255) / 256 + 1;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned char *>(ptr), (long long)nbytes);
+    return launch_status("fill_zero");
 }
 
 extern "C" int lssvc_clamp_inplace(float *x, int64_t n, float lo, float hi, void *stream) {

@@ -32,10 +32,14 @@ class LSSVC_extend(_HostModel):
     def __init__(self):
         super().__init__()
         self._sd = None
-        self._ahead = None             # look-ahead protocol: {"for": frame id, "bits": its four BL bit counts} of the base layer coded ahead
-        self._stash = [None, None]     # ... and that base layer's tensors (STASH_KEYS), by frame parity
+        self._ahead = None             # look-ahead protocol: {"for": frame id, "geom": ..., "bits": its four BL bit counts} of the base layer coded ahead
         self._ahead_stream = None      # the stream BL(t+1) is launched on
-        self._el_out = [None, None]    # EL reconstruction + feature of the look-ahead plans, by frame parity (persistent)
+        # Persistent buffers of the look-ahead plans, PER GEOMETRY (BL size, EL size, scale, padding, conv precision: everything that
+        # fixes their shapes and the launch sequences that have their addresses baked in) and by frame parity: the base layer coded
+        # ahead (STASH_KEYS) and the EL reconstruction + feature. One model object serves every dataset and ratio of a harness run
+        # (harness._load_nets), so a second size must get its own buffers AND its own plans; at most MAX_GEOMS are kept.
+        self._lookahead_bufs = {}      # geom -> {"stash": [None, None], "el_out": [None, None]}
+        self._geom = None              # the geometry of the frame being issued
 
     def load_dict(self, pretrained_dict, strict=True):
         """LSSVC.load_dict (LSSVC_net.py:141-149): strip 'module.' and load strictly."""
@@ -481,6 +485,30 @@ class LSSVC_extend(_HostModel):
     # clamped to [0,1] -- what test.py:249-250 makes of the DPB before the next frame; a caller of this mode promises that clamp --
     # and leaves its four results in persistent buffers (self._stash, by frame parity) for the next call, which codes its EL only.
     STASH_KEYS = ("recon", "feature", "y_hat", "mv_hat")
+    MAX_GEOMS = 3
+
+    def _bufs(self, geom=None):
+        """The look-ahead buffers of a geometry (default: the frame being issued), least recently used geometries dropped together
+        with every frame plan that has their addresses baked in."""
+        geom = self._geom if geom is None else geom
+        b = self._lookahead_bufs.pop(geom, None)
+        if b is None:
+            assert not torch.cuda.is_current_stream_capturing()
+            b = {"stash": [None, None], "el_out": [None, None]}
+            while len(self._lookahead_bufs) >= self.MAX_GEOMS:
+                old = next(iter(self._lookahead_bufs))
+                del self._lookahead_bufs[old]
+                self._plans = {k: v for k, v in self._plans.items() if old not in k}
+        self._lookahead_bufs[geom] = b                     # (re-)insert as most recently used
+        return b
+
+    @property
+    def _stash(self):
+        return self._bufs()["stash"]
+
+    @property
+    def _el_out(self):
+        return self._bufs()["el_out"]
 
     def _ahead_bl_body(self, t, src_parity, out_parity):
         """BL(t+1): reference = clamp(frame t's BL reconstruction) and its feature, from the stash (src_parity) or, behind a frame
@@ -548,19 +576,25 @@ class LSSVC_extend(_HostModel):
                    "ref_feature_bl": ref_feature_bl, "ref_feature_el": ref_feature_el}
         t_issue = time.perf_counter()
         stashed = None
-        if frame_id is None or not ops.MULTI_STREAM:
-            # (single-stream mode, LSSVC_STREAMS=0, codes the frames one after the other whatever the caller offers: with the
-            # look-ahead plans captured in that mode, replayed graphs -- the plain plans included -- gave wrong results,
-            # deterministically, and the cause was not found in the time there was (not a race: it happens with the two plans
-            # serialised; not an out-of-bounds write or an uninitialised read of the frame's launches: guard zones and NaN-filled
-            # buffers come back clean; a trivial branch in every graph does not cure it). The default mode is held by
-            # tests/test_gpu_graph.py and by bench.py's bit check on every run.)
+        if frame_id is None:
+            # (Round 4 also sent single-stream mode, LSSVC_STREAMS=0, down this branch: with the look-ahead plans captured there,
+            # replayed graphs -- the plain plans included -- gave deterministically wrong results. Round 5 found the cause:
+            # T.zeros went through hipMemsetAsync, which a stream capture records as a MEMSET NODE, and with several captured
+            # frame plans alive this ROCm replays such nodes wrongly (the zero-initialised SpyNet flow / four-part buffers came back
+            # stale; every other node was right). lssvc_fill_zero is a kernel launch now, and the mode needs no guard:
+            # tools/debug_lookahead_single.py, profiles/r05_lookahead_root_cause.txt)
             self._ahead = None
             frame_id = None
             r = self._run_body(self._frame_key(tensors), tensors, self._frame_body)
         else:
             fid = int(frame_id)
-            stashed = self._ahead if (self._ahead is not None and self._ahead["for"] == fid) else None
+            # everything the look-ahead buffers' shapes and the plans that bake their addresses in depend on (one
+            # model object codes several sizes and ratios in a harness run)
+            geom = ("geom", tuple(x_bl.shape[1:]), tuple(x_el.shape[1:]), float(self.scale_factor), self.shape_hr, self.pad_size, ops.CONV_PRECISION)
+            self._geom = geom
+            if next_x_bl is not None:
+                assert tuple(next_x_bl.shape) == tuple(x_bl.shape), "next_x_bl is %s, x_bl %s" % (tuple(next_x_bl.shape), tuple(x_bl.shape))
+            stashed = self._ahead if (self._ahead is not None and self._ahead["for"] == fid and self._ahead["geom"] == geom) else None
             self._ahead = None
             main = torch.cuda.current_stream(self.device)
             if self._ahead_stream is None:
@@ -572,7 +606,7 @@ class LSSVC_extend(_HostModel):
                 tb = {"next_x_bl": next_x_bl}
                 if src is not None:
                     tb.update(ref_recon=src["recon_bl"].to_nchw(), ref_feature=src["feature_bl"].to_nchw())
-                key = ("p-ahead-bl", src is None, fid & 1) + tuple(shape(v) for v in tb.values())
+                key = ("p-ahead-bl", geom, src is None, fid & 1) + tuple(shape(v) for v in tb.values())
                 side.wait_stream(main)                     # (the previous frame, the caller's clamp of the DPB; not this frame's EL)
                 with torch.cuda.stream(side):
                     self._run_body(key, tb, lambda ins: self._ahead_bl_body(ins, (fid & 1) if src is None else None, (fid + 1) & 1))
@@ -590,7 +624,7 @@ class LSSVC_extend(_HostModel):
                                             and v.stride() == (prev[k].H * prev[k].W * prev[k].C, 1, prev[k].W * prev[k].C, prev[k].C)
                                             for k, v in (("recon", ref_frame_el), ("feature", ref_feature_el))):
                     te.update(ref_frame_el=None, ref_feature_el=None)       # the previous frame's outputs where they are (_ahead_el_body)
-                r = self._run_body(("p-ahead-el", fid & 1) + tuple(shape(v) for v in te.values()), te,
+                r = self._run_body(("p-ahead-el", geom, fid & 1) + tuple(shape(v) for v in te.values()), te,
                                    lambda ins: self._ahead_el_body(ins, fid & 1))      # ... EL(t) beside it
             main.wait_stream(side)
         self.last_issue_s = time.perf_counter() - t_issue        # host time to put the frame on the stream (no GPU wait)
@@ -604,7 +638,7 @@ class LSSVC_extend(_HostModel):
         out["bit_bl"] = b[0] + b[1] + b[2] + b[3]          # y + z + mv_y + mv_z  (dmc_net.py:473)
         out["bit_el"] = s[4] + s[5] + s[6] + s[7]          # y + mv_y + z + mv_z  (LSSVC_net.py:508)
         if frame_id is not None and next_x_bl is not None:
-            self._ahead = {"for": int(frame_id) + 1, "bits": s[8:12]}
+            self._ahead = {"for": int(frame_id) + 1, "geom": self._geom, "bits": s[8:12]}
         return out
 
     def encode_decode_extend(self, x_bl, x_el, dpb, output_path_bl, output_path_el):

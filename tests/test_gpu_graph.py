@@ -21,7 +21,7 @@ def _nets(seed, gain):
     return inet, pnet
 
 
-def _code(inet, pnet, x_bl, x_el, H, W, gops, frames, lookahead=False):
+def _code(inet, pnet, x_bl, x_el, H, W, gops, frames, lookahead=False, scale=2.0):
     """test.py's loop; returns per frame (bit_bl, bit_el, clones of the four DPB tensors + mv_hat).
     lookahead: the P-frames name the next frame's base-layer input (LSSVC_extend.forward_one_frame's look-ahead protocol)."""
     rows = []
@@ -29,8 +29,8 @@ def _code(inet, pnet, x_bl, x_el, H, W, gops, frames, lookahead=False):
         dpb = None
         for t in range(frames):
             ahead = dict(next_x_bl=(x_bl[t + 1:t + 2] if t + 1 < frames else None), frame_id=t) if lookahead else {}
-            inet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
-            pnet.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+            inet.set_scale_information(scale, (H, W), (0, 0, 0, 0))
+            pnet.set_scale_information(scale, (H, W), (0, 0, 0, 0))
             if t == 0:
                 r = inet.encode_decode(x_bl[t:t + 1], x_el[t:t + 1], None, None)
                 dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
@@ -72,7 +72,7 @@ def test_graph_replay_is_bit_identical_to_eager(H, W, precision):
         hip_ops.set_conv_precision(old)
 
 
-@pytest.mark.parametrize("streams,alias", [(True, False), (True, True), (False, False)])
+@pytest.mark.parametrize("streams,alias", [(True, False), (True, True), (False, False), (False, True)])
 def test_lookahead_base_layer_is_bit_identical(streams, alias):
     """BL(t+1) coded beside EL(t) (forward_one_frame's look-ahead protocol): bits and every DPB tensor of every frame equal the plain
     loop's, eager and replayed from the look-ahead plans, with and without side streams inside the layers."""
@@ -92,10 +92,9 @@ def test_lookahead_base_layer_is_bit_identical(streams, alias):
         pnet.set_graph_mode(True, alias_outputs=alias)      # memory, which the next EL then reads in place instead of loading it
         got += _code(inet, pnet, x_bl, x_el, H, W, gops, frames, lookahead=True)     # GOP 0: eager + captures, later: replays
         plans = [k for k in pnet._plans if str(k[0]).startswith("p-ahead")]         # BL(t+1): behind a whole frame + two parities; EL(t): two parities
-        if streams:                                                                  # (+ with alias: the first EL plan loads its references, the others are bound)
-            assert len(plans) == (6 if alias else 5) and all(pnet._plans[k].graph is not None for k in plans), plans
-        else:
-            assert not plans                                                         # single-stream mode codes frame after frame (inter.py)
+        # (+ with alias: the first EL plan loads its references, the others are bound.) Single-stream mode captures them too since round 5:
+        # what broke it in round 4 was a hipMemsetAsync recorded as a memset node of the frame plans (lssvc_fill_zero is a kernel now).
+        assert len(plans) == (6 if alias else 5) and all(pnet._plans[k].graph is not None for k in plans), plans
         for i, (bb, be, tens) in enumerate(got):
             wb, we, wt = want[i % frames]
             assert (bb, be) == (wb, we), (i, bb, wb, be, we)
@@ -103,6 +102,38 @@ def test_lookahead_base_layer_is_bit_identical(streams, alias):
                 assert (a is None and b is None) or torch.equal(a, b), i
     finally:
         hip_ops.MULTI_STREAM = old
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_lookahead_serves_several_sizes_and_ratios_through_one_model(graph):
+    """harness._load_nets keeps ONE LSSVC_extend per worker for every dataset and ratio of a run: the look-ahead protocol's
+    persistent buffers and the plans that bake their addresses in are per geometry (BL size, EL size, scale), so sizes may alternate --
+    same BL size under two EL sizes included -- and every frame equals the plain loop's, eager and replayed."""
+    from lssvc_amd.synth import synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic
+    frames = 4
+    jobs = [(128, 256, 2.0, (64, 128)), (192, 192, 1.5, (128, 128)), (256, 256, 2.0, (128, 128)), (128, 256, 2.0, (64, 128)), (192, 192, 1.5, (128, 128))]
+    clips = {}
+    for H, W, scale, bl in jobs:
+        if (H, W, scale) not in clips:
+            clip = synth_clip(frames, H, W, seed=H + W).float() / 255.0
+            clips[(H, W, scale)] = (imresize_bicubic(clip, bl).clamp_(0, 1).to(DEV), clip.to(DEV))
+    inet, pnet = _nets(4, 0.6)
+    want = {k: _code(inet, pnet, v[0], v[1], k[0], k[1], 1, frames, scale=k[2]) for k, v in clips.items()}
+    inet.set_graph_mode(graph)
+    pnet.set_graph_mode(graph)
+    assert pnet.MAX_GEOMS >= 3
+    pnet.MAX_PLANS = 40                                # (three geometries x six P plans: none evicted before its replays)
+    for rounds in range(3 if graph else 1):            # graph mode: eager first calls, captures, replays
+        for H, W, scale, _ in jobs:
+            x_bl, x_el = clips[(H, W, scale)]
+            got = _code(inet, pnet, x_bl, x_el, H, W, 1, frames, lookahead=True, scale=scale)
+            for i, (bb, be, tens) in enumerate(got):
+                wb, we, wt = want[(H, W, scale)][i]
+                assert (bb, be) == (wb, we), (H, W, scale, rounds, i, bb, wb, be, we)
+                for a, b in zip(tens, wt):
+                    assert (a is None and b is None) or torch.equal(a, b), (H, W, scale, rounds, i)
+    assert len(pnet._lookahead_bufs) == 3
 
 
 def test_graph_mode_host_time_per_frame():
