@@ -425,14 +425,29 @@ def config3_2160p(device, gop=12):
         torch.cuda.empty_cache()
 
 
-def cpu_baseline(full_size=False):
+def _host_description():
+    import platform
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"cpu": cpu, "os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "platform": platform.platform(),
+            "torch": torch.__version__}
+
+
+def cpu_baseline(mode="full"):
     """The CPU oracle (a port of the reference's PyTorch CPU path, pinned bit-exact to it on the golden fixtures) timed on
-    this box's host cores on a BOUNDED sample: (i) all cores the process may use, 1 I + 1 P frame
-    at EL 384x640 / BL 192x320 = 1/9 of the 1152x1920 workload's pixels, frames/s scaled by 1/9 (conv work is linear in
-    pixels), GOP time = I + 31 P; (ii) torch.set_num_threads(1), which is what the reference pins per worker
-    (test.py:642), on a 1/22.5-size sample (EL 256x384). `--cpu-baseline-full` times (i) at the full size instead: on the
-    GPU box's 16-core host share that is several minutes of CPU work for the two frames, which is why it is not the
-    default."""
+    this box's host cores on a BOUNDED sample of the benchmark's own workload, IN THIS RUN:
+      mode "full" (default, round 5): 1 I-frame + 1 P-frame at the FULL EL 1152x1920 / BL 576x960 size on all cores the process
+          may use (capped at the 16-core share of a 1-GPU box), no scaling: about 70 s of CPU work; frames/s of the GOP-32
+          mix = 32 / (I + 31 P). `value` is this measurement; the once-per-round file under profiles/ (1 I + 2 P, the second
+          P a steady-state one) is quoted beside it as a cross-check only.
+      mode "steady": the same with a second, steady-state P-frame (`--cpu-baseline-full`, ~2 min).
+      mode "small": the round-1..4 default, 1 I + 1 P at EL 384x640 (1/9 of the pixels) scaled by 1/9 (`--cpu-baseline-small`;
+          it flatters the CPU by about a third: smaller working set).
+    Beside it, always: torch.set_num_threads(1) -- what the reference pins per worker (test.py:642) -- on a 1/22.5-size sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
         usable = len(os.sched_getaffinity(0))
@@ -440,9 +455,11 @@ def cpu_baseline(full_size=False):
         usable = os.cpu_count()
     cores = max(1, min(usable, 16))       # a 1-GPU box owns a 16-core share of a 256-thread host: more threads than that
     #                                        oversubscribe the share and run an order of magnitude slower (measured)
+    full_size = mode != "small"
     H, W = (1152, 1920) if full_size else (384, 640)
-    log("  cpu baseline: %d threads (os.cpu_count() = %s), 1 I + 1 P at EL %dx%d ..." % (cores, os.cpu_count(), H, W))
-    t_i, t_p, t_ps = _oracle_frames(H, W, cores, n_p=2 if full_size else 1)
+    n_p = 2 if mode == "steady" else 1
+    log("  cpu baseline: %d threads (os.cpu_count() = %s), 1 I + %d P at EL %dx%d ..." % (cores, os.cpu_count(), n_p, H, W))
+    t_i, t_p, t_ps = _oracle_frames(H, W, cores, n_p=n_p)
     scale = (H * W) / (1152.0 * 1920.0)
     fps = GOP / (t_i + (GOP - 1) * t_p) * scale
     h1, w1 = 256, 384                     # smallest sample whose BL (128x192) is still a multiple of 64
@@ -452,23 +469,19 @@ def cpu_baseline(full_size=False):
     torch.set_num_threads(cores)
     size = "the full EL 1152x1920 / BL 576x960 size, no scaling" if full_size else \
         "EL 384x640 / BL 192x320 (1/9 of the pixels), scaled by 1/9"
-    full = _cached_cpu_baseline()
-    sample = ("1 I-frame (%.2f s) + 1 P-frame (%.2f s; with --cpu-baseline-full the steady-state second P-frame) at %s, GOP-32 mix (1 I + 31 P); %d threads "
+    sample = ("measured in this run: 1 I-frame (%.2f s) + %s (%.2f s) at %s, GOP-32 mix (1 I + 31 P); %d threads "
               "(os.cpu_count() = %s, affinity = %d, capped at the 16-core share of a 1-GPU box); torch %s CPU fp32" % (
-                  t_i, t_p, size, cores, os.cpu_count(), usable, torch.__version__))
+                  t_i, "the steady-state second P-frame" if n_p == 2 else "the first P-frame", t_p, size, cores, os.cpu_count(), usable, torch.__version__))
     single = {"value": round(fps1, 6), "unit": "frames/s", "cores": 1,
               "sample": "torch.set_num_threads(1) (test.py:642): 1 I (%.2f s) + 1 P (%.2f s) at EL %dx%d, scaled by "
                         "pixel count (1/22.5)" % (s_i, s_p, h1, w1)}
-    this_run = {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "p_frame_seconds": [round(t, 2) for t in t_ps], "sample": sample}
-    if full_size or not full or "value" not in full:
-        this_run.update(kind="port", full_size_measured_once=full, single_thread=single)
-        return this_run
-    # headline = the FULL-SIZE measurement (1 I + 2 P at 1152x1920, minutes of CPU work: made once per round on a GPU box's
-    # host by `python bench.py --cpu-baseline-only` and kept under profiles/); the bounded sample this run timed is beside
-    # it -- scaled from 1/9 of the pixels it flatters the CPU by about a third (smaller working set)
-    return {"value": full["value"], "unit": "frames/s", "cores": full.get("cores", cores), "kind": "port",
-            "sample": "FULL SIZE, measured once (%s): %s" % (full.get("source"), full.get("sample")),
-            "host": full.get("host"), "bounded_sample_this_run": this_run, "single_thread": single}
+    out = {"value": round(fps, 6), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
+           "i_frame_seconds": round(t_i, 2), "p_frame_seconds": [round(t, 2) for t in t_ps], "host": _host_description(), "single_thread": single}
+    cached = _cached_cpu_baseline()
+    if cached and "value" in cached:
+        out["cross_check_measured_once"] = {"value": cached["value"], "cores": cached.get("cores"), "p_frame_seconds": cached.get("p_frame_seconds"),
+                                            "host": cached.get("host"), "source": cached.get("source")}
+    return out
 
 
 def _free_port():
@@ -540,7 +553,8 @@ def main():
     ap.add_argument("--no-streams", action="store_true", help="one stream: no parallel branches in the frame plans (same as LSSVC_STREAMS=0)")
     ap.add_argument("--no-lookahead", action="store_true", help="code BL(t+1) after EL(t), not beside it (the plain per-frame protocol of test.py)")
     ap.add_argument("--no-h2d-pass", action="store_true", help="skip the second timed loop (per-frame H2D + pre-processing included)")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline at the full 1152x1920 size, 1 I + 2 P (takes > 7 min on a 16-core host share)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="CPU baseline at the full 1152x1920 size with a steady-state second P-frame, 1 I + 2 P (~2 min; the default is 1 I + 1 P, ~70 s)")
+    ap.add_argument("--cpu-baseline-small", action="store_true", help="CPU baseline on the 1/9-size sample of rounds 1-4 (EL 384x640, scaled; ~7 s)")
     ap.add_argument("--no-side-configs", action="store_true", help="skip the configs[3] (2160p IP12) and configs[4] (write_stream=1) side measurements")
     ap.add_argument("--precision", choices=["f32", "f16x3"], default=None,
                     help="conv arithmetic (default: lssvc_amd's default, see hip_ops.CONV_PRECISION)")
@@ -552,17 +566,8 @@ def main():
     if os.environ.get("LSSVC_BENCH_DRYRUN", "0") == "1":
         return launcher_dry_run(args)
     if args.cpu_baseline_only:
-        import platform
-        d = cpu_baseline(full_size=True)
-        d.pop("full_size_measured_once", None)
-        cpu = ""
-        try:
-            with open("/proc/cpuinfo") as f:
-                cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
-        except OSError:
-            pass
-        d["host"] = {"cpu": cpu, "os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "platform": platform.platform(),
-                     "torch": torch.__version__}
+        d = cpu_baseline("steady")
+        d.pop("cross_check_measured_once", None)
         print(json.dumps(d), flush=True)
         return
 
@@ -728,8 +733,10 @@ def main():
             # progress outside the dominant kernel: ALGORITHMIC conv flops of the whole GOP over the GOP's wall time. The
             # per-P-frame figure is the sampled launches' (the GOP's last EVENT_FRAMES P-frames); the I-frame's share comes from
             # SURVEY section 8d (5.04 TFLOP).
-            p_tflop = roof["conv_tflop_sampled"] / EVENT_FRAMES
-            gop_tflop = 5.04 + (args.frames - 1) * p_tflop
+            logged = max(1, min(args.frames - 1, EVENT_FRAMES))       # P-frames that carried events (encode_gop: the GOP's last min(n - 1, EVENT_FRAMES))
+            p_tflop = roof["conv_tflop_sampled"] / logged
+            # (the I-frame's 5.04 TFLOP is SURVEY section 8d's figure for EL 1152x1920 / BL 576x960; conv work is linear in pixels)
+            gop_tflop = 5.04 * (shape_hr[0] * shape_hr[1]) / (1152.0 * 1920.0) + (args.frames - 1) * p_tflop
             ach = gop_tflop / (dt / args.steps)
             out["whole_frame"] = {"algorithmic_conv_tflop_per_gop": round(gop_tflop, 1), "achieved": round(ach, 1), "unit": "TFLOP/s",
                                   "peak": PEAK_FP16_MFMA_TFLOPS, "frac": round(ach / PEAK_FP16_MFMA_TFLOPS, 4),
@@ -756,8 +763,8 @@ def main():
                 except Exception as e:
                     out[name] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            log("timing the CPU oracle on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(full_size=args.cpu_baseline_full)
+            log("timing the CPU oracle on a bounded sample (1 I + 1 P at full size: about 70 s) ...")
+            out["cpu_baseline"] = cpu_baseline("steady" if args.cpu_baseline_full else ("small" if args.cpu_baseline_small else "full"))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

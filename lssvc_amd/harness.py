@@ -27,7 +27,6 @@ import time
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import preprocess
 from .hip_ops import T
@@ -45,7 +44,6 @@ def _prep(device):
 
 RATIO_FACTOR = {"x1_5": 1.5, "x2": 2.0, "x3": 3.0, "x4": 4.0}          # test.py:27-33
 RATIO_LIST = ["x2", "x1_5"]                                            # test.py:681
-KR, KG, KB = 0.2126, 0.7152, 0.0722                                    # ITU-R BT.709 (functional.py:10-13)
 
 RESULT_KEYS = ["i_frame_num", "p_frame_num",
                "ave_i_frame_bpp", "ave_i_frame_psnr", "ave_i_frame_rgb_psnr", "ave_i_frame_msssim", "ave_i_frame_rgb_msssim",
@@ -143,38 +141,6 @@ class YUV420Reader:
 
     def close(self):
         self.file.close()
-
-
-def yuv420_to_rgb(y, u, v, device):
-    """`ycbcr420_to_rgb(y, uv, order=1)` (functional.py:42-58) on the device: chroma x2 by linear interpolation with
-    scipy.ndimage.zoom's sample positions (output i <-> input i*(n-1)/(2n-1), i.e. align_corners=True), BT.709, clip.
-    Returns (1,3,H,W) fp32 plus the normalised planes the per-plane PSNRs are taken against."""
-    yt = torch.from_numpy(np.ascontiguousarray(y)).to(device).float().div_(255.0)[None, None]
-    uv = torch.from_numpy(np.stack([u, v])).to(device).float().div_(255.0)[None]
-    up = F.interpolate(uv, size=(yt.shape[2], yt.shape[3]), mode="bilinear", align_corners=True)
-    cb, cr = up[:, 0:1], up[:, 1:2]
-    r = yt + (2 - 2 * KR) * (cr - 0.5)
-    b = yt + (2 - 2 * KB) * (cb - 0.5)
-    g = (yt - KR * r - KB * b) / KG
-    return torch.cat([r, g, b], dim=1).clamp_(0.0, 1.0), yt[0, 0], uv[0, 0], uv[0, 1]
-
-
-def rgb_to_yuv420(rgb):
-    """`rgb_to_ycbcr420` (functional.py:16-39) for a (1,3,H,W) device tensor -> (y, u, v) planes in [0,1]."""
-    r, g, b = rgb[0, 0], rgb[0, 1], rgb[0, 2]
-    y = KR * r + KG * g + KB * b
-    cb = 0.5 * (b - y) / (1 - KB) + 0.5
-    cr = 0.5 * (r - y) / (1 - KR) + 0.5
-    h, w = y.shape
-    cb = cb.reshape(h // 2, 2, w // 2, 2).mean(dim=(1, 3))
-    cr = cr.reshape(h // 2, 2, w // 2, 2).mean(dim=(1, 3))
-    return y.clamp(0, 1), cb.clamp(0, 1), cr.clamp(0, 1)
-
-
-def _plane_psnr(a, b):
-    """mse2PSNR (test.py:104-109)."""
-    mse = torch.mean((a - b) ** 2).item()
-    return 10 * np.log10(1.0 / mse) if mse > 1e-10 else 999.9
 
 
 def _crop(x, pad):

@@ -206,3 +206,75 @@ def tie_clusters(diff, key, H, W, h, w, radius=8):
         if not any(abs(y - cy) <= radius and abs(x - cx) <= radius for cy, cx in centres):
             centres.append((y, x))
     return n, int(np.abs(diff).max()), len(centres)
+
+
+# ---- the CPU oracle's closed loops as fixtures (round 5) ---------------------------------------------------------------------------
+# The GPU tests that hold whole GOPs to the oracle used to RUN the oracle on the GPU box's host cores inside `-m gpu` (most of the suite's
+# eleven minutes). The oracle is deterministic CPU code, so its results are generated once, here in the build container, by
+# tests/golden/make_oracle_gops.py and committed as tests/golden/oracle_gops/*.npz: per frame the two bit counts, the two PSNRs and
+# every quantised latent (int16). Inputs are not stored (synth_clip / synth_state_dict are seeded integer generators, imresize_bicubic is
+# checked against the reference). A configuration without a fixture is still computed on the spot.
+ORACLE_GOP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_gops")
+
+
+def oracle_gop_inputs(n, H, W, seed, bl):
+    from lssvc_amd.synth import synth_clip
+    from lssvc_amd.preprocess import imresize_bicubic
+    clip = synth_clip(n, H, W, seed=seed).float() / 255.0
+    return clip, imresize_bicubic(clip, bl).clamp_(0, 1)
+
+
+def oracle_gop_name(n, H, W, seed, gain, scale, bl):
+    return "gop%d_%dx%d_bl%dx%d_s%d_g%s_r%s" % (n, H, W, bl[0], bl[1], seed, ("%g" % gain).replace(".", "p"), ("%g" % scale).replace(".", "p"))
+
+
+def compute_oracle_gop(n, H, W, seed, gain, scale, bl):
+    """The CPU oracle's closed-loop coding of a synthetic clip (1 I + n-1 P): per frame (bit_bl, bit_el, psnr_bl, psnr_el, symbols)."""
+    from lssvc_amd.synth import synth_state_dict
+    from lssvc_amd.preprocess import psnr as psnr_
+    from lssvc_oracle.intra import intra_forward
+    from lssvc_oracle.inter import inter_forward
+    sd_i, sd_p = synth_state_dict("intra_ss", seed, gain), synth_state_dict("lssvc_extend", seed, gain)
+    clip, x_bl = oracle_gop_inputs(n, H, W, seed, bl)
+    rows, do = [], None
+    with torch.no_grad():
+        for t in range(n):
+            xb, xe = x_bl[t:t + 1], clip[t:t + 1]
+            if t == 0:
+                o = intra_forward(sd_i, xb, xe, (H, W), extras=True)
+                do = {"ref_frame_bl": o["x_hat_bl"], "ref_frame_el": o["x_hat_el"], "ref_feature_bl": None,
+                      "ref_feature_el": o["feature_el"]}
+            else:
+                o = inter_forward(sd_p, xb, xe, do, (H, W), scale, extras=True)
+                do = o["dpb"]
+            do["ref_frame_bl"].clamp_(0, 1)
+            do["ref_frame_el"].clamp_(0, 1)
+            syms = {k: v.reshape(-1).to(torch.int16).numpy() for k, v in o["sym"].items()}      # the integers the coder would see
+            rows.append((float(o["bit_bl"]), float(o["bit_el"]), psnr_(xb, do["ref_frame_bl"]), psnr_(xe, do["ref_frame_el"]), syms))
+            del o
+    return clip, x_bl, rows
+
+
+def save_oracle_gop(path, rows):
+    arrays = {"scalars": np.array([r[:4] for r in rows], dtype=np.float64)}
+    for t, r in enumerate(rows):
+        for k, v in r[4].items():
+            arrays["sym_%d_%s" % (t, k)] = v
+    np.savez_compressed(path, **arrays)
+
+
+def load_oracle_gop(n, H, W, seed, gain, scale, bl):
+    """-> (clip, x_bl, rows) from the committed fixture, or None when this configuration has none."""
+    path = os.path.join(ORACLE_GOP_DIR, oracle_gop_name(n, H, W, seed, gain, scale, bl) + ".npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    sc = z["scalars"]
+    assert sc.shape == (n, 4), (path, sc.shape)
+    rows = []
+    for t in range(n):
+        pre = "sym_%d_" % t
+        syms = {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+        rows.append((float(sc[t, 0]), float(sc[t, 1]), float(sc[t, 2]), float(sc[t, 3]), syms))
+    clip, x_bl = oracle_gop_inputs(n, H, W, seed, bl)
+    return clip, x_bl, rows

@@ -4,8 +4,11 @@
     x1_5_1080p_ip   the non-integer ratio at full size: EL 1152x1920 / BL 768x1280, I + first P
     x2_2160p_ipp    BASELINE configs[3]'s shape: EL 2176x3840 / BL 1088x1920, I + first P + steady P
     x2_1080p_gop32  BASELINE configs[1] in full: all 32 frames of the closed loop (test.py:182-250) at 1152x1920 / 576x960; bits,
-                    PSNR, whole-tensor sums and symbols of every frame, strided samples of frames 0, 1, 2, 15, 31 (marked slow:
-                    the host rebuilds 32 bicubic base-layer frames; profiles/r04_golden_full_gpu.txt holds its run)
+                    PSNR, whole-tensor sums and symbols of every frame, strided samples of frames 0, 1, 2, 15, 31 (round 5: in the
+                    default run for the default precision; the exact-fp32 mode behind --runslow). Result: every frame inside the
+                    bars with the plain rule on 31 of 32 frames (f16x3) and by the tie allowance on one -- frame 19, 2.08e-5 bpp,
+                    ONE tie event of 9 symbols (profiles/r05_golden_gop32_gpu.txt).
+                    test_free_running_gop32_against_reference codes the same GOP WITHOUT re-aligning the loop after a tie.
 
 Bars (BASELINE.json north_star): |d bpp| <= 1e-5 and |d PSNR| <= 1e-4 dB per layer per frame, in both conv precisions.
 The fixtures also hold the reference's QUANTISED LATENTS, which makes the comparison exact where a plain replay cannot
@@ -47,9 +50,16 @@ def precision(request):
     hip_ops.set_conv_precision(old)
 
 
-@pytest.mark.parametrize("case", ["x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_ipp", pytest.param("x2_1080p_gop32", marks=pytest.mark.slow)])
-def test_full_size_frames_match_reference(case, precision):
+def _runslow(request):
+    import os
+    return bool(request.config.getoption("--runslow")) or os.environ.get("LSSVC_SLOW") == "1"
+
+
+@pytest.mark.parametrize("case", ["x2_1080p_ipp", "x1_5_1080p_ip", "x2_2160p_ipp", "x2_1080p_gop32"])
+def test_full_size_frames_match_reference(case, precision, request):
     from lssvc_amd import IntraSS, LSSVC_extend
+    if case == "x2_1080p_gop32" and precision == "f32" and not _runslow(request):
+        pytest.skip("the 32-frame GOP runs by default in the default precision (f16x3); the exact-fp32 mode behind --runslow")
     from lssvc_amd.preprocess import psnr
     from lssvc_amd.synth import synth_state_dict
     from helpers import full_case_inputs
@@ -136,3 +146,73 @@ def test_full_size_frames_match_reference(case, precision):
         report.append((t, sum(v[0] for v in flips.values())))
     print("%s %s: (frame, flipped symbols) = %s; %d symbols compared, %d flipped" % (
         case, precision, [r for r in report if r[1]] or "none", n_sym, sum(r[1] for r in report)))
+
+
+def test_free_running_gop32_against_reference(request):
+    """What a rounding tie costs a caller who just codes the GOP: BASELINE configs[1]'s 32 frames through the public API
+    alone, every frame's DPB the previous frame's own output -- no decoder pass on the reference's symbols, no re-alignment -- in
+    the default precision, against the reference's per-frame bits and PSNR (tests/golden/x2_1080p_gop32.npz). Up to the first frame
+    in which a symbol falls on the other side of a tie the plain bars hold (1e-5 bpp, 1e-4 dB). From there on the loop is a
+    slightly different, equally valid closed loop: the flipped symbol changes the reconstruction in its neighbourhood and the
+    difference feeds forward through the DPB, so later frames are RECORDED (gpurun_out/free_running_gop32.json, printed) and held
+    to a drift bar two orders of magnitude above the per-frame bar but far below anything visible in an RD point: 1e-3 bpp and
+    1e-2 dB per frame, and 2e-4 bpp / 2e-3 dB on the GOP average."""
+    import json
+    import os
+    from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
+    from lssvc_amd.preprocess import psnr
+    from lssvc_amd.synth import synth_state_dict
+    from helpers import full_case_inputs
+    case = "x2_1080p_gop32"
+    old = hip_ops.CONV_PRECISION
+    hip_ops.set_conv_precision("f16x3")
+    try:
+        z, m = load_full_case(case)
+        inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", m["seed"], m["gain"])).to(DEV).eval()
+        pnet = LSSVC_extend()
+        pnet.load_dict(synth_state_dict("lssvc_extend", m["seed"], m["gain"]))
+        pnet.to(DEV).eval()
+        inputs, _ = full_case_inputs(case)
+        hr = (m["H"], m["W"])
+        dpb, rows, first_flip = None, [], None
+        for t, (x_bl, x_el) in enumerate(inputs):
+            x_bl, x_el = x_bl.to(DEV), x_el.to(DEV)
+            net = inet if t == 0 else pnet
+            net.set_scale_information(m["scale"], hr, (0, 0, 0, 0))
+            taps = net.taps = {}
+            if t == 0:
+                r = inet.encode_decode(x_bl, x_el, None, None, m["h"], m["w"], m["H"], m["W"])
+                dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+            else:
+                r = pnet.encode_decode(x_bl, x_el, dpb, None, None, m["W"], m["H"], m["w"], m["h"])
+                dpb = r["dpb"]
+            net.taps = None
+            dpb["ref_frame_bl"].clamp_(0, 1)                            # test.py:249-250
+            dpb["ref_frame_el"].clamp_(0, 1)
+            differing = 0
+            for key in [k[len("f%d_sym_" % t):] for k in z.files if k.startswith("f%d_sym_" % t)]:
+                differing += int(np.count_nonzero(taps[key].reshape(-1).numpy().astype(np.int32) - z["f%d_sym_%s" % (t, key)].astype(np.int32)))
+            if differing and first_flip is None:
+                first_flip = t
+            bits, want_psnr = z["f%d_bits" % t], z["f%d_psnr" % t]
+            row = {"frame": t, "d_bpp_bl": (r["bit_bl"] - float(bits[0])) / (m["h"] * m["w"]), "d_bpp_el": (r["bit_el"] - float(bits[1])) / (m["H"] * m["W"]),
+                   "d_psnr_bl": psnr(x_bl, dpb["ref_frame_bl"]) - float(want_psnr[0]), "d_psnr_el": psnr(x_el, dpb["ref_frame_el"]) - float(want_psnr[1]),
+                   "symbols_differing_from_reference": differing}
+            rows.append(row)
+            print("free-running frame %2d: d bpp (%+.2e, %+.2e)  d PSNR (%+.1e, %+.1e) dB  symbols differing %d" % (
+                t, row["d_bpp_bl"], row["d_bpp_el"], row["d_psnr_bl"], row["d_psnr_el"], differing), flush=True)
+            aligned = first_flip is None
+            bpp_bar, db_bar = (1e-5, 1e-4) if aligned else (1e-3, 1e-2)
+            assert abs(row["d_bpp_bl"]) <= bpp_bar and abs(row["d_bpp_el"]) <= bpp_bar, (row, first_flip)
+            assert abs(row["d_psnr_bl"]) <= db_bar and abs(row["d_psnr_el"]) <= db_bar, (row, first_flip)
+        n = len(rows)
+        avg = {k: sum(r_[k] for r_ in rows) / n for k in ("d_bpp_bl", "d_bpp_el", "d_psnr_bl", "d_psnr_el")}
+        worst = {k: max(abs(r_[k]) for r_ in rows) for k in avg}
+        print("free-running GOP: first frame with a symbol off the reference's: %s; GOP average %s; worst frame %s" % (first_flip, avg, worst))
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "free_running_gop32.json"), "w") as f:
+            json.dump({"case": case, "precision": "f16x3", "first_frame_with_a_differing_symbol": first_flip, "gop_average": avg, "worst_frame_abs": worst, "frames": rows}, f, indent=1)
+        assert abs(avg["d_bpp_bl"]) <= 2e-4 and abs(avg["d_bpp_el"]) <= 2e-4 and abs(avg["d_psnr_bl"]) <= 2e-3 and abs(avg["d_psnr_el"]) <= 2e-3, avg
+    finally:
+        hip_ops.set_conv_precision(old)

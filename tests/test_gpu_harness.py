@@ -18,13 +18,14 @@ SEED, GAIN = 4, 0.6
 @pytest.fixture(scope="module")
 def workdir(tmp_path_factory):
     from lssvc_amd import harness as H
+    import colour_torch_ref as CT
     from lssvc_amd.synth import synth_clip, synth_state_dict
     d = tmp_path_factory.mktemp("harness")
     os.makedirs(d / "data" / "seq0")
     clip = synth_clip(FRAMES, H_EL, W_EL, seed=SEED).float() / 255.0           # (T,3,H,W)
     with open(d / "data" / "seq0" / "x1.yuv", "wb") as f:
         for t in range(FRAMES):
-            y, u, v = H.rgb_to_yuv420(clip[t:t + 1])
+            y, u, v = CT.rgb_to_yuv420(clip[t:t + 1])
             for p in (y, u, v):
                 f.write(p.mul(255).round().clamp(0, 255).byte().numpy().tobytes())
     torch.save({"state_dict": synth_state_dict("intra_ss", SEED, GAIN)}, d / "i.pth")        # wrapped, as published ckpts may be
@@ -46,6 +47,7 @@ def _run(workdir, out, extra=()):
 
 def test_harness_end_to_end_matches_direct_calls(workdir):
     from lssvc_amd import harness as H, preprocess, IntraSS, LSSVC_extend
+    import colour_torch_ref as CT
     from lssvc_amd.synth import synth_state_dict
     res = _run(workdir, "out")
     el = res["EL"]["SYN"]["seq0"]["p.pth"]
@@ -71,7 +73,7 @@ def test_harness_end_to_end_matches_direct_calls(workdir):
         f_el, _ = prep.frame_from_yuv420(y8, u8, v8, pad["HR_padded_size"])            # the product's pre-processing kernels
         f_bl = prep.bicubic(f_el, pad["LR_padded_size"])
         x_bl, x_el = f_bl.to_nchw(), f_el.to_nchw()
-        rgb, _, _, _ = H.yuv420_to_rgb(*planes, DEV)                                 # torch restatement, for the PSNR cross-check
+        rgb, _, _, _ = CT.yuv420_to_rgb(*planes, DEV)                                 # torch restatement, for the PSNR cross-check
         xb_t, xe_t, _ = preprocess.make_layers(rgb, 2.0)
         assert (x_el - xe_t).abs().max().item() <= 1e-6 and (x_bl - xb_t).abs().max().item() <= 2e-6
         inet.set_scale_information(2.0, pad["HR_padded_size"], (0, 0, 0, 0))

@@ -44,10 +44,10 @@ def test_bicubic_matches_reference_fixture(prep):
 
 @pytest.mark.parametrize("H,W,Hp,Wp", [(128, 192, 128, 192), (1080, 1920, 1152, 1920), (66, 34, 128, 64)])
 def test_yuv420_to_frame(prep, H, W, Hp, Wp):
-    from lssvc_amd import harness as Hn
+    import colour_torch_ref as CT
     g = np.random.default_rng(H)
     y, u, v = (g.integers(0, 256, s, dtype=np.uint8) for s in ((H, W), (H // 2, W // 2), (H // 2, W // 2)))
-    want, wy, wu, wv = Hn.yuv420_to_rgb(y, u, v, "cpu")      # the torch restatement on the CPU, like the reference (x / 255 is a
+    want, wy, wu, wv = CT.yuv420_to_rgb(y, u, v, "cpu")      # the torch restatement on the CPU, like the reference (x / 255 is a
     #                                                          true division there; torch's CUDA kernel multiplies by 1/255)
     f, (py, pu, pv) = prep.frame_from_yuv420(*(torch.from_numpy(a).to(DEV) for a in (y, u, v)), (Hp, Wp))
     got = f.to_nchw().cpu()
@@ -58,7 +58,7 @@ def test_yuv420_to_frame(prep, H, W, Hp, Wp):
 
 
 def test_rgb_to_yuv420_and_sqdiff(prep):
-    from lssvc_amd import harness as Hn
+    import colour_torch_ref as CT
     from lssvc_amd.hip_ops import T
     g = torch.Generator().manual_seed(3)
     a = torch.rand(1, 3, 72, 96, generator=g) * 1.4 - 0.2                          # includes values outside [0,1]
@@ -66,7 +66,7 @@ def test_rgb_to_yuv420_and_sqdiff(prep):
     ta, tb = T.from_nchw(a.to(DEV)), T.from_nchw(b.to(DEV))
     for clamp in (False, True):
         src = a.clamp(0, 1) if clamp else a
-        wy, wu, wv = Hn.rgb_to_yuv420(src[:, :, :64, :80])
+        wy, wu, wv = CT.rgb_to_yuv420(src[:, :, :64, :80])
         y, u, v = prep.rgb_to_yuv420(ta, 64, 80, clamp01=clamp)
         for got, want in ((y, wy), (u, wu), (v, wv)):
             assert (got.cpu() - want).abs().max().item() <= 1e-6

@@ -9,6 +9,7 @@ import scipy.ndimage
 import torch
 
 from lssvc_amd import harness as H
+import colour_torch_ref as CT
 
 
 def _write_yuv(path, frames, h, w, seed=0):
@@ -42,24 +43,24 @@ def test_yuv_reader_frames_and_seek(tmp_path):
 
 def test_colour_conversion_matches_reference_formulas(tmp_path):
     (y, u, v), = _write_yuv(str(tmp_path / "a.yuv"), 1, 16, 24, seed=3)
-    rgb, yt, ut, vt = H.yuv420_to_rgb(y, u, v, "cpu")
+    rgb, yt, ut, vt = CT.yuv420_to_rgb(y, u, v, "cpu")
     # functional.py:42-58 in numpy/scipy
     yf = y[None].astype(np.float32) / 255
     uv = np.stack([u, v]).astype(np.float32) / 255
     up = scipy.ndimage.zoom(uv, (1, 2, 2), order=1)
     cb, cr = up[0:1], up[1:2]
-    r = yf + (2 - 2 * H.KR) * (cr - 0.5)
-    b = yf + (2 - 2 * H.KB) * (cb - 0.5)
-    g = (yf - H.KR * r - H.KB * b) / H.KG
+    r = yf + (2 - 2 * CT.KR) * (cr - 0.5)
+    b = yf + (2 - 2 * CT.KB) * (cb - 0.5)
+    g = (yf - CT.KR * r - CT.KB * b) / CT.KG
     want = np.clip(np.concatenate([r, g, b], 0), 0, 1)
     assert np.abs(rgb[0].numpy() - want).max() <= 2e-6
     assert np.array_equal(yt.numpy(), yf[0]) and np.array_equal(ut.numpy(), uv[0])
     # functional.py:16-39
-    yy, cbb, crr = H.rgb_to_yuv420(torch.from_numpy(want[None]))
+    yy, cbb, crr = CT.rgb_to_yuv420(torch.from_numpy(want[None]))
     rr, gg, bb = want
-    y2 = H.KR * rr + H.KG * gg + H.KB * bb
-    cb2 = (0.5 * (bb - y2) / (1 - H.KB) + 0.5).reshape(8, 2, 12, 2).mean(axis=(1, 3))
-    cr2 = (0.5 * (rr - y2) / (1 - H.KR) + 0.5).reshape(8, 2, 12, 2).mean(axis=(1, 3))
+    y2 = CT.KR * rr + CT.KG * gg + CT.KB * bb
+    cb2 = (0.5 * (bb - y2) / (1 - CT.KB) + 0.5).reshape(8, 2, 12, 2).mean(axis=(1, 3))
+    cr2 = (0.5 * (rr - y2) / (1 - CT.KR) + 0.5).reshape(8, 2, 12, 2).mean(axis=(1, 3))
     assert np.abs(yy.numpy() - np.clip(y2, 0, 1)).max() <= 1e-6
     assert np.abs(cbb.numpy() - np.clip(cb2, 0, 1)).max() <= 1e-6 and np.abs(crr.numpy() - np.clip(cr2, 0, 1)).max() <= 1e-6
 
@@ -167,9 +168,9 @@ def test_colour_conversion_matches_reference_outputs(golden_dir):
     """The same two conversions against what the REFERENCE's own functions returned for frame 0 of the harness clip
     (tests/golden/make_harness_golden.py ran src/utils/functional.py:16-58 from /root/reference and stored the arrays)."""
     z = np.load(os.path.join(golden_dir, "harness_x2_clip.npz"))
-    rgb, _, _, _ = H.yuv420_to_rgb(z["y"][0], z["u"][0], z["v"][0], "cpu")
+    rgb, _, _, _ = CT.yuv420_to_rgb(z["y"][0], z["u"][0], z["v"][0], "cpu")
     assert np.abs(rgb[0].numpy() - z["rgb0"]).max() <= 2e-6
-    yy, cb, cr = H.rgb_to_yuv420(torch.from_numpy(z["rgb0"][None]))
+    yy, cb, cr = CT.rgb_to_yuv420(torch.from_numpy(z["rgb0"][None]))
     assert np.abs(yy.numpy() - z["y_back"][0]).max() <= 1e-6
     assert np.abs(cb.numpy() - z["uv_back"][0]).max() <= 1e-6 and np.abs(cr.numpy() - z["uv_back"][1]).max() <= 1e-6
 

@@ -5,6 +5,8 @@ conversion, padding, bicubic base layer, both codecs, PSNRs and the JSON result 
 import json, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import colour_torch_ref as CT  # noqa: E402
 from lssvc_amd import harness as H
 from lssvc_amd.synth import synth_clip, synth_state_dict
 
@@ -17,7 +19,7 @@ def main():
     clip = synth_clip(frames, h, w, seed=0).float() / 255.0
     with open(os.path.join(d, "data", "seq0", "x1.yuv"), "wb") as f:
         for t in range(frames):
-            for p in H.rgb_to_yuv420(clip[t:t + 1]):
+            for p in CT.rgb_to_yuv420(clip[t:t + 1]):
                 f.write(p.mul(255).round().clamp(0, 255).byte().numpy().tobytes())
     del clip
     torch.save(synth_state_dict("intra_ss", 0, 0.55), os.path.join(d, "i.pth"))

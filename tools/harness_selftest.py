@@ -4,6 +4,8 @@ workers) and then `--worker 1` (in-process) and compares the result files."""
 import json, os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import colour_torch_ref as CT  # noqa: E402
 from lssvc_amd import harness as H
 from lssvc_amd.synth import synth_clip, synth_state_dict
 
@@ -14,7 +16,7 @@ def main():
     clip = synth_clip(frames, hw, hw, seed=9).float() / 255.0
     with open(os.path.join(d, "data", "seq0", "x1.yuv"), "wb") as f:
         for t in range(frames):
-            for p in H.rgb_to_yuv420(clip[t:t + 1]):
+            for p in CT.rgb_to_yuv420(clip[t:t + 1]):
                 f.write(p.mul(255).round().clamp(0, 255).byte().numpy().tobytes())
     torch.save(synth_state_dict("intra_ss", 9, 0.6), os.path.join(d, "i.pth"))
     torch.save(synth_state_dict("lssvc_extend", 9, 0.6), os.path.join(d, "p.pth"))
