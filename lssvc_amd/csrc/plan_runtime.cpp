@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <string>
@@ -301,7 +302,7 @@ int load_plan(const char *path, Plan &p, Checkpoint *ck) {
                     x.field = r.get<uint32_t>();
                     x.region = r.get<uint32_t>();
                     x.index = r.get<uint32_t>();
-                    LSSVC_CHECK(r.ok && x.index < 4 && x.field + 4 <= len && x.region < n_regions, "engine: corrupt plan (scalar fix)");
+                    LSSVC_CHECK(r.ok && x.index < 4 && (uint64_t)x.field + 4 <= (uint64_t)len && x.region < n_regions, "engine: corrupt plan (scalar fix)");
                 }
                 break;
             }
@@ -426,7 +427,7 @@ int bind(Plan &p) {
                 a.ptr = static_cast<char *>(p.regions[a.region].ptr) + a.offset;
             } else if (a.tag == TAG_STRUCT) {
                 for (auto &x : a.fixes) {
-                    LSSVC_CHECK(x.region < p.regions.size() && p.regions[x.region].ptr && x.field + 8 <= a.blob.size(),
+                    LSSVC_CHECK(x.region < p.regions.size() && p.regions[x.region].ptr && (uint64_t)x.field + 8 <= (uint64_t)a.blob.size(),
                                 "engine: unbound region %u", x.region);
                     void *q = static_cast<char *>(p.regions[x.region].ptr) + x.offset;
                     memcpy(a.blob.data() + x.field, &q, 8);
@@ -747,11 +748,48 @@ extern "C" void *lssvc_engine_create(int32_t device) {
 
 extern "C" void lssvc_engine_destroy(void *h) { delete static_cast<Engine *>(h); }
 
+// CRC-32 (zlib's polynomial) over the tensors the CDF tables are a function of: plan_compiler.py entropy_params_crc
+static uint32_t crc32_update(uint32_t crc, const unsigned char *p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
+static int64_t entropy_params_crc(const Checkpoint &ck) {
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < ck.names.size(); ++i)
+        if (ck.names[i].find("bit_estimator") != std::string::npos || ck.names[i].find("entropy_bottleneck") != std::string::npos) idx.push_back(i);
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ck.names[a] < ck.names[b]; });
+    uint32_t crc = 0;
+    for (size_t i : idx) {
+        crc = crc32_update(crc, reinterpret_cast<const unsigned char *>(ck.names[i].data()), ck.names[i].size());
+        crc = crc32_update(crc, reinterpret_cast<const unsigned char *>(ck.data[i].data()), ck.data[i].size() * sizeof(float));
+    }
+    return (int64_t)crc;
+}
+
 static int load_into(Engine *eng, std::unique_ptr<Plan> &slot, const char *path, const char *want_a, const char *want_b) {
     std::unique_ptr<Plan> p(new Plan());
     const bool intra_model = want_a[0] == 'i';                  // "iframe*" plans run IntraSS, "pframe*" plans LSSVC
+    const Checkpoint *ck = eng->ckpt[intra_model ? 0 : 1].get();
     if (int e = load_plan(path, *p, eng->ckpt[intra_model ? 0 : 1].get())) return e;
     LSSVC_CHECK(p->kind == want_a || (want_b && p->kind == want_b), "engine: %s holds a '%s' plan", path, p->kind.c_str());
+    // a write_stream plan holds the CDF tables update() built from the checkpoint it was compiled with (and the bottleneck medians);
+    // bound to another checkpoint its strings would be coded against the wrong tables and decode nowhere else
+    if (const int64_t want = p->meta_value("entropy_params_crc", -1); want >= 0 && ck) {
+        const int64_t have = entropy_params_crc(*ck);
+        LSSVC_CHECK(have == want, "engine: %s was compiled with another checkpoint's entropy parameters (CRC %08llx, this checkpoint %08llx): its CDF tables "
+                    "do not belong to these weights -- compile the stream plans from this checkpoint", path, (unsigned long long)want, (unsigned long long)have);
+    }
     slot = std::move(p);
     return 0;
 }

@@ -44,10 +44,29 @@ bool get(const lssvc_tensor *t, int n, const std::string &name, Src &s, bool req
         if (required) fail("prepare_weights: the checkpoint has no tensor '%s'", name.c_str());
         return false;
     }
+    if (x->ndim < 0 || x->ndim > 4) {
+        fail("prepare_weights: tensor '%s' has %d dimensions", name.c_str(), (int)x->ndim);
+        return false;
+    }
     s.p = x->data;
     s.nd = x->ndim;
-    for (int i = 0; i < 4; ++i) s.d[i] = i < x->ndim ? x->shape[i] : 1;
+    int64_t total = 1;
+    for (int i = 0; i < 4; ++i) {
+        s.d[i] = i < x->ndim ? x->shape[i] : 1;
+        if (s.d[i] < 1 || s.d[i] > (int64_t(1) << 28) || (total *= s.d[i]) > (int64_t(1) << 32)) {      // (a checkpoint tensor of > 2^32 elements is not one of this model's)
+            fail("prepare_weights: tensor '%s' has a bad shape", name.c_str());
+            return false;
+        }
+    }
     return true;
+}
+
+// every tensor a prepared layout reads is checked against the element count the layout assumes BEFORE anything is written: a
+// checkpoint with other shapes (another architecture, a truncated dump) is an error message, not an out-of-bounds access
+bool want_numel(const Src &s, int64_t n, const char *layer, const char *what) {
+    if (s.numel() == n) return true;
+    fail("prepare_weights(%s): %s has %lld elements, expected %lld", layer, what, (long long)s.numel(), (long long)n);
+    return false;
 }
 
 inline int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
@@ -167,8 +186,12 @@ int conv_f16(const Oihw &o, const int32_t *splits, int n_splits, Out &out, float
 
 int sum_splits(const lssvc_prep_spec *s, int64_t cin) {
     int64_t t = 0;
-    for (int i = 0; i < s->n_splits; ++i) t += s->splits[i];
-    if (s->n_splits < 1 || s->n_splits > 3 || t != cin) return fail("prepare_weights(%s): input segments do not add up to %lld channels", s->name, (long long)cin);
+    if (s->n_splits < 1 || s->n_splits > 3) return fail("prepare_weights(%s): %d input segments", s->name, (int)s->n_splits);
+    for (int i = 0; i < s->n_splits; ++i) {
+        if (s->splits[i] < 1) return fail("prepare_weights(%s): input segment %d has %d channels", s->name, i, (int)s->splits[i]);
+        t += s->splits[i];
+    }
+    if (t != cin) return fail("prepare_weights(%s): input segments do not add up to %lld channels", s->name, (long long)cin);
     return 0;
 }
 
@@ -178,6 +201,8 @@ int conv_transpose(const lssvc_tensor *t, int n, const lssvc_prep_spec *s, Out &
     if (!get(t, n, std::string(s->name) + ".weight", w) || !get(t, n, std::string(s->name) + ".bias", b)) return 1;
     const int64_t cin = w.d[0], cout = w.d[1];
     if (w.nd != 4 || w.d[2] != 3 || w.d[3] != 3) return fail("prepare_weights(%s): ConvTranspose2d weight must be (Cin, Cout, 3, 3)", s->name);
+    if (!want_numel(b, cout, s->name, "bias")) return 1;
+    if (s->flag != 1 && s->flag != 2) return fail("prepare_weights(%s): ConvTranspose2d stride %d", s->name, (int)s->flag);
     const int32_t one_split[1] = {(int32_t)cin};
     if (s->flag == 1) {             // stride 1: flipped 3x3, (Cout, Cin)
         Oihw o{std::vector<float>((size_t)(cout * cin * 9)), cout, cin, 3, 3};
@@ -224,6 +249,9 @@ int gdn(const lssvc_tensor *t, int n, const lssvc_prep_spec *s, Out &out, float 
         if (!get(t, n, nm + ".beta_reparam.lower_bound.bound", bb) || !get(t, n, nm + ".beta_reparam.pedestal", bp) ||
             !get(t, n, nm + ".gamma_reparam.lower_bound.bound", gb) || !get(t, n, nm + ".gamma_reparam.pedestal", gp))
             return 1;
+        if (!want_numel(bb, 1, s->name, "beta_reparam.lower_bound.bound") || !want_numel(bp, 1, s->name, "beta_reparam.pedestal") ||
+            !want_numel(gb, 1, s->name, "gamma_reparam.lower_bound.bound") || !want_numel(gp, 1, s->name, "gamma_reparam.pedestal"))
+            return 1;
         for (int64_t i = 0; i < c; ++i) {
             const float m = std::fmax(beta.p[i], bb.p[0]);
             be[(size_t)i] = m * m - bp.p[0];
@@ -265,11 +293,15 @@ int ffn(const lssvc_tensor *t, int n, const lssvc_prep_spec *s, Out &out, float 
         !get(t, n, nm + ".conv.2.bias", b2))
         return 1;
     const int64_t hidden = w1.d[0], c = w1.d[1];
+    if (w1.nd != 4 || w2.nd != 4 || w1.d[2] != 1 || w1.d[3] != 1 || w2.d[2] != 1 || w2.d[3] != 1) return fail("prepare_weights(%s): ConvFFN weights must be (Cout, Cin, 1, 1)", s->name);
+    if (!want_numel(b1, hidden, s->name, "conv.0.bias") || !want_numel(b2, c, s->name, "conv.2.bias")) return 1;
     if (c % 16 || hidden % 32 || w2.d[0] != c || w2.d[1] != hidden) return fail("prepare_weights(%s): ConvFFN shapes (%lld, %lld)", s->name, (long long)hidden, (long long)c);
     const int64_t cf = c / 16, tt = hidden / 32, ss = (cf + 1) / 2;
     const bool pre = s->name2[0] != 0;
     Src wp, bp;
     if (pre && (!get(t, n, std::string(s->name2) + ".weight", wp) || !get(t, n, std::string(s->name2) + ".bias", bp))) return 1;
+    if (pre && (wp.nd != 4 || wp.d[2] != 1 || wp.d[3] != 1 || wp.d[0] != c || !want_numel(bp, wp.d[0], s->name2, "bias")))
+        return fail("prepare_weights(%s): the leading conv must be a 1x1 conv with %lld output channels and a bias", s->name2, (long long)c);
     const int64_t n1 = tt * 2 * ss * 16 * 32, n2 = tt * cf * 16 * 32;
     _Float16 *o1 = (_Float16 *)out.take(2 * n1 * 2);
     _Float16 *o2 = (_Float16 *)out.take(2 * n2 * 2);
@@ -342,6 +374,8 @@ int bit_estimator(const lssvc_tensor *t, int n, const lssvc_prep_spec *s, Out &o
         if (i < 3 && !get(t, n, f + ".a", a[i])) return 1;
     }
     const int64_t c = h[0].numel();
+    for (int i = 0; i < 4; ++i)
+        if (!want_numel(h[i], c, s->name, "f*.h") || !want_numel(b[i], c, s->name, "f*.b") || (i < 3 && !want_numel(a[i], c, s->name, "f*.a"))) return 1;
     float *o = (float *)out.take(11 * c * 4);
     dims[0] = (int32_t)c;
     if (!o) return 0;
@@ -369,6 +403,16 @@ int entropy_bottleneck(const lssvc_tensor *t, int n, const lssvc_prep_spec *s, O
         if (!get(t, n, nm + "._factors." + std::to_string(i), f[i])) return 1;
     if (!get(t, n, nm + ".quantiles", q)) return 1;
     const int64_t c = m[0].d[0];
+    {   // filters (1, 3, 3, 3, 3, 1) (img_entropy_models.py:400-431): matrices (C, f[i+1], f[i]), biases (C, f[i+1], 1), factors (C, f[i+1], 1), quantiles (C, 1, 3);
+        // checked before the 59-row blob is taken, so that a checkpoint with other filter sizes cannot overflow it
+        static const int64_t fl[6] = {1, 3, 3, 3, 3, 1};
+        for (int i = 0; i < 5; ++i) {
+            if (m[i].nd != 3 || m[i].d[0] != c || m[i].d[1] != fl[i + 1] || m[i].d[2] != fl[i]) return fail("prepare_weights(%s): _matrices.%d must be (C, %lld, %lld)", s->name, i, (long long)fl[i + 1], (long long)fl[i]);
+            if (b[i].nd != 3 || b[i].d[0] != c || b[i].d[1] != fl[i + 1] || b[i].d[2] != 1) return fail("prepare_weights(%s): _biases.%d must be (C, %lld, 1)", s->name, i, (long long)fl[i + 1]);
+            if (i < 4 && (f[i].nd != 3 || f[i].d[0] != c || f[i].d[1] != fl[i + 1] || f[i].d[2] != 1)) return fail("prepare_weights(%s): _factors.%d must be (C, %lld, 1)", s->name, i, (long long)fl[i + 1]);
+        }
+        if (q.nd != 3 || q.d[0] != c || q.d[1] != 1 || q.d[2] != 3) return fail("prepare_weights(%s): quantiles must be (C, 1, 3)", s->name);
+    }
     float *o = (float *)out.take(59 * c * 4);
     dims[0] = (int32_t)c;
     if (!o) return 0;
@@ -393,7 +437,8 @@ int entropy_bottleneck(const lssvc_tensor *t, int n, const lssvc_prep_spec *s, O
 
 extern "C" int lssvc_prepare_weights(const lssvc_tensor *ckpt, int32_t n_tensors, const lssvc_prep_spec *spec, int32_t *n_blobs,
                                      int64_t blob_bytes[LSSVC_PREP_MAX_BLOBS], float scalars[4], int32_t dims[8], void *const *blobs) {
-    LSSVC_CHECK(ckpt && spec && n_blobs && blob_bytes && scalars && dims, "prepare_weights: bad arguments");
+    LSSVC_CHECK(ckpt && spec && n_blobs && blob_bytes && scalars && dims && n_tensors >= 0, "prepare_weights: bad arguments");
+    LSSVC_CHECK(memchr(spec->name, 0, sizeof(spec->name)) && memchr(spec->name2, 0, sizeof(spec->name2)), "prepare_weights: unterminated layer name");
     for (int i = 0; i < 4; ++i) scalars[i] = 1.0f;
     for (int i = 0; i < 8; ++i) dims[i] = 0;
     Out out{const_cast<void **>(blobs), blob_bytes, 0};
@@ -411,6 +456,7 @@ extern "C" int lssvc_prepare_weights(const lssvc_tensor *ckpt, int32_t n_tensors
         const Oihw o = shuffle_rows(w.p, w.d[0], w.d[1], w.d[2], w.d[3], ps);
         if (spec->kind == LSSVC_PREP_CONV) {
             const bool has_b = get(ckpt, n_tensors, nm + ".bias", b, false);
+            if (has_b && !want_numel(b, w.d[0], spec->name, "bias")) return 1;
             rc = conv_f32(o, has_b ? b.p : nullptr, spec->splits, spec->n_splits, ps, out, dims);
         } else {
             rc = conv_f16(o, spec->splits, spec->n_splits, out, &scalars[0]);
@@ -422,7 +468,8 @@ extern "C" int lssvc_prepare_weights(const lssvc_tensor *ckpt, int32_t n_tensors
         Src w, b;
         if (!get(ckpt, n_tensors, nm + ".weight", w) || !get(ckpt, n_tensors, nm + ".bias", b)) return 1;
         const int64_t c = w.d[0];
-        if (w.numel() != c * 9) return fail("prepare_weights(%s): depthwise weight must be (C, 1, 3, 3)", spec->name);
+        if (w.nd != 4 || w.d[1] != 1 || w.d[2] != 3 || w.d[3] != 3) return fail("prepare_weights(%s): depthwise weight must be (C, 1, 3, 3)", spec->name);
+        if (!want_numel(b, c, spec->name, "bias")) return 1;
         float *o = (float *)out.take(9 * c * 4);
         float *ob = (float *)out.take(c * 4);
         dims[0] = (int32_t)c;

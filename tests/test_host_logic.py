@@ -291,6 +291,47 @@ def test_weight_prep_tables_and_whole_checkpoints():
         W.conv_f16x3(next(k[:-7] for k, v in sd.items() if k.endswith(".weight") and v.dim() == 4), [1, 2])
 
 
+def test_weight_prep_rejects_checkpoints_of_other_shapes():
+    """lssvc_prepare_weights is fed raw checkpoint dumps by the engine (lssvc_engine_load_checkpoint), so a checkpoint
+    whose tensors have other shapes than the architecture's -- other EntropyBottleneck filter sizes, short biases, a depthwise
+    weight that is not (C,1,3,3), a ConvFFN whose bias does not match, a non-positive input segment -- must be an error message
+    BEFORE anything is written, never an out-of-bounds read or a heap overflow."""
+    from lssvc_amd import _lib
+    from lssvc_amd.synth import synth_state_dict
+    si = synth_state_dict("intra_ss", 3, 0.6)
+    bad = dict(si)
+    bad["entropy_bottleneck._matrices.1"] = torch.zeros(64, 5, 3)                    # filters (3, 5, ...) would need 67 rows
+    with pytest.raises(_lib.LssvcHipError, match="_matrices.1 must be"):
+        _store(bad).entropy_bottleneck("entropy_bottleneck")
+    bad = dict(si)
+    bad["entropy_bottleneck.quantiles"] = torch.zeros(64, 1, 2)
+    with pytest.raises(_lib.LssvcHipError, match="quantiles must be"):
+        _store(bad).entropy_bottleneck("entropy_bottleneck")
+    sd = synth_state_dict("lssvc_extend", 3, 0.6)
+    bad = dict(sd)
+    bad["bit_estimator_z.f2.a"] = torch.zeros(1, 7, 1, 1)
+    with pytest.raises(_lib.LssvcHipError, match="elements, expected"):
+        _store(bad).bit_estimator("bit_estimator_z")
+    g = torch.Generator().manual_seed(1)
+    rn = lambda *sh: torch.randn(*sh, generator=g)
+    with pytest.raises(_lib.LssvcHipError, match="bias has 5 elements"):
+        _store({"a.weight": rn(16, 8, 3, 3), "a.bias": rn(5)}).conv("a", [8])
+    with pytest.raises(_lib.LssvcHipError, match="depthwise weight must be"):
+        _store({"d.weight": rn(24, 3, 3), "d.bias": rn(24)}).dwconv("d")
+    with pytest.raises(_lib.LssvcHipError, match="bias has"):
+        _store({"d.weight": rn(24, 1, 3, 3), "d.bias": rn(8)}).dwconv("d")
+    with pytest.raises(_lib.LssvcHipError, match="bias has"):
+        _store({"t.weight": rn(10, 6, 3, 3), "t.bias": rn(10)}).conv_t("t", 2)
+    ffn = {"f.conv.0.weight": rn(64, 32, 1, 1), "f.conv.0.bias": rn(8), "f.conv.2.weight": rn(32, 64, 1, 1), "f.conv.2.bias": rn(32)}
+    with pytest.raises(_lib.LssvcHipError, match="conv.0.bias has 8 elements"):
+        _store(ffn).ffn_f16x3("f")
+    with pytest.raises(_lib.LssvcHipError, match="input segment 1 has -8 channels"):
+        _store({"a.weight": rn(16, 8, 3, 3)}).conv("a", [16, -8])
+    with pytest.raises(_lib.LssvcHipError, match="GDN wants|elements, expected"):
+        _store({"g.beta": rn(16), "g.gamma": rn(16, 16), "g.beta_reparam.lower_bound.bound": rn(2), "g.beta_reparam.pedestal": rn(1),
+                "g.gamma_reparam.lower_bound.bound": rn(1), "g.gamma_reparam.pedestal": rn(1)}).gdn("g", "intra")
+
+
 def test_framing_matches_reference_fixture(tmp_path):
     """tests/golden/framing.json was written by the reference's own stream_helper.py (make_framing_golden.py imports it
     from /root/reference): our framing must produce the same file bytes from the same strings, parse the reference's
