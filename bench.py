@@ -719,7 +719,8 @@ def main():
                         "(6.2 MB), u8 -> fp32, zero padding to 1152x1920, MATLAB-bicubic BL 576x960 (HIP kernels, csrc/prepost.hip), "
                         "encode, D2H of the bit counts (BASELINE.md section 3 'GPU side')",
                 "bits_equal_resident_run": bool(bits_incl == bits)}
-        out["hbm_reserved_gib"] = round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 1)      # frame plans' graph pools + inputs (of 288 GB)
+        out["hbm_reserved_gib"] = round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 1)      # PEAK over the run, priming included (of 288 GB)
+        out["hbm_reserved_steady_gib"] = round(torch.cuda.memory_reserved(device) / 2 ** 30, 1)  # now: the frame plans' graph pools + inputs
         out["lookahead"] = {"on": bool(LOOKAHEAD and hip_ops.MULTI_STREAM), "bits_equal_frame_after_frame_run": lookahead_check,
                             "what": "the frame loop hands frame t+1's base-layer input to the call of frame t (LSSVC_extend.forward_one_frame, "
                                     "frame_id / next_x_bl): BL(t+1) is coded on a second stream beside EL(t); same launches, bit-identical results"}

@@ -32,6 +32,9 @@ def _channel_indexes(c, h, w):
 _CDF_BUFFERS = ("._offset", "._quantized_cdf", "._cdf_length")
 
 
+SHARED_GRAPH_POOL = _os.environ.get("LSSVC_SHARED_GRAPH_POOL", "1") == "1"
+
+
 class FramePlan:
     """The static launch plan of one frame type at one size: the estimate-mode forward issues a
     FIXED sequence of ~250 (I) / ~400 (P) kernel launches whose shapes depend only on the frame size, so after one
@@ -82,6 +85,7 @@ class _HostModel:
         self.graph_mode = _os.environ.get("LSSVC_GRAPH", "0") == "1"
         self.alias_outputs = _os.environ.get("LSSVC_GRAPH_ALIAS", "0") == "1"
         self._plans = {}
+        self._graph_pools = {}    # lane (0: plans on the caller's stream, 1: the look-ahead base-layer plans) -> graph memory pool handle
         self.last_issue_s = 0.0
         self.range_audit = ops.RANGE_AUDIT_DEFAULT     # audit the first frame of every type for fp16 range (hip_ops.RangeAudit)
         self._audited = set()
@@ -121,20 +125,44 @@ class _HostModel:
             while len(self._plans) >= self.MAX_PLANS:
                 self._plans.pop(next(iter(self._plans)))             # dicts keep insertion order: the first key is the LRU
         self._plans[key] = plan                                      # (re-)insert as most recently used
+        lane = 1 if frame_type[0] == "p-ahead-bl" else 0
         if plan.calls == 0:
             plan.calls = 1
             ins = {k: (None if v is None else T.from_nchw(v)) for k, v in tensors.items()}
-            return self._with_range_audit(frame_type, lambda: body(ins))
+            # The eager first call of a frame type (weights laid out, LDS granted, fp16 range audit) runs its chains in program order
+            # on one stream -- same launches, same results as with side streams (tests/test_gpu_graph.py) -- because that way a freed
+            # buffer is recycled at once instead of at its branch's join: 14 instead of 26 GB of working set for a 1080p P-frame. The
+            # plan that follows gets its memory from a graph pool, so the allocator's cache is handed back right away rather than at
+            # the next capture. Together: peak reserved HBM of the 1080p bench's priming 51 -> 3x GiB.
+            streams, ops.MULTI_STREAM = ops.MULTI_STREAM, False
+            try:
+                r = self._with_range_audit(frame_type, lambda: body(ins))
+            finally:
+                ops.MULTI_STREAM = streams
+            torch.cuda.synchronize(self.device)
+            torch.cuda.empty_cache()
+            return r
         plan.load(tensors)
         if plan.graph is None:
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # One graph memory pool per model and LANE instead of one per plan (round 5; 98 GiB -> about a third reserved for the 1080p
+            # bench): the frame plans of a model that run one after the other on the caller's stream (I; first-P / steady-P; the
+            # look-ahead EL plans) share a pool -- a plan's intermediates are dead when its replay ends, its outputs stay allocated --
+            # and the look-ahead BASE-LAYER plans, which run beside them on the second stream, share another. Every plan writes its
+            # intermediates before it reads them and takes its inputs from buffers outside the pools, so the replay order is free.
+            kw = {"pool": self._graph_pool(lane).id} if SHARED_GRAPH_POOL else {}
+            with torch.cuda.graph(g, **kw):
                 plan.outs = body(plan.inputs)
             plan.graph = g
         plan.graph.replay()
         plan.calls += 1
         return plan.outs
+
+    def _graph_pool(self, lane):
+        if lane not in self._graph_pools:
+            self._graph_pools[lane] = torch.cuda.MemPool()
+        return self._graph_pools[lane]
 
     def to(self, device):
         device = torch.device(device)
