@@ -163,7 +163,7 @@ def roofline_from_log(op_log):
     dom = table[0]
     common = {"kernel": dom["kernel"], "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
               "gflop_per_launch": dom["gflop_per_launch"], "mbytes_per_launch": dom["mbytes_per_launch"],
-              "traffic": pmc_traffic(dom["kernel"]), "mfma_busy": pmc_mfma_busy(dom["kernel"]),
+              "traffic": pmc_traffic(dom["kernel"]), "mfma_busy": pmc_mfma_busy(dom["kernel"]), "clock": stamped_clock(dom["kernel"]),
               "sampled_frames": EVENT_FRAMES,
               "conv_time_ms_sampled": round(sum(r["total_ms"] for r in table), 2),
               "conv_tflop_sampled": round(sum(r["gflop_per_launch"] * r["launches"] for r in table) * 1e-3, 3)}
@@ -210,6 +210,24 @@ def pmc_traffic(kernel):
                 if _strip_tmpl(rec["kernel"]).startswith(_strip_tmpl(kernel).rstrip(">")):
                     return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch_corrected"], "kernel_in_profile": rec["kernel"],
                             "source": os.path.relpath(path, ROOT), "collected_on": rec.get("command")}
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return None
+
+
+def stamped_clock(kernel):
+    """The shader clock the chip held inside `kernel` (delta s_memtime / delta s_memrealtime of its diagnostic stamp build after 200
+    back-to-back launches, tools/p3_stamps.py --json; DESIGN section 8: the dominant conv kernel runs at 1.56-1.69 GHz, not 2.4) and the
+    MFMA-issue share of its consumer waves' cycles -- committed per round, like the PMC passes."""
+    path = _latest_profile("p3_stamps.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        for rec in doc["kernels"]:
+            if _strip_tmpl(kernel).startswith(_strip_tmpl(rec["kernel"]).rstrip(">")):
+                out = dict(rec)
+                out.update(source=os.path.relpath(path, ROOT), nominal_ghz=2.4, collected_on=doc.get("command"))
+                return out
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return None

@@ -16,6 +16,7 @@ from lssvc_amd.weights import WeightStore  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
+    records = []
     ops.set_conv_precision("f16x3")
     g = torch.Generator().manual_seed(0)
     for name, cin, cout, H, W in (("64->64 @1152x1920", 64, 64, 1152, 1920), ("128->64 @576x960", 128, 64, 576, 960)):
@@ -65,15 +66,28 @@ def main():
         print("   compute %5.1f %% (%.0f cyc/phase; 336 MFMAs = 5376 issue cycles)   barrier wait %5.1f %% (%.0f cyc/phase)   "
               "epilogue %5.1f %% (%.0f cyc/tile, of which zeroing the accumulators %.0f)" % (100 * comp / cyc, comp / phases, 100 * bar / cyc, bar / phases,
                                                     100 * epi / cyc, epi / max(tiles, 1), zero / max(tiles, 1)))
+        records.append({"kernel": _lib.lib.lssvc_conv2d_last_kernel().decode().replace(" split", ""), "shape": name, "in_kernel_clock_ghz": round(clock / 1e3, 3),
+                        "mfma_issue_share_of_cycles": round(phases * 5376.0 / cyc, 3), "consumer_cycles": {"compute": round(comp / cyc, 3), "wait_for_fills": round(bar / cyc, 3), "epilogue": round(epi / cyc, 3)},
+                        "us_per_launch": round(wall_us, 1)})
         if pr.shape[0]:
             dma, ld, wait, cvt, pbar, pph, geo = (pr[:, i].median().item() for i in range(7))
             print("   producer wave, cycles per phase: weight-DMA issue %.0f, patch-load issue %.0f, convert + LDS stores %.0f, "
                   "barrier wait %.0f, tile geometry %.0f; staged build: boundary fill (consumers done -> fill signalled) %.0f cycles per tile" % (
                       dma / pph, ld / pph, cvt / pph, pbar / pph, geo / pph, wait / max(tiles, 1)))
+    if "--json" in sys.argv:
+        _write_json(records)
 
 
 def _unused():
     pass
+
+
+def _write_json(records):
+    import json
+    path = sys.argv[sys.argv.index("--json") + 1]
+    with open(path, "w") as f:
+        json.dump({"command": "LSSVC_CONV_DEBUG=256 python tools/p3_stamps.py --json <path> (diagnostic stamp build; 200 warm-up launches, then 30 timed)",
+                   "kernels": records[:1]}, f, indent=1)          # the first shape is the bench's dominant one (64->64 @1152x1920)
 
 
 if __name__ == "__main__":
