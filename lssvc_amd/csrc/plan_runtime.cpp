@@ -138,6 +138,9 @@ struct Plan {
     hipGraphExec_t exec = nullptr;
     int runs = 0;
     int bits_region = -1;
+    // fp16 range audit of the FIRST frame a plan codes with the engine's checkpoint (replay): one float per audited f16x3 launch
+    float *audit_dev = nullptr;
+    std::vector<std::pair<int, float>> audit_recs;      // (launch index, limit) per slot
     // write_stream = 1 plans
     bool has_host_steps = false;
     std::vector<Table> tables;
@@ -159,6 +162,7 @@ struct Plan {
         if (flag_host) (void)hipHostFree(flag_host);
         if (staged) (void)hipEventDestroy(staged);
         if (exec) (void)hipGraphExecDestroy(exec);
+        if (audit_dev) (void)hipFree(audit_dev);
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto s : side) (void)hipStreamDestroy(s);
         for (auto &r : regions)
@@ -526,11 +530,49 @@ int host_step(Plan &p, const Launch &l, hipStream_t main) {
     }
 }
 
-int replay(Plan &p, hipStream_t main) {
+// fp16 range of the f16x3 kernels' inputs (hip_ops.RangeAudit): they split activations into fp16 hi / lo parts and saturate at
+// +-65504 (GDN's 1x1 squares first), which the reference's fp32 convs do not. The Python front end audits the first frame of every
+// type and moves layers that come within 2x of the limit to the exact fp32 kernel; a plan bakes that kernel choice in. The engine
+// binds plans to ANY checkpoint of the architecture, so the first frame a plan codes is audited here as well: max |x| of every
+// input view of its f16x3 conv / fused-DepthConv / FFN launches (the tensors INSIDE the fused kernels are not visible here; the
+// Python audit splits those kernels). A value over the limit is an error that says so -- recompile the plans from this checkpoint
+// -- instead of a silently saturated frame.
+constexpr float kF16InputLimit = 32768.0f, kF16SquareInputLimit = 181.01934f;      // 2^15, 2^7.5: hip_ops.F16_INPUT_LIMIT / F16_SQUARE_INPUT_LIMIT
+
+static int audit_views(Plan &p, int launch, const lssvc_view *const *views, int n, float limit, hipStream_t st, size_t &slot) {
+    if (slot >= p.audit_recs.size()) p.audit_recs.emplace_back(launch, limit);
+    for (int i = 0; i < n; ++i)
+        if (views[i] && views[i]->ptr)
+            if (int rc = lssvc_absmax(views[i], p.audit_dev + slot, st)) return rc;
+    ++slot;
+    return 0;
+}
+
+int replay(Plan &p, hipStream_t main, bool audit = false) {
     auto stream_of = [&](uint32_t s) { return s == 0 ? main : p.side[s - 1]; };
-    size_t ev = 0;
+    size_t ev = 0, slot = 0;
+    if (audit) {
+        if (!p.audit_dev) LSSVC_HIP(hipMalloc(&p.audit_dev, sizeof(float) * (p.launches.size() + 1)));
+        LSSVC_HIP(hipMemsetAsync(p.audit_dev, 0, sizeof(float) * (p.launches.size() + 1), main));
+        p.audit_recs.clear();
+        LSSVC_HIP(hipStreamSynchronize(main));      // (the side streams' first launches may come before main's next one: the zeroing must have landed)
+    }
+    int li = -1;
     for (auto &l : p.launches) {
         hipStream_t st = stream_of(l.stream);
+        ++li;
+        if (audit && (l.id == FN_CONV2D || l.id == FN_CONV1X1_DW)) {
+            const lssvc_conv_desc *d = reinterpret_cast<const lssvc_conv_desc *>(l.args[0].blob.data());
+            if ((d->precision & LSSVC_PREC_MASK) == LSSVC_PREC_F16X3 && !(d->precision & LSSVC_PREC_SPLIT_IN)) {
+                const lssvc_view *v[LSSVC_CONV_MAX_INPUTS] = {nullptr, nullptr, nullptr};
+                for (int i = 0; i < d->n_in && i < LSSVC_CONV_MAX_INPUTS; ++i) v[i] = &d->in[i];
+                if (int rc = audit_views(p, li, v, LSSVC_CONV_MAX_INPUTS, d->in_act == LSSVC_INACT_SQUARE ? kF16SquareInputLimit : kF16InputLimit, st, slot)) return rc;
+            }
+        } else if (audit && l.id == FN_FFN) {
+            const lssvc_ffn_desc *d = reinterpret_cast<const lssvc_ffn_desc *>(l.args[0].blob.data());
+            const lssvc_view *v[3] = {&d->x, &d->pre_in, &d->ident};
+            if (int rc = audit_views(p, li, v, 3, kF16InputLimit, st, slot)) return rc;
+        }
         auto P = [&](int i) -> void * { return l.args[i].tag == TAG_PTR ? l.args[i].ptr : nullptr; };
         auto V = [&](int i) { return reinterpret_cast<const lssvc_view *>(l.args[i].blob.data()); };
         auto F = [&](int i) { return l.args[i].f; };
@@ -613,6 +655,21 @@ struct Engine {
     hipStream_t stream(void *s) const { return s ? (hipStream_t)s : own; }
 };
 
+// after the audited first frame has finished: every audited launch's max |input| against its limit
+static int audit_verdict(Plan &p, hipStream_t st) {
+    if (p.audit_recs.empty()) return 0;
+    std::vector<float> v(p.audit_recs.size());
+    LSSVC_HIP(hipMemcpyAsync(v.data(), p.audit_dev, sizeof(float) * v.size(), hipMemcpyDeviceToHost, st));
+    LSSVC_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < v.size(); ++i)
+        if (!(v[i] < p.audit_recs[i].second))
+            return fail("engine: with this checkpoint the input of launch %d of the '%s' plan (%s) reaches |x| = %g, outside what its fp16-split kernel can hold "
+                        "(limit %g): the plan's kernel choice was audited against another checkpoint -- compile the plans from this one (its range audit moves "
+                        "such layers to the exact fp32 kernel)", p.audit_recs[i].first, p.kind.c_str(), p.launches[(size_t)p.audit_recs[i].first].fn.c_str(), (double)v[i],
+                        (double)p.audit_recs[i].second);
+    return 0;
+}
+
 // Run one plan: caller's inputs in, first call eager, second call capture, later calls hipGraphLaunch, outputs out.
 int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &ins,
              const std::vector<std::pair<const char *, void *>> &outs, double *slots16, hipStream_t st) {
@@ -626,8 +683,9 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
         LSSVC_HIP(hipMemcpyAsync(p.regions[i].ptr, kv.second, p.regions[i].nbytes, hipMemcpyDefault, st));
     }
     LSSVC_CHECK(!p.has_host_steps, "engine: a '%s' plan runs through the encode / decode entry points", p.kind.c_str());
+    const bool audit = p.runs == 0 && !std::getenv("LSSVC_ENGINE_NO_AUDIT");
     if (p.runs == 0 || std::getenv("LSSVC_ENGINE_EAGER")) {
-        if (int e = replay(p, st)) return e;
+        if (int e = replay(p, st, audit)) return e;
     } else {
         if (!p.exec) {
             hipGraph_t graph = nullptr;
@@ -654,7 +712,7 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
     }
     LSSVC_HIP(hipMemcpyAsync(slots16, p.regions[p.bits_region].ptr, 16 * sizeof(double), hipMemcpyDeviceToHost, st));
     LSSVC_HIP(hipStreamSynchronize(st));                 // the bit counts are host values, as in the reference (.item())
-    return 0;
+    return audit ? audit_verdict(p, st) : 0;
 }
 
 // Run the encoder or decoder half of a frame: inputs in, eager replay with its host steps, outputs out; the strings the
@@ -674,7 +732,10 @@ int run_stream_plan(Plan &p, const std::vector<std::pair<const char *, const voi
     p.out_strings.clear();
     for (void *e : p.encoders)
         if (e) lssvc_rans_encoder_reset(e);
-    if (int e = replay(p, st)) return e;
+    const bool audit = p.runs == 0 && !std::getenv("LSSVC_ENGINE_NO_AUDIT");
+    if (int e = replay(p, st, audit)) return e;
+    if (audit)
+        if (int e = audit_verdict(p, st)) return e;
     ++p.runs;
     for (auto &kv : outs) {
         if (!kv.second) continue;

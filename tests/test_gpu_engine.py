@@ -367,3 +367,44 @@ def test_a_stream_plan_refuses_another_checkpoint(tmp_path):
                 assert rc != 0 and "another checkpoint's entropy parameters" in lib.lssvc_last_error().decode()
         finally:
             lib.lssvc_engine_destroy(eng)
+
+
+def test_the_engine_audits_the_fp16_range_of_a_checkpoint_it_was_not_compiled_with(tmp_path):
+    """a plan bakes in the kernel choice of the fp16 range audit of the checkpoint it was compiled from, and the engine binds
+    it to any checkpoint of the architecture. The first frame a plan codes is therefore audited in the engine too (max |x| of every input
+    of its f16x3 launches against the limits of hip_ops.RangeAudit): a checkpoint whose activations leave the range is an error that
+    says what to do, not a silently saturated frame; the checkpoint the plan came from passes."""
+    import ctypes as C
+    from lssvc_amd import IntraSS, plan_compiler, _lib
+    from lssvc_amd.synth import synth_state_dict
+    g = torch.Generator().manual_seed(5)
+    H = W = 128
+    x_el, x_bl = torch.rand(1, 3, H, W, generator=g).to(DEV), torch.rand(1, 3, H // 2, W // 2, generator=g).to(DEV)
+    sd = synth_state_dict("intra_ss", 3, 0.6)
+    a = IntraSS.from_state_dict(sd).to(DEV).eval()
+    a.set_scale_information(2.0, (H, W), (0, 0, 0, 0))
+    plan = str(tmp_path / "i.plan")
+    plan_compiler.compile_iframe(a, x_bl, x_el, plan)
+    loud = dict(sd)
+    loud["base_layer_model.g_a.0.conv1.weight"] = sd["base_layer_model.g_a.0.conv1.weight"] * 3.0e6      # its output feeds the next f16x3 conv
+    b = IntraSS.from_state_dict(loud)                                                                      # (host side only: the table of raw tensors)
+    from lssvc_amd.weights import WeightStore
+    lib = _lib.lib
+    P = lambda t: C.c_void_p(t.data_ptr())
+    for name, store, ok in (("same", a.W, True), ("loud", WeightStore(b._sd, torch.device(DEV)), False)):
+        eng = lib.lssvc_engine_create(0)
+        try:
+            table, n = store._ckpt()
+            _lib.check(lib.lssvc_engine_load_checkpoint(eng, 0, table, n))
+            _lib.check(lib.lssvc_engine_load_intra(eng, plan.encode()))
+            bits = (C.c_double * 2)()
+            oi = [torch.empty(1, 3, H // 2, W // 2, device=DEV), torch.empty(1, 3, H, W, device=DEV), torch.empty(1, 64, H, W, device=DEV)]
+            rc = lib.lssvc_engine_iframe(eng, P(x_bl), P(x_el), bits, *[P(o) for o in oi], None)
+            torch.cuda.synchronize()
+            if ok:
+                _lib.check(rc)
+            else:
+                msg = lib.lssvc_last_error().decode()
+                assert rc != 0 and "outside what its fp16-split kernel can hold" in msg and "compile the plans from this one" in msg, (rc, msg)
+        finally:
+            lib.lssvc_engine_destroy(eng)
