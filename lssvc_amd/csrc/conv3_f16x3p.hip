@@ -57,7 +57,18 @@ struct P3Geom {
     static constexpr int W_INSTR = 2 * W_ITEMS / 64;              // wave-level DMA instructions for both planes (= 9 MF)
     static constexpr int NPROD = kP3ProducerThreads / 64;
     static constexpr int NDMA = (W_INSTR + NPROD - 1) / NPROD;
-    static constexpr int LDS_BYTES = 2 * (2 * PATCH_HALFS + 2 * W_HALFS) * 2;      // + the bias vector (launch_p3)
+    // PATCH RING (round 5): with three patch buffers instead of two the producers run the patch one phase further ahead than the weights
+    // (patch of phase k+2 beside the weights of phase k+1, while the consumers run phase k): twice the patch bytes in flight per CU and no
+    // fill that is late because its buffer was released late -- the 48-channel kernels waited 18 % of their cycles for fills. Where the LDS
+    // holds it: 3 x 30 KB of patch + 2 x 27.6 KB of weights at MF = 3; at MF = 4 the sum is 163 584 of the 163 840 bytes and the bias
+    // vector, the hand-off slots and the trash slots no longer fit, at stride 2 the patch is 36 KB: those keep two buffers.
+#ifdef LSSVC_P3_NO_RING      // (A/B build: two patch buffers everywhere, the round-4 schedule)
+    static constexpr int NPB = 2;
+#else
+    static constexpr int NPB = (S == 1 && (3 * 2 * PATCH_HALFS + 2 * 2 * W_HALFS) * 2 + 2048 + 64 + 2 * kP3ProducerThreads * 8 <= 160 * 1024) ? 3 : 2;
+#endif
+    static constexpr int LDS_BYTES = 2 * (2 * PATCH_HALFS + 2 * W_HALFS) * 2;      // two-buffer layout; + the bias vector (launch_p3)
+    static constexpr int LDS_BYTES_RING = (NPB * 2 * PATCH_HALFS + 2 * 2 * W_HALFS) * 2;
     // ---- STAGE variant (staged epilogue, see the kernel): the whole 160 KB, laid out [patch 0][weights 0][F][weights 1][patch 1][tail]
     // so that either operand buffer pair plus the free middle F is ONE contiguous run the finished tile can be parked in
     static constexpr int PB = 2 * PATCH_HALFS * 2, WB = 2 * W_HALFS * 2;          // bytes of one patch / weight buffer (both planes)
@@ -106,9 +117,10 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     using G = P3Geom<MF, S>;
     constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP, NP = G::NP;
     constexpr int SR = STAGE ? G::SR : 0;
+    constexpr int NPB = STAGE ? 2 : G::NPB;                                         // patch buffers (P3Geom: PATCH RING)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *const patch0 = reinterpret_cast<_Float16 *>(smem);                    // [buf][plane][PH*PW][16]
-    _Float16 *const wts0 = STAGE ? reinterpret_cast<_Float16 *>(smem + G::OFF_W0) : patch0 + 4 * G::PATCH_HALFS;      // [buf][plane][tap][m][16]
+    _Float16 *const wts0 = STAGE ? reinterpret_cast<_Float16 *>(smem + G::OFF_W0) : patch0 + NPB * 2 * G::PATCH_HALFS;      // [buf][plane][tap][m][16]
     float *const bias_s = STAGE ? reinterpret_cast<float *>(smem + G::OFF_TAIL) : reinterpret_cast<float *>(wts0 + 4 * G::W_HALFS);   // [m_tiles * TM], zero past M_pad
     // operand buffer b of the double buffer (STAGE: buffer 1 sits at the far end, see P3Geom)
     auto patch_buf = [&](int b) { return STAGE ? reinterpret_cast<_Float16 *>(smem + (b ? G::OFF_P1 : G::OFF_P0)) : patch0 + b * 2 * G::PATCH_HALFS; };
@@ -303,6 +315,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
         float4 preg[NP];
         unsigned pmask = 0;
         auto load_patch = [&](const P3Phase &ph) {
+            pmask = 0;
             long long ts = 0;
             if (STAMP) ts = __builtin_amdgcn_s_memtime();
             if (ph.it != pgeom_it) patch_geometry(ph.it);
@@ -314,7 +327,6 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
             const V X = p.in[ph.k.seg];
             const bool cvalid = quad4 < X.C - ph.k.c0;
             const int cc = cvalid ? ph.k.c0 + quad4 : 0;
-            pmask = 0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const bool ok = ppix[i] >= 0 && cvalid;
@@ -491,6 +503,63 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 store_patch(buf);
             }
         };
+        if constexpr (NPB == 3) {
+            // ---- PATCH RING schedule: weights(k+1) and patch(k+2) while the consumers run phase k
+            P3Phase php = ph;                               // the phase whose patch is filled next
+            stage_weights(ph, 0);
+            fill_patch(php, 0);
+            if (total > 1) {
+                php = next_phase(php);
+                fill_patch(php, 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();                               // (A) phase 0 is in weight buffer 0 / patch buffer 0, the patch of phase 1 in patch buffer 1
+            int pb = 2;                                    // patch buffer of phase k+2
+            for (int k = 0; k + 1 < total; ++k) {
+                long long tb = 0;
+                if (STAMP) tb = __builtin_amdgcn_s_memtime();
+                if (k >= 1) wait_for(sync_s + 4, k);       // phase k-1 is over: weight buffer (k+1)&1 and patch buffer (k+2)%3 = (k-1)%3 are free
+                if (STAMP) s_bar += __builtin_amdgcn_s_memtime() - tb;
+                ph = next_phase(ph);
+                const bool ablate = STAMP && (p.debug & 7);
+                if (!(ablate && (p.debug & 2))) stage_weights(ph, (k + 1) & 1);
+                const bool more = k + 2 < total && !(ablate && (p.debug & 1));
+                if (more) {
+                    php = next_phase(php);
+                    if constexpr (SPLIT) dma_patch(php, pb);
+                    else load_patch(php);
+                }
+                // fill(k+1) = the weights just requested + the patch of phase k+1, whose LDS stores were waited for at the end of the previous
+                // iteration: signalled as soon as the weight DMA has landed -- the NP (SPLIT: NPDMA) younger patch requests stay in flight
+                if (more) {
+                    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_INSTR % G::NPROD == 0 ? NPDMA : NPDMA - 1) : "memory");      // (some waves issue one patch DMA fewer)
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                // (published by a ds_write written in asm: before a compiler-visible LDS store the compiler drains vmcnt(0) as long as an
+                // LDS-DMA is in flight -- the wait above has just named the DMA that matters -- and the patch loads would be waited for too)
+                if (lane == 0) {
+                    const unsigned slot_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)(sync_s + pw);
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(k + 1) : "memory");
+                }
+                if (more) {
+                    if constexpr (!SPLIT) {
+                        if (!(ablate && (p.debug & 4))) store_patch(pb);
+                        else
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(preg[i].x), "v"(preg[i].y), "v"(preg[i].z), "v"(preg[i].w));
+                    }
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the patch of phase k+2 is in the LDS before fill(k+2) is signalled
+                    pb = pb == 2 ? 0 : pb + 1;
+                }
+            }
+            if (STAMP && lane == 0 && p.gdn_x.p) {
+                long long *o = reinterpret_cast<long long *>(p.gdn_x.p) + ((size_t)gridDim.x * kP3Consumers + (size_t)blockIdx.x * 4 + pw) * 8;
+                o[0] = s_dma; o[1] = s_ld; o[2] = s_wait; o[3] = s_cvt; o[4] = s_bar; o[5] = total; o[6] = s_geo; o[7] = 0;
+            }
+            return;
+        }
         stage_weights(ph, 0);
         fill_patch(ph, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of this wave has landed
@@ -576,6 +645,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
 
     __syncthreads();                                       // (A)
     int it = 0, kt = 0;                                    // tile index in this workgroup's sequence, phase inside the tile
+    int pring = 0;                                         // PATCH RING: k % 3
     const int total = n_it * phases_per_tile;
     long long t_comp = 0, t_bar = 0, t_epi = 0, t_zero = 0, t_mark = 0, t_real0 = 0, t_cyc0 = 0;
     if (STAMP) {
@@ -585,8 +655,9 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
     for (int k = 0; k < total; ++k) {
         int fill_seen = 0;                                 // producers' slots as read during the last unit of this phase
         const int buf = k & 1;
-        const _Float16 *ph_ = patch_buf(buf);                               // hi plane; the lo plane follows it
+        const _Float16 *ph_ = patch_buf(NPB == 3 ? pring : buf);           // hi plane; the lo plane follows it (PATCH RING: buffer k % 3)
         const _Float16 *wh_ = wts_buf(buf);
+        if (NPB == 3) pring = pring == 2 ? 0 : pring + 1;
         // The phase as NSTEP x NG units (K step u, row group g of GR rows), software-pipelined and INTERLEAVED by hand.
         // In-kernel stamps: the straightforward loop takes 6.6 k cycles per phase for 336 MFMAs = 5.4 k issue cycles, with
         // the producers idle or not and with the fragment reads prefetched or not -- it is neither LDS latency nor
@@ -802,7 +873,7 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
     q.tiles_x = (p.Wout + 15) / 16;
     q.tiles_y = (p.Hout + G::TH - 1) / G::TH;
     q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
-    const size_t lds = (size_t)G::LDS_BYTES + (size_t)q.m_tiles * G::TM * sizeof(float) + 32 + 2 * kP3ProducerThreads * 8;      // + bias vector + hand-off slots + trash slots
+    const size_t lds = (size_t)G::LDS_BYTES_RING + (size_t)q.m_tiles * G::TM * sizeof(float) + 32 + 2 * kP3ProducerThreads * 8;      // + bias vector + hand-off slots + trash slots
     if (lds > 160 * 1024) return fail("conv2d(f16x3p): %zu bytes of LDS", lds);
     static LdsGrant grant;
     if (grant.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, INACT, false, false, S, SPLIT>), lds)) return 1;
@@ -839,10 +910,10 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
         hipLaunchKernelGGL((conv3_f16x3p_kernel<4, false, true, true>), dim3((unsigned)blocks), dim3(kP3Threads), G::TOTAL, st, q);
         return launch_status("conv2d(f16x3p, staged, stamps)");
     }
-    if (MF == 4 && !INACT && (p.debug & 256)) {             // diagnostic: in-kernel stamps (tools/p3_stamps.py)
+    if ((MF == 4 || MF == 3) && !INACT && (p.debug & 256)) {             // diagnostic: in-kernel stamps (tools/p3_stamps.py)
         static LdsGrant grant_s;
-        if (grant_s.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<4, false, true>), lds)) return 1;
-        hipLaunchKernelGGL((conv3_f16x3p_kernel<4, false, true>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
+        if (grant_s.ensure(reinterpret_cast<const void *>(conv3_f16x3p_kernel<MF, false, true>), lds)) return 1;
+        hipLaunchKernelGGL((conv3_f16x3p_kernel<MF, false, true>), dim3((unsigned)blocks), dim3(kP3Threads), lds, st, q);
         return launch_status("conv2d(f16x3p, stamps)");
     }
     // staged epilogue (the kernel's STAGE note; option p3_stage, OFF by default: measured 5-12 % SLOWER than the direct epilogue,

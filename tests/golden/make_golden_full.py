@@ -7,6 +7,7 @@ benchmark's own sizes on seeded synthetic weights and an integer-exact synthetic
     x1_5_1080p_ip   EL 1152x1920 / BL 768x1280 (the non-integer ratio at full size), I + first P
     x2_2160p_ipp    BASELINE configs[3] shape: EL 2176x3840 / BL 1088x1920, I + first P + steady P (a P-frame: ~40 GB of host memory)
     x2_1080p_gop32  BASELINE configs[1] in full: the whole 32-frame closed loop of test.py:182-250 at EL 1152x1920 / BL 576x960.
+    x2_2160p_gop12  BASELINE configs[3] in full (round 5): the 12-frame closed loop (IP12) at EL 2176x3840 / BL 1088x1920.
                     Bits, PSNR, whole-tensor sums and the quantised latents of ALL 32 frames; strided samples only of
                     frames 0, 1, 2, 15, 31 (the fixture would otherwise be 50 MB)
 
@@ -42,10 +43,11 @@ CASES = {
     "x1_5_1080p_ip": (2, 1080, 1920, 1.5, 0.55, 1),
     "x2_2160p_ipp": (3, 2160, 3840, 2.0, 0.55, 2),
     "x2_1080p_gop32": (32, 1080, 1920, 2.0, 0.55, 4),
+    "x2_2160p_gop12": (12, 2160, 3840, 2.0, 0.55, 6),     # round 5: BASELINE configs[3] in full (UVG 2160p enhancement layer, IP12): the whole 12-frame closed loop
     "_dev_x2_128_ipp": (3, 120, 128, 2.0, 0.55, 3),       # generator self-check only, not committed
 }
 # (spatial stride, channel stride) of the stored samples
-DENSE_FRAMES = (0, 1, 2, 15, 31)     # frames of a long case whose strided samples are stored
+DENSE_FRAMES = (0, 1, 2, 11, 15, 31)     # frames of a long case whose strided samples are stored (11: the last frame of the 12-frame 2160p case, round 5)
 SAMPLE = {"x_hat_bl": (4, 1), "x_hat_el": (8, 1), "feature_el": (32, 4), "feature_bl": (16, 4), "mv_hat": (8, 1),
           "warp_frame": (8, 1), "x_bl": (8, 1)}
 

@@ -19,7 +19,9 @@ def main():
     records = []
     ops.set_conv_precision("f16x3")
     g = torch.Generator().manual_seed(0)
-    for name, cin, cout, H, W in (("64->64 @1152x1920", 64, 64, 1152, 1920), ("128->64 @576x960", 128, 64, 576, 960)):
+    shapes = (("64->64 @1152x1920", 64, 64, 1152, 1920), ("128->64 @576x960", 128, 64, 576, 960), ("48->48 @1152x1920", 48, 48, 1152, 1920),
+              ("96->48 @1152x1920", 96, 48, 1152, 1920))
+    for name, cin, cout, H, W in shapes:
         w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
         b = torch.randn(cout, generator=g)
         Wt = WeightStore({"c.weight": w, "c.bias": b}, dev)
@@ -63,11 +65,11 @@ def main():
         clock = cyc / real * 100.0                 # s_memrealtime ticks at 100 MHz
         print("%s (%s) LSSVC_CONV_DEBUG=%s: %.1f us per launch; per consumer wave, median over %d waves: %d phases / %d tiles; total %.0f cycles at %.0f MHz" %
               (name, _lib.lib.lssvc_conv2d_last_kernel().decode(), os.environ["LSSVC_CONV_DEBUG"], wall_us, s.shape[0], phases, tiles, cyc, clock))
-        print("   compute %5.1f %% (%.0f cyc/phase; 336 MFMAs = 5376 issue cycles)   barrier wait %5.1f %% (%.0f cyc/phase)   "
+        print("   compute %5.1f %% (%.0f cyc/phase; MF = 4: 336 MFMAs = 5376 issue cycles, MF = 3: 252 = 4032)   barrier wait %5.1f %% (%.0f cyc/phase)   "
               "epilogue %5.1f %% (%.0f cyc/tile, of which zeroing the accumulators %.0f)" % (100 * comp / cyc, comp / phases, 100 * bar / cyc, bar / phases,
                                                     100 * epi / cyc, epi / max(tiles, 1), zero / max(tiles, 1)))
         records.append({"kernel": _lib.lib.lssvc_conv2d_last_kernel().decode().replace(" split", ""), "shape": name, "in_kernel_clock_ghz": round(clock / 1e3, 3),
-                        "mfma_issue_share_of_cycles": round(phases * 5376.0 / cyc, 3), "consumer_cycles": {"compute": round(comp / cyc, 3), "wait_for_fills": round(bar / cyc, 3), "epilogue": round(epi / cyc, 3)},
+                        "mfma_issue_share_of_cycles": round(phases * (5376.0 if cout % 64 == 0 else 4032.0) / cyc, 3), "consumer_cycles": {"compute": round(comp / cyc, 3), "wait_for_fills": round(bar / cyc, 3), "epilogue": round(epi / cyc, 3)},
                         "us_per_launch": round(wall_us, 1)})
         if pr.shape[0]:
             dma, ld, wait, cvt, pbar, pph, geo = (pr[:, i].median().item() for i in range(7))
