@@ -31,3 +31,18 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _process_wide_modes_do_not_leak(request):
+    """Several GPU tests switch process-wide modes (hip_ops.CONV_PRECISION, hip_ops.MULTI_STREAM) and some used to leave them switched:
+    tests/test_gpu_bench_kernels.py ended in "f32", and every file after it in a whole-suite run silently tested the exact-fp32 mode
+    instead of the default f16x3 one (found in round 5 when a test that needs f16x3 launches passed alone and failed in the suite).
+    Every GPU test now starts from, and hands back, the modes it found."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    from lssvc_amd import hip_ops
+    saved = (hip_ops.CONV_PRECISION, hip_ops.MULTI_STREAM)
+    yield
+    hip_ops.CONV_PRECISION, hip_ops.MULTI_STREAM = saved

@@ -51,6 +51,7 @@ def _get(name):
 
 def _run(hip, mode, fn):
     """fn() under conv precision `mode` with the op log on -> (result, kernel name of the last conv launch)."""
+    old = hip.CONV_PRECISION
     try:
         hip.set_conv_precision(mode)
         hip.OP_LOG = []
@@ -58,7 +59,7 @@ def _run(hip, mode, fn):
         return out, hip.OP_LOG[-1]["kernel"]
     finally:
         hip.OP_LOG = None
-        hip.set_conv_precision("f32")
+        hip.set_conv_precision(old)          # (round 5: this used to LEAVE the process in "f32", and every test file after this one ran in that mode)
 
 
 # cins, cout, H, W, in_act, act, residual, pixel_shuffle, expected persistent instantiation
