@@ -45,7 +45,7 @@ def _code(inet, pnet, x_bl, x_el, H, W, gops, frames, lookahead=False, scale=2.0
     return rows
 
 
-@pytest.mark.parametrize("H,W,precision", [(128, 128, "f16x3"), (128, 256, "f16x3"), (128, 128, "f32")])
+@pytest.mark.parametrize("H,W,precision", [(128, 128, "f16x3"), (128, 256, "f16x3"), pytest.param(128, 128, "f32", marks=pytest.mark.slow)])
 def test_graph_replay_is_bit_identical_to_eager(H, W, precision):
     from lssvc_amd import hip_ops
     from lssvc_amd.synth import synth_clip
@@ -72,7 +72,7 @@ def test_graph_replay_is_bit_identical_to_eager(H, W, precision):
         hip_ops.set_conv_precision(old)
 
 
-@pytest.mark.parametrize("streams,alias", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("streams,alias", [(True, False), (True, True), (False, False), pytest.param(False, True, marks=pytest.mark.slow)])
 def test_lookahead_base_layer_is_bit_identical(streams, alias):
     """BL(t+1) coded beside EL(t) (forward_one_frame's look-ahead protocol): bits and every DPB tensor of every frame equal the plain
     loop's, eager and replayed from the look-ahead plans, with and without side streams inside the layers."""
