@@ -163,7 +163,7 @@ def roofline_from_log(op_log):
     dom = table[0]
     common = {"kernel": dom["kernel"], "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
               "gflop_per_launch": dom["gflop_per_launch"], "mbytes_per_launch": dom["mbytes_per_launch"],
-              "traffic": pmc_traffic(dom["kernel"]), "mfma_busy": pmc_mfma_busy(dom["kernel"]), "clock": stamped_clock(dom["kernel"]),
+              "traffic": pmc_traffic(dom["kernel"]), "mfma_busy": pmc_mfma_busy(dom["kernel"]), "clock": stamped_clock(dom["kernel"]), "chip_sustains": clock_probe(),
               "sampled_frames": EVENT_FRAMES,
               "conv_time_ms_sampled": round(sum(r["total_ms"] for r in table), 2),
               "conv_tflop_sampled": round(sum(r["gflop_per_launch"] * r["launches"] for r in table) * 1e-3, 3)}
@@ -229,6 +229,26 @@ def stamped_clock(kernel):
                 out.update(source=os.path.relpath(path, ROOT), nominal_ghz=2.4, collected_on=doc.get("command"))
                 return out
     except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return None
+
+
+def clock_probe():
+    """What the chip sustains for a bare v_mfma_f32_16x16x32_f16 loop (tools/probes/clock_probe.hip, committed per round): issued TFLOP/s and
+    in-kernel clock on zeros, on random operands, and on random operands re-read from LDS at the conv kernel's ratio -- the ceiling the
+    2.5 PFLOP/s `peak` stands for on real data."""
+    path = _latest_profile("clock_probe.txt")
+    try:
+        out = {}
+        with open(path) as f:
+            for ln in f:
+                t = ln.split()
+                if len(t) > 8 and t[2] == "issued":
+                    out[t[0]] = {"issued_tflops": float(t[1]), "clock_mhz": float(t[t.index("clock") + 1]), "mfma_duty": float(t[t.index("duty") + 1])}
+        if out:
+            out["source"] = os.path.relpath(path, ROOT)
+            return out
+    except (OSError, ValueError, IndexError):
         pass
     return None
 
