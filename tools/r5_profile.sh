@@ -25,6 +25,7 @@ cd $GRAFT_REPO_ROOT
 LSSVC_CONV_DEBUG=256 timeout -k 10 200 python tools/p3_stamps.py --json profiles/r05_p3_stamps.json 2>&1 | grep -v amdgpu.ids > profiles/r05_p3_stamps.txt || exit 1
 LSSVC_BENCH_SIGNATURES=profiles/r05_bench_signatures.txt timeout -k 10 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d-pass --no-side-configs > $OUT/bench_signatures.json 2> $OUT/bench_signatures.log || exit 1
 timeout -k 10 200 python tools/plan_histogram.py > profiles/r05_plan_histogram.txt 2>&1 || exit 1
+[ -x tools/probes/clock_probe.bin ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/clock_probe.hip -o tools/probes/clock_probe.bin || exit 1
 timeout -k 10 120 tools/probes/clock_probe.bin 2.5 > profiles/r05_clock_probe.txt 2>&1 || exit 1
 cp profiles/r05_p3_stamps.json profiles/r05_p3_stamps.txt profiles/r05_bench_signatures.txt profiles/r05_plan_histogram.txt profiles/r05_clock_probe.txt profiles/r05_overlap_bench_single_stream.txt $OUT/ 2>/dev/null
 cat profiles/r05_p3_stamps.txt; head -5 profiles/r05_bench_signatures.txt; tail -5 profiles/r05_plan_histogram.txt
