@@ -539,10 +539,14 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 }
                 // (published by a ds_write written in asm: before a compiler-visible LDS store the compiler drains vmcnt(0) as long as an
                 // LDS-DMA is in flight -- the wait above has just named the DMA that matters -- and the patch loads would be waited for too)
+#ifdef LSSVC_P3_RELEASE_SIGNAL
+                signal(sync_s + pw, k + 1);                // (diagnostic build: a RELEASE store, ordering by the compiler -- it drains every load first)
+#else
                 if (lane == 0) {
                     const unsigned slot_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)(sync_s + pw);
                     asm volatile("ds_write_b32 %0, %1" ::"v"(slot_addr), "v"(k + 1) : "memory");
                 }
+#endif
                 if (more) {
                     if constexpr (!SPLIT) {
                         if (!(ablate && (p.debug & 4))) store_patch(pb);
