@@ -523,6 +523,7 @@ __global__ __launch_bounds__(kP3Threads, 1) void conv3_f16x3p_kernel(const ConvP
                 ph = next_phase(ph);
                 const bool ablate = STAMP && (p.debug & 7);
                 if (!(ablate && (p.debug & 2))) stage_weights(ph, (k + 1) & 1);
+                asm volatile("" ::: "memory");             // the counted wait below relies on this order: every weight DMA is OLDER than every patch request
                 const bool more = k + 2 < total && !(ablate && (p.debug & 1));
                 if (more) {
                     php = next_phase(php);
