@@ -1,0 +1,34 @@
+// conv3_f16x3p_r2.hip -- round-6 instantiations of the persistent warp-specialised 3x3 kernel, second translation unit (see
+// conv3_f16x3p_r.hip): the narrow heads, stride 2 with register prefetch / pair loads, and the 24x16 tiling with pair loads.
+#include "conv3_f16x3p_kernel.h"
+
+namespace lssvc {
+
+int launch_p3_narrow(const ConvP &p, bool inact, bool flat, int pf, hipStream_t st) {
+#define LSSVC_P3N_CASE(f)                                                                                                                   \
+    if (pf == f) {                                                                                                                          \
+        if (flat) return inact ? launch_p3r<1, true, 1, 4, f, true, true>(p, st) : launch_p3r<1, false, 1, 4, f, true, true>(p, st);        \
+        return inact ? launch_p3r<1, true, 1, 4, f, false, true>(p, st) : launch_p3r<1, false, 1, 4, f, false, true>(p, st);                \
+    }
+    LSSVC_P3N_CASE(2) LSSVC_P3N_CASE(1) LSSVC_P3N_CASE(0)
+#undef LSSVC_P3N_CASE
+    return fail("conv2d(f16x3p narrow): prefetch mode %d", pf);
+}
+
+int launch_p3s2_pf(const ConvP &p, int mf, bool inact, int pf, hipStream_t st) {
+#define LSSVC_P3S_CASE(m, f) \
+    if (mf == m && pf == f) return inact ? launch_p3r<m, true, 2, 0, f, false, false>(p, st) : launch_p3r<m, false, 2, 0, f, false, false>(p, st);
+    LSSVC_P3S_CASE(4, 1) LSSVC_P3S_CASE(4, 2) LSSVC_P3S_CASE(3, 1) LSSVC_P3S_CASE(3, 2)
+#undef LSSVC_P3S_CASE
+    return fail("conv2d(f16x3p, stride 2, prefetch %d): no kernel for MF=%d", pf, mf);
+}
+
+int launch_p3_big_pair(const ConvP &p, int mf, bool inact, hipStream_t st) {
+#define LSSVC_P3B_CASE(m) \
+    if (mf == m) return inact ? launch_p3r<m, true, 1, 0, 2, false, false>(p, st) : launch_p3r<m, false, 1, 0, 2, false, false>(p, st);
+    LSSVC_P3B_CASE(4) LSSVC_P3B_CASE(3) LSSVC_P3B_CASE(2)
+#undef LSSVC_P3B_CASE
+    return fail("conv2d(f16x3p, pair loads): no kernel for MF=%d", mf);
+}
+
+}  // namespace lssvc

@@ -26,9 +26,11 @@ namespace lssvc {
 // ---- runtime tuning switches: environment at first use, lssvc_set_option() afterwards ----------------
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<bool> g_opt_set[OPT_COUNT];
-static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS", "LSSVC_DWPRE_DEEP", "LSSVC_P3_BLOCKS", "LSSVC_P3_STAGE", "LSSVC_F16X3_PERSIST_S2"};
-static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks", "dwpre_deep", "p3_blocks", "p3_stage", "f16x3_persist_s2"};
-static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1};      // p3_stage: off (measured slower); kept for the record and its test
+static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS", "LSSVC_DWPRE_DEEP", "LSSVC_P3_BLOCKS", "LSSVC_P3_STAGE", "LSSVC_F16X3_PERSIST_S2",
+                                              "LSSVC_P3_SMALL", "LSSVC_P3_NARROW", "LSSVC_P3_PF2", "LSSVC_P3_FORCE", "LSSVC_GDN_FAST_OPT", "LSSVC_P3_BIG_PAIR"};
+static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks", "dwpre_deep", "p3_blocks", "p3_stage", "f16x3_persist_s2",
+                                               "p3_small", "p3_narrow", "p3_pf2", "p3_force", "gdn_fast", "p3_big_pair"};
+static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1, 1, 1, 2, 0, 1, 0};      // p3_stage: off (measured slower); kept for the record and its test
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
         const char *e = getenv(kOptEnv[which]);
@@ -171,6 +173,11 @@ extern "C" int lssvc_conv2d(const lssvc_conv_desc *d, void *stream) {
         p.fast_epi = 0;
         if (common && !d->pixel_shuffle && (!d->residual.ptr || p.res_vec)) p.fast_epi = 1;
         if (common && d->pixel_shuffle && !d->residual.ptr && (d->Cout % 16 == 0)) p.fast_epi = 2;   // cps % 4 == 0
+    }
+    {
+        static const int gdn_fast_on = getenv("LSSVC_GDN_FAST") ? atoi(getenv("LSSVC_GDN_FAST")) : 1;
+        p.gdn_fast = (gdn_fast_on && option_get(OPT_GDN_FAST) && d->epilogue != LSSVC_EPI_NONE && (d->Cout % 4 == 0) && p.out_vec && p.gdn_vec && !d->pixel_shuffle &&
+                      d->out_scale == 1.0f && (!d->residual.ptr || p.res_vec)) ? 1 : 0;
     }
     LSSVC_CHECK(!d->residual2.ptr || p.fast_epi == 1, "conv2d: residual2 needs the plain fused epilogue (no GDN / shuffle / scale, Cout %% 4 == 0)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -39,6 +39,7 @@ struct ConvP {
     int fast_epi;    // host: Cout % 4 == 0, 16-byte addressable out / residual, no pixel shuffle, no GDN -> straight-line epilogue
     int in_split;    // every input is a PRE-SPLIT tensor (LSSVC_PREC_SPLIT_IN): [pixel][16-channel chunk][hi x16 | lo x16] fp16, activation applied
     int out_split;   // the output is written pre-split (LSSVC_PREC_SPLIT_OUT), after out_act
+    int gdn_fast;    // host: GDN / IGDN epilogue with Cout % 4 == 0, 16-byte addressable out / gdn_x / residual, no shuffle, out_scale 1 -> conv_epilogue_gdn
 };
 
 constexpr int CP = 12;  // LDS row pitch in floats (CK=8 + 4 pad)
@@ -213,6 +214,73 @@ struct EpiSide {
     float4 rs[MF];    // residual
 };
 
+// The GDN / IGDN epilogue for the common case (p.gdn_fast; round 6): what conv_epilogue_flat computes per element -- bias, sqrt, the
+// normalisation x * (1 / s) | x * s | x / s, activation, residual -- in the same order with the same roundings, but with the kind of
+// normalisation a COMPILE-TIME parameter and float4 loads / stores only. The general routine carries all three normalisations, the
+// scalar fall-backs of every load and store, the pixel-shuffle store and the output scale behind run-time tests: 7 k instructions per
+// 32-pixel group in the GDN 1x1 kernels (two correctly rounded divisions compiled per element, one of them never executed), which ran
+// at 2.0 TB/s where the same kernel without the normalisation streams at 4.6 (profiles/r06_gdn_ab.txt).
+template <int MF, int RPW, int EPI>
+__device__ __forceinline__ void conv_epilogue_gdn_impl(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0, int lg) {
+    float4 bb[MF];
+    bool mv[MF];                                        // this lane's 4 channels of fragment f exist (Cout % 4 == 0: all four or none)
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int mb = m0 + f * 16 + 4 * lg;
+        mv[f] = mb < p.Cout;
+        bb[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && mv[f]) bb[f] = *reinterpret_cast<const float4 *>(p.bias + mb);
+    }
+    const bool has_res = p.res.p != nullptr;
+    float4 gx[2][MF], rs[2][MF];
+    auto load_side = [&](int r, float4 (&g)[MF], float4 (&q)[MF]) {
+        const size_t opix = (size_t)(pix[r] >= 0 ? pix[r] : 0);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int mb = mv[f] ? m0 + f * 16 + 4 * lg : 0;
+            g[f] = *reinterpret_cast<const float4 *>(p.gdn_x.p + opix * p.gdn_x.ld + mb);
+            if (has_res) q[f] = *reinterpret_cast<const float4 *>(p.res.p + opix * p.res.ld + mb);
+        }
+    };
+    load_side(0, gx[0], rs[0]);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        if (r + 1 < RPW) load_side(r + 1, gx[(r + 1) & 1], rs[(r + 1) & 1]);      // issued before row r's stores (see conv_epilogue_flat)
+        const size_t opix = (size_t)(pix[r] >= 0 ? pix[r] : 0);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int mb = m0 + f * 16 + 4 * lg;
+            float v[4] = {acc[f][r][0] + bb[f].x, acc[f][r][1] + bb[f].y, acc[f][r][2] + bb[f].z, acc[f][r][3] + bb[f].w};
+            const float x[4] = {gx[r & 1][f].x, gx[r & 1][f].y, gx[r & 1][f].z, gx[r & 1][f].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sq = sqrtf(v[j]);
+                if (EPI == LSSVC_EPI_X_MUL_RSQRT) v[j] = x[j] * (1.0f / sq);
+                else if (EPI == LSSVC_EPI_X_MUL_SQRT) v[j] = x[j] * sq;
+                else v[j] = x[j] / sq;
+            }
+            if (p.act == LSSVC_ACT_LRELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+            } else if (p.act == LSSVC_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            }
+            if (has_res) {
+                v[0] += rs[r & 1][f].x; v[1] += rs[r & 1][f].y; v[2] += rs[r & 1][f].z; v[3] += rs[r & 1][f].w;
+            }
+            if (pix[r] >= 0 && mv[f]) *reinterpret_cast<float4 *>(p.out.p + opix * p.out.ld + mb) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int MF, int RPW>
+__device__ __forceinline__ void conv_epilogue_gdn(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0, int lg) {
+    if (p.epilogue == LSSVC_EPI_X_MUL_RSQRT) conv_epilogue_gdn_impl<MF, RPW, LSSVC_EPI_X_MUL_RSQRT>(p, acc, pix, m0, lg);      // (wave-uniform)
+    else if (p.epilogue == LSSVC_EPI_X_MUL_SQRT) conv_epilogue_gdn_impl<MF, RPW, LSSVC_EPI_X_MUL_SQRT>(p, acc, pix, m0, lg);
+    else conv_epilogue_gdn_impl<MF, RPW, -1>(p, acc, pix, m0, lg);
+}
+
 template <int MF, int RPW, bool GDN = true, typename PIXF>
 __device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], const PIXF &pixf,
                                                    int m0, int lg, bool interior = false) {
@@ -222,6 +290,12 @@ __device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[
     if (p.fast_epi) {
         conv_epilogue_fast_f<MF, RPW, false>(p, acc, pixf, m0, lg, 1.0f, interior);
         return;
+    }
+    if constexpr (GDN) {
+        if (p.gdn_fast) {
+            conv_epilogue_gdn<MF, RPW>(p, acc, pix, m0, lg);
+            return;
+        }
     }
     const int cps = p.Cout >> 2;  // channels after pixel shuffle
     float4 bb[MF];

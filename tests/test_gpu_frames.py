@@ -148,9 +148,13 @@ def _gpu_gop_against_oracle(n, H, W, seed, gain, want_kernels=(), scale=2.0, bl=
 
 
 TIE_STATS = {}             # precision -> [symbols compared, symbols that differ from the oracle's]
-MAX_EVENTS_PER_PLANE = 2   # independent tie events (helpers.tie_clusters) per latent plane of a frame (3 k - 150 k symbols each at these sizes)
-MAX_FLIPS_PER_PLANE = 16   # differing symbols per plane, a cluster's followers included; every one must be off by exactly one
-FLIP_BITS = 40.0           # bound on what ONE flipped symbol moves a frame's bit count (likelihoods are floored at 1e-9 = 29.9 bits)
+# The tie allowance (round 6): TWICE what the reference does to itself between two runs on other thread counts, read from
+# tests/golden/x2_1080p_gop32_ref_t2.npz (helpers.tie_allowance / reference_self_disagreement; tests/test_gpu_golden_full.py says how it
+# was made): 2 independent tie events (helpers.tie_clusters) and 22 differing symbols per latent plane, each off by exactly one, and
+# 33.4 bits of a layer's count per differing symbol. Rounds 3-5 used numbers this file had chosen (2 / 16 / 40).
+def _allowance():
+    from helpers import tie_allowance
+    return tie_allowance()
 
 
 def _gpu_gop_symbol_aware(n, H, W, seed, gain, scale=2.0, bl=None):
@@ -160,7 +164,7 @@ def _gpu_gop_symbol_aware(n, H, W, seed, gain, scale=2.0, bl=None):
     section 9); at 256x384 pixels one such symbol is 1.9e-4 bpp, beyond the 1e-5 bar by construction, and from then on a
     plain closed loop drifts away from the oracle's. So per frame:
       ENCODER pass (public API, estimate mode) from a DPB aligned with the oracle's: every symbol against the oracle's --
-          at most MAX_EVENTS_PER_PLANE independent tie events per plane (spatial clusters), each difference by exactly one; bits inside 1e-5 bpp + FLIP_BITS per
+          at most the derived number of independent tie events per plane (spatial clusters), each difference by exactly one; bits inside 1e-5 bpp + the derived allowance per
           flipped symbol (no flip: the plain bar); PSNR inside 1e-4 dB when nothing flipped.
       DECODER pass (decoder role of the same codec functions on the ORACLE's symbols): PSNR of both layers inside 1e-4 dB,
           always; its outputs are the next frame's DPB.
@@ -169,6 +173,7 @@ def _gpu_gop_symbol_aware(n, H, W, seed, gain, scale=2.0, bl=None):
     from lssvc_amd.synth import synth_state_dict
     from lssvc_amd.preprocess import psnr
     from helpers import decode_from_symbols, tie_clusters
+    al = _allowance()
     clip, x_bl, rows = _oracle_gop(n, H, W, seed, gain, scale, bl)
     h, w = x_bl.shape[2:]
     inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", seed, gain)).to(DEV).eval()
@@ -199,12 +204,12 @@ def _gpu_gop_symbol_aware(n, H, W, seed, gain, scale=2.0, bl=None):
             assert got.shape == want.shape, (key, got.shape, want.shape)
             d = got.astype(np.int32) - want.astype(np.int32)
             nz, mx, events = tie_clusters(d, key, H, W, h, w)
-            assert nz <= MAX_FLIPS_PER_PLANE and mx <= 1 and events <= MAX_EVENTS_PER_PLANE, (t, key, nz, mx, events)
+            assert nz <= al["max_flips"] and mx <= al["max_abs_diff"] and events <= al["max_events"], (t, key, nz, mx, events)
             flips[key[:2]] += nz
             stats[0] += d.size
             stats[1] += nz
-        assert abs(g["bit_bl"] - o_bl) <= 1e-5 * h * w + FLIP_BITS * flips["bl"], (t, g["bit_bl"], o_bl, flips)
-        assert abs(g["bit_el"] - o_el) <= 1e-5 * H * W + FLIP_BITS * flips["el"], (t, g["bit_el"], o_el, flips)
+        assert abs(g["bit_bl"] - o_bl) <= 1e-5 * h * w + al["flip_bits"] * flips["bl"], (t, g["bit_bl"], o_bl, flips)
+        assert abs(g["bit_el"] - o_el) <= 1e-5 * H * W + al["flip_bits"] * flips["el"], (t, g["bit_el"], o_el, flips)
         if flips["bl"] == 0:
             assert abs(psnr(xb, enc["ref_frame_bl"].cpu().clamp(0, 1)) - o_pbl) <= 1e-4, t
             if flips["el"] == 0:

@@ -20,10 +20,11 @@ saw exactly that). One flipped symbol changes the reconstruction by ~2e-3 in a 1
 on the closed loop drifts locally, although bits and PSNR stay inside the bars. So every frame is checked twice:
 
   ENCODER pass (the public estimate-mode API, from a DPB that is aligned with the reference's): PSNR at the bar; every symbol
-      against the reference's -- differences must be off by exactly one and rare as EVENTS (<= MAX_EVENTS spatial clusters per
-      latent plane of 0.2-1.6 M symbols: a tie in the 4-step spatial prior can take near-tie neighbours with it), i.e. ties,
-      not errors; bits at 1e-5 bpp, plus FLIP_BITS per symbol that fell the other way (the I-frame of
-      x2_2160p_ipp has two such BL symbols in the f32 mode: 38 bits = 1.8e-5 bpp of its 2.09 M pixels).
+      against the reference's -- differences must be off by exactly one and rare as EVENTS (spatial clusters per latent plane
+      of 0.2-1.6 M symbols: a tie in the 4-step spatial prior can take near-tie neighbours with it), i.e. ties, not errors; bits
+      at 1e-5 bpp, plus an allowance per symbol that fell the other way (the I-frame of x2_2160p_ipp has two such BL symbols in
+      the f32 mode: 38 bits = 1.8e-5 bpp of its 2.09 M pixels). How many events, symbols and bits: TWICE what the reference does
+      to itself between two runs on other thread counts (helpers.tie_allowance; the comment below the imports).
   DECODER pass (the decoder role of the same codec functions, fed the REFERENCE's symbols): every tensor the model hands
       back (reconstructions, features, mv_hat, warp_frame) against the reference's samples and whole-tensor sums, with no
       rounding in the way. Its outputs are the DPB of the next frame, which keeps the loop aligned with the reference.
@@ -32,15 +33,18 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_full_case, replay_full, full_sample, decode_from_symbols, tie_clusters
+from helpers import load_full_case, replay_full, full_sample, decode_from_symbols, tie_clusters, tie_allowance, reference_self_disagreement
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-MAX_EVENTS = 4         # independent tie events per latent plane (0.2-1.6 M symbols each): spatial clusters of differing symbols
-#                        (helpers.tie_clusters); the expectation from the fp32 noise floor is ~0-1 per plane
-MAX_FLIPS = 48         # differing symbols per plane, clusters' followers included (seen: 9 in one frame of the 32-frame case)
-FLIP_BITS = 40.0       # what ONE symbol on the other side of a rounding tie may move a layer's bit count (likelihoods are floored at 1e-9 = 29.9 bits);
-#                        same rule as tests/test_gpu_frames.py::_gpu_gop_symbol_aware: with no flip the plain 1e-5 bpp bar
+# THE TIE ALLOWANCE IS DERIVED, NOT CHOSEN (round 6): tests/golden/x2_1080p_gop32_ref_t2.npz is the REFERENCE run a
+# second time on this GOP with 8 threads instead of 6, and helpers.reference_self_disagreement() reads from it what the reference does
+# to itself: symbols off by exactly one, at most 11 per latent plane in ONE spatial cluster, at most 16.7 bits of a layer's count per
+# differing symbol, worst frame 4.30e-5 bpp. helpers.tie_allowance() is TWICE that, per plane, scaled with the plane's size:
+#   max_flips   differing symbols per plane, clusters' followers included      (2 x 11 = 22 at 1080p; rounds 4-5 had CHOSEN 48)
+#   max_events  independent tie events per plane (helpers.tie_clusters)         (2 x 1 = 2; chosen: 4)
+#   flip_bits   what one such symbol may move a layer's bit count beyond 1e-5 bpp (2 x 16.7 = 33.4; chosen: 40)
+# With no symbol off the reference's the plain bar holds: 1e-5 bpp, 1e-4 dB.
 
 
 @pytest.fixture(params=["f16x3", "f32"])
@@ -111,12 +115,15 @@ def test_full_size_frames_match_reference(case, precision, request):
         nflip = {k: "%d in %d event(s)" % (v[0], v[2]) for k, v in flips.items() if v[0]}
         print("%s %s frame %d: d bpp (%.2e, %.2e), encoder d PSNR (%.1e, %.1e), flipped symbols %s, inputs bit-equal %s" % (
             case, precision, t, d_bpp[0], d_bpp[1], p_enc[0] - want_psnr[0], p_enc[1] - want_psnr[1], nflip or "none", exact), flush=True)
+        flip_bits = 0.0
         for key, (n, mx, events) in flips.items():
-            assert n <= MAX_FLIPS and mx <= 1 and events <= MAX_EVENTS, (t, key, n, mx, events)
+            al = tie_allowance(z["f%d_sym_%s" % (t, key)].size, key)
+            flip_bits = al["flip_bits"]
+            assert n <= al["max_flips"] and mx <= al["max_abs_diff"] and events <= al["max_events"], (t, key, n, mx, events, al["max_flips"], al["max_events"])
         n_bl = sum(v[0] for k, v in flips.items() if k.startswith("bl"))
         n_el = sum(v[0] for k, v in flips.items() if k.startswith("el"))
-        assert abs(r["bit_bl"] - bits[0]) <= 1e-5 * m["h"] * m["w"] + FLIP_BITS * n_bl, (t, r["bit_bl"], bits[0], n_bl)
-        assert abs(r["bit_el"] - bits[1]) <= 1e-5 * m["H"] * m["W"] + FLIP_BITS * n_el, (t, r["bit_el"], bits[1], n_el)
+        assert abs(r["bit_bl"] - bits[0]) <= 1e-5 * m["h"] * m["w"] + flip_bits * n_bl, (t, r["bit_bl"], bits[0], n_bl)
+        assert abs(r["bit_el"] - bits[1]) <= 1e-5 * m["H"] * m["W"] + flip_bits * n_el, (t, r["bit_el"], bits[1], n_el)
         assert abs(p_enc[0] - want_psnr[0]) <= 1e-4 and abs(p_enc[1] - want_psnr[1]) <= 1e-4, (t, p_enc, want_psnr)
         del r, enc
         # ---------------- decoder pass on the reference's symbols: every tensor, tight, and the next frame's DPB
@@ -162,9 +169,12 @@ def test_free_running_gop32_against_reference(request):
     the default precision, against the reference's per-frame bits and PSNR (tests/golden/x2_1080p_gop32.npz). Up to the first frame
     in which a symbol falls on the other side of a tie the plain bars hold (1e-5 bpp, 1e-4 dB). From there on the loop is a
     slightly different, equally valid closed loop: the flipped symbol changes the reconstruction in its neighbourhood and the
-    difference feeds forward through the DPB, so later frames are RECORDED (gpurun_out/free_running_gop32.json, printed) and held
-    to a drift bar two orders of magnitude above the per-frame bar but far below anything visible in an RD point: 1e-3 bpp and
-    1e-2 dB per frame, and 2e-4 bpp / 2e-3 dB on the GOP average."""
+    difference feeds forward through the DPB, so later frames are RECORDED (gpurun_out/free_running_gop32.json, printed) and held to
+    TWICE WHAT THE REFERENCE DOES TO ITSELF on this GOP (round 6: tests/golden/x2_1080p_gop32_ref_t2.npz, the reference on 8 threads
+    against the reference on 6, free-running like this test; helpers.reference_self_disagreement): per frame 2 x 4.30e-5 bpp and 2 x 11
+    differing symbols, over the GOP 2 x 46 differing symbols in 2 x 10 frames and 2 x the reference's GOP-average |d bpp|; PSNR at the
+    plain 1e-4 dB bar on every frame (the reference moves its own by 9.5e-7 dB). Rounds 4-5 held these frames to bars this test had
+    chosen for itself (1e-3 bpp, 1e-2 dB)."""
     import json
     import os
     from lssvc_amd import IntraSS, LSSVC_extend, hip_ops
@@ -183,6 +193,7 @@ def test_free_running_gop32_against_reference(request):
         inputs, _ = full_case_inputs(case)
         hr = (m["H"], m["W"])
         dpb, rows, first_flip = None, [], None
+        yard = reference_self_disagreement(case)
         for t, (x_bl, x_el) in enumerate(inputs):
             x_bl, x_el = x_bl.to(DEV), x_el.to(DEV)
             net = inet if t == 0 else pnet
@@ -210,9 +221,10 @@ def test_free_running_gop32_against_reference(request):
             print("free-running frame %2d: d bpp (%+.2e, %+.2e)  d PSNR (%+.1e, %+.1e) dB  symbols differing %d" % (
                 t, row["d_bpp_bl"], row["d_bpp_el"], row["d_psnr_bl"], row["d_psnr_el"], differing), flush=True)
             aligned = first_flip is None
-            bpp_bar, db_bar = (1e-5, 1e-4) if aligned else (1e-3, 1e-2)
-            assert abs(row["d_bpp_bl"]) <= bpp_bar and abs(row["d_bpp_el"]) <= bpp_bar, (row, first_flip)
-            assert abs(row["d_psnr_bl"]) <= db_bar and abs(row["d_psnr_el"]) <= db_bar, (row, first_flip)
+            bpp_bar = 1e-5 if aligned else 2 * yard["max_d_bpp"]
+            assert abs(row["d_bpp_bl"]) <= bpp_bar and abs(row["d_bpp_el"]) <= bpp_bar, (row, first_flip, bpp_bar)
+            assert abs(row["d_psnr_bl"]) <= 1e-4 and abs(row["d_psnr_el"]) <= 1e-4, (row, first_flip)
+            assert differing <= 2 * yard["max_symbols_per_plane"], (row, yard["max_symbols_per_plane"])
         n = len(rows)
         avg = {k: sum(r_[k] for r_ in rows) / n for k in ("d_bpp_bl", "d_bpp_el", "d_psnr_bl", "d_psnr_el")}
         worst = {k: max(abs(r_[k]) for r_ in rows) for k in avg}
@@ -220,7 +232,15 @@ def test_free_running_gop32_against_reference(request):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "free_running_gop32.json"), "w") as f:
-            json.dump({"case": case, "precision": "f16x3", "first_frame_with_a_differing_symbol": first_flip, "gop_average": avg, "worst_frame_abs": worst, "frames": rows}, f, indent=1)
-        assert abs(avg["d_bpp_bl"]) <= 2e-4 and abs(avg["d_bpp_el"]) <= 2e-4 and abs(avg["d_psnr_bl"]) <= 2e-3 and abs(avg["d_psnr_el"]) <= 2e-3, avg
+            json.dump({"case": case, "precision": "f16x3", "first_frame_with_a_differing_symbol": first_flip, "gop_average": avg, "worst_frame_abs": worst, "frames": rows,
+                       "reference_against_itself": {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in yard.items() if k != "plane_symbols"}}, f, indent=1)
+        n_frames = sum(1 for r_ in rows if r_["symbols_differing_from_reference"])
+        n_syms = sum(r_["symbols_differing_from_reference"] for r_ in rows)
+        print("against the reference's disagreement with itself (8 vs 6 threads): frames with a differing symbol %d (reference %d), differing symbols %d (%d), "
+              "worst frame %.2e bpp (%.2e), GOP average %.2e bpp (%.2e)" % (n_frames, yard["frames_with_differing_symbols"], n_syms, yard["symbols"],
+                                                                          max(worst["d_bpp_bl"], worst["d_bpp_el"]), yard["max_d_bpp"], max(abs(avg["d_bpp_bl"]), abs(avg["d_bpp_el"])), yard["gop_avg_d_bpp"]))
+        assert n_frames <= 2 * yard["frames_with_differing_symbols"] and n_syms <= 2 * yard["symbols"], (n_frames, n_syms, yard)
+        assert abs(avg["d_bpp_bl"]) <= 2 * yard["gop_avg_d_bpp"] and abs(avg["d_bpp_el"]) <= 2 * yard["gop_avg_d_bpp"], (avg, yard["gop_avg_d_bpp"])
+        assert abs(avg["d_psnr_bl"]) <= 1e-4 and abs(avg["d_psnr_el"]) <= 1e-4, avg
     finally:
         hip_ops.set_conv_precision(old)

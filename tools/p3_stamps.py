@@ -21,6 +21,9 @@ def main():
     g = torch.Generator().manual_seed(0)
     shapes = (("64->64 @1152x1920", 64, 64, 1152, 1920), ("128->64 @576x960", 128, 64, 576, 960), ("48->48 @1152x1920", 48, 48, 1152, 1920),
               ("96->48 @1152x1920", 96, 48, 1152, 1920))
+    stride = int(os.environ.get("P3_STRIDE", "1"))            # 2: the stride-2 form (round 6; MF = 4 shapes only)
+    if stride == 2:
+        shapes = (("s2 48->64 in 1152x1920", 48, 64, 1152, 1920), ("s2 64->64 in 576x960", 64, 64, 576, 960), ("s2 128->128 in 288x480", 128, 128, 288, 480))
     for name, cin, cout, H, W in shapes:
         w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
         b = torch.randn(cout, generator=g)
@@ -30,7 +33,7 @@ def main():
         if split:
             x = ops.presplit(x)
         stamps = torch.zeros(2 * 256 * 4 * 8, dtype=torch.int64, device=dev)      # consumer records, then producer records
-        out = ops.T.empty(H, W, cout, dev)
+        out = ops.T.empty(H // stride, W // stride, cout, dev)
         import ctypes as C
         w_dev, b_dev, co, m_pad, KH, KW = Wt.conv("c", [cin], False)
         w16 = Wt.conv_f16x3("c", [cin], False)
@@ -38,7 +41,7 @@ def main():
         d.inp[0] = x.v
         d.n_in = 1
         d.weight, d.bias = w_dev.data_ptr(), b_dev.data_ptr()
-        d.KH, d.KW, d.stride, d.pad_t, d.pad_l = 3, 3, 1, 1, 1
+        d.KH, d.KW, d.stride, d.pad_t, d.pad_l = 3, 3, stride, 1, 1
         d.Cout, d.M_pad = co, m_pad
         d.in_act, d.in_slope, d.epilogue = 0, 0.01, 0
         d.gdn_x = _lib.View(stamps.data_ptr(), 1, 1, 1, 1)
