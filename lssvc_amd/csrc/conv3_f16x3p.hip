@@ -121,19 +121,19 @@ int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
 #undef LSSVC_P3_CASE
     }
     if (p3_narrow_wanted(p)) {
-        const int pf = option_get(OPT_P3_PF2);
-        snprintf(kernel_name, 96, "conv3n_f16x3p_kernel<%s, %s>%s", inact ? "true" : "false", p.fast_epi ? "fast" : "flat", pf == 2 ? " pair" : pf == 1 ? " pf2" : "");
+        const int pf = option_get(OPT_P3_PF2) ? 1 : 0;      // register prefetch: +3 ... +8 % on these (profiles/r06_narrow_ab.txt); pair loads are not built for them (slower)
+        snprintf(kernel_name, 96, "conv3n_f16x3p_kernel<%s, %s>%s", inact ? "true" : "false", p.fast_epi ? "fast" : "flat", pf == 1 ? " pf2" : "");
         return launch_p3_narrow(p, inact, !p.fast_epi, pf, st);
     }
     if (P3Small c; !p.in_split && p3_pick_tiling(p, c) && c.rpw != LSSVC_P3_RPW) {
         // p3_small: 1 = the register prefetch from 8 phases on (+3 ... +8 %; below that it is neutral: profiles/r06_small_map_ab.txt), 2 = always,
-        // 3 = never, 4 = pair loads
+        // 3 = never
         const int sm = option_get(OPT_P3_SMALL);
-        const int pf = sm == 4 ? 2 : (sm == 2 || (sm == 1 && p.n_chunks16 >= 8)) ? 1 : 0;
+        const int pf = (sm == 2 || (sm == 1 && p.n_chunks16 >= 8)) ? 1 : 0;
         snprintf(kernel_name, 96, "conv3r_f16x3p_kernel<%d, %s, rpw %d%s>", c.mf, inact ? "true" : "false", c.rpw, pf == 2 ? ", pair" : pf == 1 ? ", pf2" : "");
         return launch_p3_small(p, c.mf, c.rpw, inact, pf, st);
     }
-    if (option_get(OPT_P3_BIG_PAIR) && mf >= 2 && !(p.debug & 256)) {      // experiment: the 24x16 tiling with pair loads
+    if (option_get(OPT_P3_BIG_PAIR) && mf == 4 && !inact && !(p.debug & 256)) {      // experiment: the 24x16 tiling with pair loads
         snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s> pair", mf, inact ? "true" : "false");
         return launch_p3_big_pair(p, mf, inact, st);
     }

@@ -10,7 +10,6 @@ namespace lssvc {
 int launch_p3_small(const ConvP &p, int mf, int rpw, bool inact, int pf, hipStream_t st) {
 #define LSSVC_P3R_CASE(m, r)                                                                                              \
     if (mf == m && rpw == r) {                                                                                            \
-        if (pf == 2) return inact ? launch_p3r<m, true, 1, r, 2, false, false>(p, st) : launch_p3r<m, false, 1, r, 2, false, false>(p, st);   \
         if (pf == 1) return inact ? launch_p3r<m, true, 1, r, 1, false, false>(p, st) : launch_p3r<m, false, 1, r, 1, false, false>(p, st);   \
         return inact ? launch_p3r<m, true, 1, r, 0, false, false>(p, st) : launch_p3r<m, false, 1, r, 0, false, false>(p, st);           \
     }

@@ -1,5 +1,5 @@
 // conv3_f16x3p_r2.hip -- round-6 instantiations of the persistent warp-specialised 3x3 kernel, second translation unit (see
-// conv3_f16x3p_r.hip): the narrow heads, stride 2 with register prefetch / pair loads, and the 24x16 tiling with pair loads.
+// conv3_f16x3p_r.hip): the narrow heads, stride 2 with register prefetch / pair loads, and (one instantiation, an experiment) the 24x16 tiling with pair loads.
 #include "conv3_f16x3p_kernel.h"
 
 namespace lssvc {
@@ -10,7 +10,7 @@ int launch_p3_narrow(const ConvP &p, bool inact, bool flat, int pf, hipStream_t 
         if (flat) return inact ? launch_p3r<1, true, 1, 4, f, true, true>(p, st) : launch_p3r<1, false, 1, 4, f, true, true>(p, st);        \
         return inact ? launch_p3r<1, true, 1, 4, f, false, true>(p, st) : launch_p3r<1, false, 1, 4, f, false, true>(p, st);                \
     }
-    LSSVC_P3N_CASE(2) LSSVC_P3N_CASE(1) LSSVC_P3N_CASE(0)
+    LSSVC_P3N_CASE(1) LSSVC_P3N_CASE(0)
 #undef LSSVC_P3N_CASE
     return fail("conv2d(f16x3p narrow): prefetch mode %d", pf);
 }
@@ -23,12 +23,11 @@ int launch_p3s2_pf(const ConvP &p, int mf, bool inact, int pf, hipStream_t st) {
     return fail("conv2d(f16x3p, stride 2, prefetch %d): no kernel for MF=%d", pf, mf);
 }
 
+// (experiment, `p3_big_pair`: the 24x16 tiling with pair loads -- 2 ... 13 % SLOWER on every shape of the bench, profiles/r06_pair_loads_ab.txt;
+// only the dominant instantiation is kept so that the A/B can be re-run)
 int launch_p3_big_pair(const ConvP &p, int mf, bool inact, hipStream_t st) {
-#define LSSVC_P3B_CASE(m) \
-    if (mf == m) return inact ? launch_p3r<m, true, 1, 0, 2, false, false>(p, st) : launch_p3r<m, false, 1, 0, 2, false, false>(p, st);
-    LSSVC_P3B_CASE(4) LSSVC_P3B_CASE(3) LSSVC_P3B_CASE(2)
-#undef LSSVC_P3B_CASE
-    return fail("conv2d(f16x3p, pair loads): no kernel for MF=%d", mf);
+    if (mf == 4 && !inact) return launch_p3r<4, false, 1, 0, 2, false, false>(p, st);
+    return fail("conv2d(f16x3p, pair loads): only the MF = 4 instantiation without input activation is built");
 }
 
 }  // namespace lssvc

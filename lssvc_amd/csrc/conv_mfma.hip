@@ -30,7 +30,7 @@ static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16
                                               "LSSVC_P3_SMALL", "LSSVC_P3_NARROW", "LSSVC_P3_PF2", "LSSVC_P3_FORCE", "LSSVC_GDN_FAST_OPT", "LSSVC_P3_BIG_PAIR"};
 static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks", "dwpre_deep", "p3_blocks", "p3_stage", "f16x3_persist_s2",
                                                "p3_small", "p3_narrow", "p3_pf2", "p3_force", "gdn_fast", "p3_big_pair"};
-static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1, 1, 1, 2, 0, 1, 0};      // p3_stage: off (measured slower); kept for the record and its test
+static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, 1, 0};      // p3_stage: off (measured slower); kept for the record and its test
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
         const char *e = getenv(kOptEnv[which]);

@@ -137,6 +137,7 @@ struct Plan {
     std::vector<hipEvent_t> events;
     hipGraphExec_t exec = nullptr;
     int runs = 0;
+    std::string audit_failed;     // non-empty: the first frame's range audit failed; every later run of this plan returns the same error
     int bits_region = -1;
     // fp16 range audit of the FIRST frame a plan codes with the engine's checkpoint (replay): one float per audited f16x3 launch
     float *audit_dev = nullptr;
@@ -683,6 +684,7 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
         LSSVC_HIP(hipMemcpyAsync(p.regions[i].ptr, kv.second, p.regions[i].nbytes, hipMemcpyDefault, st));
     }
     LSSVC_CHECK(!p.has_host_steps, "engine: a '%s' plan runs through the encode / decode entry points", p.kind.c_str());
+    LSSVC_CHECK(p.audit_failed.empty(), "%s", p.audit_failed.c_str());
     const bool audit = p.runs == 0 && !std::getenv("LSSVC_ENGINE_NO_AUDIT");
     if (p.runs == 0 || std::getenv("LSSVC_ENGINE_EAGER")) {
         if (int e = replay(p, st, audit)) return e;
@@ -703,6 +705,13 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
         }
         LSSVC_HIP(hipGraphLaunch(p.exec, st));
     }
+    // the verdict comes BEFORE the run is counted and before anything is handed to the caller: a failed audit leaves runs == 0 and is
+    // sticky, so a caller that carries on after the error gets the same error again, never an un-audited captured replay
+    if (audit)
+        if (int e = audit_verdict(p, st)) {
+            p.audit_failed = err_buf();
+            return e;
+        }
     ++p.runs;
     for (auto &kv : outs) {
         if (!kv.second) continue;                        // the caller does not want this one
@@ -712,7 +721,7 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
     }
     LSSVC_HIP(hipMemcpyAsync(slots16, p.regions[p.bits_region].ptr, 16 * sizeof(double), hipMemcpyDeviceToHost, st));
     LSSVC_HIP(hipStreamSynchronize(st));                 // the bit counts are host values, as in the reference (.item())
-    return audit ? audit_verdict(p, st) : 0;
+    return 0;
 }
 
 // Run the encoder or decoder half of a frame: inputs in, eager replay with its host steps, outputs out; the strings the
@@ -720,6 +729,7 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
 int run_stream_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &ins,
                     const std::vector<std::pair<const char *, void *>> &outs, hipStream_t st) {
     LSSVC_CHECK(p.has_host_steps, "engine: a '%s' plan has no coder steps", p.kind.c_str());
+    LSSVC_CHECK(p.audit_failed.empty(), "%s", p.audit_failed.c_str());
     for (auto &kv : ins) {
         const int i = p.region_index(kv.first, REGION_INPUT);
         if (i < 0) {
@@ -735,7 +745,10 @@ int run_stream_plan(Plan &p, const std::vector<std::pair<const char *, const voi
     const bool audit = p.runs == 0 && !std::getenv("LSSVC_ENGINE_NO_AUDIT");
     if (int e = replay(p, st, audit)) return e;
     if (audit)
-        if (int e = audit_verdict(p, st)) return e;
+        if (int e = audit_verdict(p, st)) {
+            p.audit_failed = err_buf();
+            return e;
+        }
     ++p.runs;
     for (auto &kv : outs) {
         if (!kv.second) continue;

@@ -113,6 +113,8 @@ def test_persistent_3x3_matches_fp64(hip, cins, cout, H, W, in_act, act, residua
     got32, k32 = _run(hip, "f32", launch)
     inact = "true" if in_act else "false"
     want = "conv3_f16x3p_kernel<%d, %s>" % (mf, inact)
+    if mf == 1:
+        want = "conv3n_f16x3p_kernel<%s, fast> pf2" % inact           # round 6: <= 16 output channels take the narrow-head instantiation
     assert k16 == want, k16                                           # really a persistent kernel
     assert k32.startswith("conv_mfma_kernel"), k32
     assert got16.shape == ref.shape
@@ -316,8 +318,8 @@ TILED_CASES = [
     ([64], 32, 7, 260, 520, "relu", False, "conv_f16x3_kernel<2, 4, 7, 1>"),      # conv3 (2.4 % of a P-frame each)
     ([32], 16, 7, 384, 400, "relu", False, "conv_f16x3_kernel<1, 4, 7, 1>"),      # conv4
     ([16], 2, 7, 384, 400, None, True, "conv_f16x3_kernel<1, 4, 7, 1>"),          # conv5 + flow residual
-    ([64], 2, 3, 384, 400, None, False, "conv_f16x3_kernel<1, 4, 3, 1>"),         # mv_resampler.recon_conv / weight maps
-    ([48], 3, 3, 384, 400, None, False, "conv_f16x3_kernel<1, 4, 3, 1>"),         # recon_conv
+    ([64], 2, 3, 384, 400, None, False, "conv3n_f16x3p_kernel<false, flat> pf2"),  # mv_resampler.recon_conv / weight maps (round 6: the narrow-head persistent kernel,
+    ([48], 3, 3, 384, 400, None, False, "conv3n_f16x3p_kernel<false, flat> pf2"),  # recon_conv                           test_narrow_heads_* hold it to the tiled kernel bit for bit)
 ]
 
 
@@ -463,3 +465,160 @@ def test_persistent_7x7_hand_off_is_race_free(hip):
         hip.set_conv_precision("f32")
         _set("f16x3_persist7", old)
     assert bad == 0, "%d of 30 launches differ" % bad
+
+
+# ---- round 6: the small-tile, narrow-head and prefetching instantiations of the persistent 3x3 kernel, the lean GDN epilogue ----------
+def _opts(**kw):
+    """Set library options for the duration of a with-block."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: _get(k) for k in kw}
+        try:
+            for k, v in kw.items():
+                _set(k, v)
+            yield
+        finally:
+            for k, v in old.items():
+                _set(k, v)
+    return cm()
+
+
+def _conv_case(hip, cins, cout, H, W, stride=1, seed=0, **kw):
+    g = torch.Generator().manual_seed(seed + hash((tuple(cins), cout, H, W)) & 0xFFFF)
+    xs = [torch.randn(1, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    shuffle = kw.pop("pixel_shuffle", False)
+    r = torch.randn(1, cout, Ho, Wo, generator=g) if kw.pop("residual", False) else None
+    name = "s.0" if shuffle else "c"
+    Wt = _W({name + ".weight": w, name + ".bias": b})
+
+    def launch():
+        ins = [nhwc(hip, x) for x in xs]
+        k2 = dict(kw, residual=nhwc(hip, r) if r is not None else None)
+        return back(hip.subpel(Wt, "s", ins, **k2) if shuffle else hip.conv(Wt, "c", ins, stride=stride, **k2))
+    return launch
+
+
+SMALL_MAP_CASES = [
+    # cins, cout, H, W, kwargs: the maps of the quarter-resolution / prior / hyper networks at 1080p (< 256 tiles of 24x16) and odd sizes
+    ([64], 64, 144, 240, {}),
+    ([64], 64, 141, 233, {"in_act": "lrelu", "in_slope": 0.1, "act": "lrelu", "residual": True}),      # partial tiles on both edges
+    ([128], 128, 72, 120, {"act": "lrelu"}),                                                       # 8 phases: the register prefetch
+    ([96], 96, 36, 60, {}),                                                                        # MF = 3
+    ([64, 64], 128, 70, 118, {"in_act": "lrelu", "in_slope": 0.1}),                                 # two-input concat
+    ([64], 256, 72, 120, {"pixel_shuffle": True}),                                                 # subpel store, 4 M tiles
+    ([192], 160, 36, 60, {"act": "relu"}),                                                         # ragged M (10 fragments)
+]
+
+
+@pytest.mark.parametrize("cins,cout,H,W,kw", SMALL_MAP_CASES)
+def test_small_tilings_are_bit_identical_to_tiled(hip, cins, cout, H, W, kw):
+    """Round 6: 3x3 convs on maps the 24x16 tiling cannot spread over 256 CUs run on the persistent kernel's
+    small-tile instantiations (16x16 / 8x16 / 4x16 pixels, MF or MF / 2 channel fragments per tile; conv3_f16x3p.hip: p3_pick_tiling).
+    Same MFMA sequence per accumulator, same epilogue: every forced (MF, rows per wave) pair, with and without the register
+    prefetch, and the dispatcher's own choice must equal the tiled kernel bit for bit."""
+    launch = _conv_case(hip, cins, cout, H, W, **dict(kw))
+    frags = (cout + 15) // 16
+    with _opts(p3_small=0, p3_force=0):
+        tiled, k0 = _run(hip, "f16x3", launch)
+    assert k0.startswith("conv_f16x3_kernel"), k0
+    with _opts(p3_small=1, p3_force=0):
+        auto, ka = _run(hip, "f16x3", launch)
+    assert ka.startswith("conv3r_f16x3p_kernel<"), ka
+    assert torch.equal(auto, tiled), ka
+    seen = set()
+    for mf in (4, 3, 2, 1):
+        if mf > frags:
+            continue
+        for rpw in (4, 2, 1):
+            for sm in (2, 3):                                    # register prefetch always / never
+                with _opts(p3_small=sm, p3_force=mf * 16 + rpw):
+                    got, k = _run(hip, "f16x3", launch)
+                assert k.startswith("conv3r_f16x3p_kernel<%d," % mf) and ("rpw %d" % rpw) in k and (("pf2" in k) == (sm == 2)), k
+                assert torch.equal(got, tiled), k
+                seen.add(k)
+    assert len(seen) >= 6
+
+
+NARROW_CASES = [
+    # cins, cout, H, W, kwargs, epilogue
+    ([64], 2, 384, 400, {}, "flat"),                                         # mv_resampler.recon_conv / weight maps
+    ([64], 2, 371, 393, {"residual": True}, "flat"),                         # a 2-channel residual (scalar loads), partial tiles
+    ([48], 3, 384, 400, {"in_act": "lrelu", "in_slope": 0.1}, "flat"),       # recon_conv form with an input activation
+    ([64], 8, 300, 340, {"act": "lrelu"}, "fast"),
+    ([32, 32], 16, 300, 340, {"act": "relu", "residual": True}, "fast"),     # two inputs, 16 channels, float4 residual
+    ([16], 12, 290, 330, {}, "fast"),                                        # Cout % 4 == 0 but not a whole fragment
+]
+
+
+@pytest.mark.parametrize("cins,cout,H,W,kw,epi", NARROW_CASES)
+def test_narrow_heads_are_bit_identical_to_round5_kernels(hip, cins, cout, H, W, kw, epi):
+    """Round 6: 3x3 convs with at most 16 output channels -- flow heads, picture heads -- on the persistent kernel's
+    narrow instantiation (MF = 1, 16x16 tiles, two workgroups per CU, register prefetch; the tiled kernel's own epilogue when Cout % 4
+    != 0): equal, bit for bit, to what round 5 ran (the tiled kernel, or the 24x16 persistent one for Cout % 4 == 0), with and
+    without the prefetch, and twice in a row."""
+    launch = _conv_case(hip, cins, cout, H, W, **dict(kw))
+    inact = "true" if kw.get("in_act") else "false"
+    with _opts(p3_narrow=0):
+        old, k0 = _run(hip, "f16x3", launch)
+    assert k0.startswith("conv_f16x3_kernel<1,") or k0.startswith("conv3_f16x3p_kernel<1,"), k0
+    with _opts(p3_narrow=0, f16x3_persist=0):
+        tiled, kt = _run(hip, "f16x3", launch)
+    assert kt.startswith("conv_f16x3_kernel<1,"), kt
+    with _opts(p3_narrow=1, p3_pf2=1):
+        new, k1 = _run(hip, "f16x3", launch)
+        again, _ = _run(hip, "f16x3", launch)
+    assert k1 == "conv3n_f16x3p_kernel<%s, %s> pf2" % (inact, epi), k1
+    with _opts(p3_narrow=1, p3_pf2=0):
+        plain, k2 = _run(hip, "f16x3", launch)
+    assert k2 == "conv3n_f16x3p_kernel<%s, %s>" % (inact, epi), k2
+    assert torch.equal(new, old) and torch.equal(new, tiled) and torch.equal(new, again) and torch.equal(plain, old)
+
+
+@pytest.mark.parametrize("cins,cout,H,W,in_act,act,residual", P3S2_CASES)
+def test_stride2_register_prefetch_is_bit_identical(hip, cins, cout, H, W, in_act, act, residual):
+    """Round 6: the stride-2 persistent kernel with the producers' register prefetch (p3_pf2 = 1, the default), with
+    pair loads (2; measured slower, kept for the A/B) and as round 5 ran it (0): one arithmetic, three schedules."""
+    launch = _conv_case(hip, cins, cout, H, W, stride=2, in_act=in_act, in_slope=0.1, act=act, slope=0.01, residual=residual)
+    outs = {}
+    for pf in (0, 1, 2):
+        with _opts(p3_pf2=pf):
+            outs[pf], k = _run(hip, "f16x3", launch)
+        assert k.startswith("conv3s2_f16x3p_kernel<") and k.endswith({0: ">", 1: "pf2", 2: "pair"}[pf]), k
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("c,H,W", [(64, 60, 100), (96, 37, 53), (128, 48, 80), (192, 20, 31), (48, 64, 64)])
+@pytest.mark.parametrize("flavour,inverse", [("intra", False), ("intra", True), ("inter", False), ("inter", True)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_gdn_lean_epilogue_is_bit_identical(hip, c, H, W, flavour, inverse, residual):
+    """Round 6 (the part that paid): the GDN / IGDN 1x1 kernels' normalising epilogue as straight-line code
+    (conv_mfma_kernel.h: conv_epilogue_gdn -- the kind of normalisation a compile-time parameter, float4 accesses only) against the
+    general epilogue it replaces (option gdn_fast = 0): same operations in the same order, equal bit for bit, in both conv
+    precisions (the exact-fp32 kernel shares the routine)."""
+    from lssvc_amd.synth import _make
+    sd = {"g.beta": _make({"key": "g.beta", "shape": [c], "kind": "gdn_beta"}, 3, 1.0),
+          "g.gamma": _make({"key": "g.gamma", "shape": [c, c], "kind": "gdn_gamma"}, 3, 1.0),
+          "g.beta_reparam.pedestal": torch.tensor([2.0 ** -36]), "g.gamma_reparam.pedestal": torch.tensor([2.0 ** -36]),
+          "g.beta_reparam.lower_bound.bound": torch.tensor([(1e-6 + 2.0 ** -36) ** 0.5]),
+          "g.gamma_reparam.lower_bound.bound": torch.tensor([2.0 ** -18])}
+    Wt = _W(sd)
+    g = torch.Generator().manual_seed(c * H + W)
+    x = torch.randn(1, c, H, W, generator=g) * 2
+    r = torch.randn(1, c, H, W, generator=g) if residual else None
+
+    def launch():
+        return back(hip.gdn(Wt, "g", nhwc(hip, x), flavour, inverse=inverse, residual=nhwc(hip, r) if residual else None))
+
+    for mode in ("f16x3", "f32"):
+        with _opts(gdn_fast=0):
+            general, k0 = _run(hip, mode, launch)
+        with _opts(gdn_fast=1):
+            lean, k1 = _run(hip, mode, launch)
+        assert k0 == k1 and (("f16x3" in k0) == (mode == "f16x3")), (k0, k1)
+        assert torch.equal(general, lean), (mode, k0, (general - lean).abs().max().item())

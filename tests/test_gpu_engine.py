@@ -406,5 +406,14 @@ def test_the_engine_audits_the_fp16_range_of_a_checkpoint_it_was_not_compiled_wi
             else:
                 msg = lib.lssvc_last_error().decode()
                 assert rc != 0 and "outside what its fp16-split kernel can hold" in msg and "compile the plans from this one" in msg, (rc, msg)
+                # the failure is STICKY and nothing is handed out -- a caller that carries on gets the same error on every later
+                # call of the plan (round 5 counted the failed run, so the second call skipped the audit, captured the plan and returned 0)
+                for o in oi:
+                    o.fill_(-7.0)
+                for _ in range(3):
+                    rc2 = lib.lssvc_engine_iframe(eng, P(x_bl), P(x_el), bits, *[P(o) for o in oi], None)
+                    torch.cuda.synchronize()
+                    assert rc2 != 0 and "outside what its fp16-split kernel can hold" in lib.lssvc_last_error().decode(), rc2
+                    assert all(bool((o == -7.0).all()) for o in oi), "a failed audit must not write the caller's outputs"
         finally:
             lib.lssvc_engine_destroy(eng)

@@ -21,7 +21,7 @@ from lssvc_amd import hip_ops as ops  # noqa: E402
 from lssvc_amd._lib import lib, check  # noqa: E402
 from lssvc_amd.weights import WeightStore  # noqa: E402
 
-DEFAULTS = {"p3_small": 1, "p3_narrow": 1, "p3_pf2": 2, "p3_force": 0, "p3_big_pair": 0, "f16x3_persist": 1, "f16x3_persist_s2": 1, "gdn_fast": 1}
+DEFAULTS = {"p3_small": 1, "p3_narrow": 1, "p3_pf2": 1, "p3_force": 0, "p3_big_pair": 0, "f16x3_persist": 1, "f16x3_persist_s2": 1, "gdn_fast": 1}
 
 
 def set_opts(**kw):
@@ -82,7 +82,7 @@ def main():
                                      ([64], 8, 576, 960, {}), ([64], 2, 576, 960, {}), ([64], 2, 288, 480, {}), ([32, 32], 16, 1152, 1920, {"act": "lrelu"})):
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
-            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("tiled / p3 rpw 6", {"p3_narrow": 0}), ("conv3n", {"p3_pf2": 0}), ("conv3n pf2", {"p3_pf2": 1}), ("conv3n pair", {"p3_pf2": 2})], rounds, reps,
+            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("tiled / p3 rpw 6", {"p3_narrow": 0}), ("conv3n", {"p3_pf2": 0}), ("conv3n pf2", {"p3_pf2": 1})], rounds, reps,
                      2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
     elif what in ("small", "small_sweep", "mid", "mid_sweep"):
         mid = (([64], 64, 288, 480, {}), ([64], 64, 288, 480, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}), ([96], 96, 288, 480, {}), ([128], 128, 288, 480, {}),
@@ -95,7 +95,7 @@ def main():
         for cins, cout, H, W, kw in shapes:
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
-            arms = [("r5: tiled / 24x16", {"p3_small": 0}), ("auto", {}), ("auto, pf2 always", {"p3_small": 2}), ("auto, pf2 never", {"p3_small": 3}), ("auto, pair loads", {"p3_small": 4})]
+            arms = [("r5: tiled / 24x16", {"p3_small": 0}), ("auto", {}), ("auto, pf2 always", {"p3_small": 2}), ("auto, pf2 never", {"p3_small": 3})]
             if what.endswith("_sweep"):
                 for mf in (4, 3, 2, 1):
                     if mf > (cout + 15) // 16 or ((cout + 15) // 16) % mf:
@@ -112,9 +112,7 @@ def main():
             run_arms("3x3 s2 %s->%d in %dx%d" % (cins, cout, H, W), call, [("one register set", {"p3_pf2": 0}), ("register prefetch", {"p3_pf2": 1}), ("pair loads", {"p3_pf2": 2}), ("tiled", {"f16x3_persist_s2": 0})],
                      rounds, reps, 2.0 * (H // 2) * (W // 2) * cout * 9 * cin, 4e-6 * (H * W * cin + (H // 2) * (W // 2) * cout))
     elif what == "big":
-        for cins, cout, H, W, kw in (([64], 64, 1152, 1920, {}), ([64], 64, 576, 960, {}), ([64], 64, 576, 960, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}),
-                                     ([48], 48, 1152, 1920, {}), ([48, 48], 48, 1152, 1920, {}), ([128], 64, 576, 960, {}), ([128], 192, 576, 960, {}), ([96], 96, 288, 480, {}),
-                                     ([64], 64, 288, 480, {}), ([64, 16], 48, 1152, 1920, {})):
+        for cins, cout, H, W, kw in (([64], 64, 1152, 1920, {}), ([64], 64, 576, 960, {}), ([128], 64, 576, 960, {}), ([128], 192, 576, 960, {}), ([64], 64, 288, 480, {})):      # (the MF = 4, no-input-activation shapes: the one instantiation kept)
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
             run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("r5 schedule", {}), ("pair loads", {"p3_big_pair": 1})], rounds, reps,
