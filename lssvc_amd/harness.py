@@ -424,7 +424,8 @@ def main(argv=None):
         torch.cuda.set_device(device)
         dist.init_process_group(backend="nccl", device_id=torch.device(device))
         _CKPT.update(broadcast_state_dicts(list(args.i_frame_model_path) + list(args.model_path), dist, device))
-        results = run_sharded(jobs, lambda j: run_job(j, device=device), dist)
+        # a work queue, longest jobs first (round 6): frames x EL pixels is what a job costs
+        results = run_sharded(jobs, lambda j: run_job(j, device=device), dist, cost=lambda j: j["count"] * j["width"] * j["height"])
         rank = dist.get_rank()
         dist.barrier()
         dist.destroy_process_group()

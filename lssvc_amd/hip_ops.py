@@ -609,6 +609,14 @@ def copy(a, out):
     return out
 
 
+def clamp_(t, lo=0.0, hi=1.0):
+    """torch.Tensor.clamp_(lo, hi) on a densely stored T (test.py:249-250's clamp of the reconstructions), as a launch of the library
+    (lssvc_clamp_inplace): a frame plan that holds it can be recorded for the C engine, an ATen kernel cannot."""
+    assert t.ld == t.C, "clamp_: the view must be dense"
+    check(lib.lssvc_clamp_inplace(C.c_void_p(t.buf.data_ptr() + 4 * t.off), t.H * t.W * t.C, lo, hi, stream_ptr()))
+    return t
+
+
 def pad_crop(x, pad):
     """F.pad(x, (left, right, top, bottom), value=0) of an NHWC view, negative entries cropping: the reference's
     get_depadded_feature (IntraSS.py:124-135, LSSVC_net.py:271-282). Pure data movement (lssvc_pad_crop); all zeros in

@@ -515,10 +515,9 @@ class LSSVC_extend(_HostModel):
         coded whole, from the inputs ref_recon / ref_feature; bit slots 8..11; results -> self._stash[out_parity]."""
         src = self._stash[src_parity] if src_parity is not None else {"recon": t["ref_recon"], "feature": t["ref_feature"]}
         rec = src["recon"]
-        n = rec.H * rec.W * rec.C
         assert rec.ld == rec.C
-        ref = T.empty(rec.H, rec.W, rec.C, self.device)
-        torch.clamp(rec.buf.view(-1)[rec.off:rec.off + n], 0.0, 1.0, out=ref.buf.view(-1)[ref.off:ref.off + n])      # = test.py:249's clamp_(0, 1)
+        ref = ops.clamp_(ops.copy(rec, T.empty(rec.H, rec.W, rec.C, self.device)))      # = test.py:249's clamp_(0, 1); two launches of the library (round 5: torch.clamp, an ATen
+        #                                                                                 kernel inside the frame plan -- the one launch that was not the extension's)
         fk = ops.Fork(self.device)
         self.slots.lane = 1                                # (its own reduction workspaces: this plan runs beside the EL's)
         try:

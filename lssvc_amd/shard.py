@@ -100,9 +100,29 @@ def broadcast_state_dicts(paths, dist=None, device="cpu", loader=None, force=Fal
     return out
 
 
-def run_sharded(units, run, dist=None):
-    """Static round-robin of `units` over the ranks, `run(unit)` on each rank's share, results gathered so that EVERY rank
-    returns the full list in unit order (rank 0 writes the result files, test.py:756-789)."""
+_QUEUE_CALLS = [0]
+
+
+def _shared_counter(dist):
+    """An atomic counter every rank can bump: the process group's own rendezvous store (TCPStore.add is atomic), or None where
+    torch keeps it out of reach."""
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        store = c10d._get_default_store()
+        store.add("lssvc_probe", 0)
+        return store
+    except Exception:                                                     # noqa: BLE001 -- no store: the static split below
+        return None
+
+
+def run_sharded(units, run, dist=None, cost=None, dynamic=True):
+    """`run(unit)` for every unit, the ranks sharing the work, results gathered so that EVERY rank returns the full list in unit order
+    (rank 0 writes the result files, test.py:756-789).
+    Round 6: a WORK QUEUE instead of the reference's static `process_idx % gpu_num` (test.py:648-656): a rank takes the next unit when
+    it has finished its last one -- an atomic counter in the process group's rendezvous store (rank 0 hosts it), no data-path
+    collective -- so that clips of unequal length (96-frame next to 600-frame sequences) do not leave GPUs idle at the tail.
+    cost(unit) (optional): expected work; units are handed out most expensive first (longest-processing-time-first keeps the tail
+    short). dynamic=False, a world of one, or no reachable store: the static round-robin."""
     solo = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
     if solo:
         return [run(u) for u in units]
@@ -111,12 +131,31 @@ def run_sharded(units, run, dist=None):
     # tears the job down: every rank finishes its share, failures travel with the results, and ALL ranks raise afterwards
     # with the failing unit and rank named.
     import traceback
+    order = sorted(range(len(units)), key=lambda i: (-cost(units[i]), i)) if cost is not None else list(range(len(units)))
+    store = _shared_counter(dist) if dynamic else None
+    agree = [store is not None]
+    dist.broadcast_object_list(agree, src=0)                              # every rank takes the same path as rank 0
+    key = "lssvc_run_sharded_%d" % _QUEUE_CALLS[0]                        # (every rank makes the same sequence of calls)
+    _QUEUE_CALLS[0] += 1
+
+    def my_units():
+        if agree[0] and store is not None:
+            while True:
+                k = store.add(key, 1) - 1                                 # atomic: position k of the hand-out order is mine
+                if k >= len(order):
+                    return
+                yield order[k]
+        elif agree[0]:
+            raise RuntimeError("rank %d cannot reach the rendezvous store rank 0 hands work out through" % rank)
+        else:
+            for n, i in enumerate(order):
+                if n % world == rank:
+                    yield i
+
     mine = []
-    for i, u in enumerate(units):
-        if i % world != rank:
-            continue
+    for i in my_units():
         try:
-            mine.append((i, True, run(u)))
+            mine.append((i, True, run(units[i])))
         except Exception:                                                 # noqa: BLE001 -- reported below, on every rank
             mine.append((i, False, "rank %d, unit %d: %s" % (rank, i, traceback.format_exc())))
     parts = [None] * world

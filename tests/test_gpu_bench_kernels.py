@@ -288,7 +288,9 @@ def test_persistent_3x3_small_grids(hip):
     """Grids with fewer than 8 workgroups (tile ranges keyed by blockIdx & 7 left tiles uncomputed): force
     the persistent kernel onto convs with 1..7 tiles and compare with the tiled kernel."""
     old_min, old_on = _get("f16x3_persist_min_tiles"), _get("f16x3_persist")
+    old_narrow = _get("p3_narrow")
     try:
+        _set("p3_narrow", 0)                              # (round 6: the 16-channel case would take the narrow-head instantiation; this test is about the 24x16 one)
         # 1..7 tiles (24x16) / a few more 16x16 ones, partial tiles, several M tiles, a lone last tile to flush
         for H, W, cout in ((24, 16, 64), (24, 48, 64), (48, 48, 64), (30, 70, 48), (24, 16, 128), (50, 20, 16), (72, 16, 64),
                            (100, 40, 192)):
@@ -308,6 +310,7 @@ def test_persistent_3x3_small_grids(hip):
     finally:
         _set("f16x3_persist_min_tiles", old_min)
         _set("f16x3_persist", old_on)
+        _set("p3_narrow", old_narrow)
 
 
 # ---- RPW = 4 instantiations of the tiled f16x3 kernels (7x7 SpyNet convs; 3x3 with 2-3 output channels) -----------
@@ -622,3 +625,40 @@ def test_gdn_lean_epilogue_is_bit_identical(hip, c, H, W, flavour, inverse, resi
             lean, k1 = _run(hip, mode, launch)
         assert k0 == k1 and (("f16x3" in k0) == (mode == "f16x3")), (k0, k1)
         assert torch.equal(general, lean), (mode, k0, (general - lean).abs().max().item())
+
+
+@pytest.mark.parametrize("cins,cout,H,W,stride,opts,kernel", [
+    ([64], 2, 576, 960, 1, {}, "conv3n_f16x3p_kernel<true, flat> pf2"),                                  # narrow head, two workgroups per CU, register prefetch
+    ([64], 64, 144, 240, 1, {}, "conv3r_f16x3p_kernel<4, true, rpw 4>"),                                 # small tiling, plain schedule
+    ([128], 128, 72, 120, 1, {}, "conv3r_f16x3p_kernel<4, true, rpw 2, pf2>"),                           # small tiling, 8 phases: register prefetch
+    ([48], 64, 576, 960, 2, {}, "conv3s2_f16x3p_kernel<4, true> pf2"),                                   # stride 2, register prefetch (3 phases per tile: odd)
+    ([64], 64, 576, 960, 2, {"p3_pf2": 2}, "conv3s2_f16x3p_kernel<4, true> pair"),                       # stride 2, pair loads
+])
+def test_round6_schedules_hand_off_is_race_free(hip, cins, cout, H, W, stride, opts, kernel):
+    """The producer schedules of round 6 (register prefetch with counted waits, pair loads, two workgroups per CU) publish LDS buffers
+    through the same per-wave slots as the round-5 kernel: thirty launches each, with an input activation, must all equal the tiled
+    kernel bit for bit (a hand-off that signalled a buffer before its patch had landed would show up as a launch that differs)."""
+    from lssvc_amd._lib import lib
+    launch = None
+    g = torch.Generator().manual_seed(sum(cins) + H + stride)
+    xs = [nhwc(hip, torch.randn(1, c, H, W, generator=g)) for c in cins]
+    cin = sum(cins)
+    Wt = _W({"c.weight": torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9), "c.bias": torch.randn(cout, generator=g)})
+
+    def launch():
+        return hip.conv(Wt, "c", xs, stride=stride, in_act="lrelu", in_slope=0.1, act="lrelu", slope=0.01)
+
+    try:
+        hip.set_conv_precision("f16x3")
+        with _opts(f16x3_persist=0, f16x3_persist_s2=0):
+            ref = launch().buf.clone()
+            assert lib.lssvc_conv2d_last_kernel().decode().startswith("conv_f16x3_kernel")
+        bad = 0
+        with _opts(**opts):
+            for _ in range(30):
+                out = launch()
+                assert lib.lssvc_conv2d_last_kernel().decode() == kernel, lib.lssvc_conv2d_last_kernel().decode()
+                bad += 0 if torch.equal(out.buf, ref) else 1
+    finally:
+        hip.set_conv_precision("f32")
+    assert bad == 0, "%d of 30 launches differ" % bad

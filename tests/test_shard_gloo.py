@@ -79,6 +79,8 @@ def _harness_worker(rank, world, port, q, cfg_dir):
     jobs = H.build_jobs(args, cfg)
 
     def fake_run(job):                                  # stand-in for run_job: closed loop inside the GOP only
+        import time
+        time.sleep(0.05)                                # (the work queue of round 6: a job takes time, or one rank could take them all)
         recs, state = [], 0.0
         for t in range(job["count"]):
             f = job["first"] + t
@@ -153,7 +155,7 @@ def _failing_worker(rank, world, port, q):
     meta_ok = sd["epoch"] == 12 and sd["cfg"] == {"q": [1, 2]} and torch.equal(sd["a.bias"], _ckpt(3)["a.bias"])
 
     def run(u):
-        if u == 3:                                       # unit 3 belongs to rank 1
+        if u == 3:                                       # (round 6: whichever rank the work queue hands unit 3 to)
             raise ValueError("sequence ends before frame 7")
         return u * 10
 
@@ -180,7 +182,55 @@ def test_a_failing_unit_is_reported_on_every_rank():
         assert p.exitcode == 0
     for rank, meta_ok, msg in got:
         assert meta_ok
-        assert msg is not None and "rank 1, unit 3" in msg and "sequence ends before frame 7" in msg and "1 of 6" in msg
+        assert msg is not None and (", unit 3" in msg) and "sequence ends before frame 7" in msg and "1 of 6" in msg
+
+
+def _queue_worker(rank, world, port, q):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    units = [0.05] * 5 + [0.6] + [0.05] * 6             # one long clip among short ones, NOT at the front of the list
+    took = []
+
+    def run(u):
+        took.append(u)
+        time.sleep(u)
+        return (u, dist.get_rank())
+
+    t0 = time.time()
+    res = run_sharded(units, run, dist, cost=lambda u: u)
+    dyn = time.time() - t0
+    t0 = time.time()
+    res_static = run_sharded(units, run, dist, cost=None, dynamic=False)
+    sta = time.time() - t0
+    q.put((rank, res, res_static, dyn, sta))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_work_queue_balances_uneven_units():
+    """Round 6 ("dynamic GOP work-queue"): run_sharded hands units out on request, most expensive first, through an atomic
+    counter in the process group's store. Twelve clips of which one is twelve times as long: every unit runs exactly once, the results
+    come back in unit order on both ranks, the rank that took the long clip took nothing else while the other one coded the eleven short
+    ones -- and the whole thing ends when the long clip does (0.6 s), where the reference's static `idx % world` split (test.py:648-656)
+    gives the long clip's rank five short ones on top (0.85 s)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_queue_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, res0, sta0, dyn0, s0), (_, res1, sta1, dyn1, s1) = got
+    assert res0 == res1 and sta0 == sta1 and len(res0) == 12
+    assert [u for u, _ in res0] == [0.05] * 5 + [0.6] + [0.05] * 6          # unit order, whatever rank ran what
+    long_rank = res0[5][1]
+    assert all(r != long_rank for i, (_, r) in enumerate(res0) if i != 5), res0      # the long clip's rank took nothing else
+    assert [r for _, r in sta0] == [0, 1] * 6                                # the static split, for comparison
+    assert max(dyn0, dyn1) < 0.8 < max(s0, s1), (dyn0, dyn1, s0, s1)
 
 
 def _run_bench(extra_env, *argv):
@@ -207,6 +257,26 @@ def test_bench_starts_its_own_ranks():
     assert lines[0]["n_gpus"] == 2 and lines[0]["dry_run"] is True and lines[0]["steps"] == 2
     assert lines[0]["checkpoint_tensors_broadcast"] == 334
     assert "starting 2 ranks" in p.stderr
+    # round 6: the line is checkable from itself -- one record per rank (its own rate, not only the max-reduce; its
+    # process; the CPUs it pinned itself to BEFORE anything else, disjoint from the other rank's), the process group as the library
+    # reports it, and every rank's bit counts held against rank 0's
+    ranks = lines[0]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and len({r["pid"] for r in ranks}) == 2
+    assert all(r["frames_per_s"] > 0 and r["ms_per_step"] > 0 for r in ranks)
+    assert ranks[0]["ms_per_step"] < ranks[1]["ms_per_step"] <= lines[0]["ms_per_step"] + 0.5        # (the dry run's rank r sleeps (1 + r) x 10 ms per step; the line quotes the slowest)
+    cpus = [_expand(r["cpu_affinity"]) for r in ranks]
+    assert cpus[0] and cpus[1] and not (set(cpus[0]) & set(cpus[1])), cpus
+    chk = lines[0]["rank_check"]
+    assert chk["process_group"] == {"backend": "gloo", "world_size": 2} and chk["all_ranks_bits_equal_rank0"] is True
+    assert chk["frames_per_s_per_rank"] == [r["frames_per_s"] for r in ranks]
+
+
+def _expand(spec):
+    out = []
+    for part in spec.split(","):
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
 
 
 def test_bench_reports_a_failed_rank():
