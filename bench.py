@@ -1093,6 +1093,14 @@ def main():
                                "frames_with_flipped_symbols": sum(1 for v in flipped if v), "first_frame_with_a_flipped_symbol": next((t for t, v in enumerate(flipped) if v), None),
                                "worst_frames": sorted(({"frame": t, "d_bpp": max(d_bpp[t]), "d_psnr_db": max(prow[t]["d_psnr"]), "symbols_flipped": flipped[t]}
                                                        for t in range(len(bits))), key=lambda r: -r["d_bpp"])[:3]})
+            second = os.path.join(ROOT, "tests", "golden", FIXTURE + "_ref_t2.npz")
+            if os.path.exists(second):
+                import numpy as np
+                z2 = np.load(second)
+                d2 = [max(abs(float(b[0]) - float(z2["f%d_bits" % t][0])) / (fx["h"] * fx["w"]), abs(float(b[1]) - float(z2["f%d_bits" % t][1])) / (fx["H"] * fx["W"])) for t, b in enumerate(bits)]
+                parity["against_the_references_second_run"] = {"frames_inside_1e-5_bpp": sum(1 for v in d2 if v <= 1e-5), "max_d_bpp": max(d2),
+                                                               "what": "the same timed bit counts against the reference's run on %d threads (tests/golden/%s_ref_t2.npz): "
+                                                                       "the two reference runs differ from each other as `reference_against_itself` says" % (int(z2["reference_threads"]), FIXTURE)}
             parity.update({"fixture": fx["path"] + " (the reference itself on %s CPU threads; tests/golden/make_golden_full.py)" % fx["threads"],
                            "bars": "per frame and layer |d bpp| <= 1e-5 and |d PSNR| <= 1e-4 dB (BASELINE.json north_star), FREE-RUNNING: no re-alignment of the closed loop after a rounding tie",
                            "bits_from": "the last timed GOP of the headline loop", "psnr_and_symbols_from": "one untimed eager GOP whose bit counts are compared with the timed GOP's",

@@ -191,7 +191,8 @@ int lssvc_lrelu(const lssvc_view *in, const lssvc_view *out, float slope, void *
 int lssvc_pad_crop(const lssvc_view *in, const lssvc_view *out, int32_t left, int32_t top, void *stream);
 /* fp32 NHWC view -> PRE-SPLIT view of the same shape (see LSSVC_PREC_SPLIT_IN): out = split(clamp(act(in), +-65504)), act = none or
  * LeakyReLU(in_slope) -- the staging arithmetic of the f16x3 convs (the reference has no counterpart: its convs read fp32,
- * layers.py:36-57). For tensors that a conv kernel did not write pre-split itself (resampled / warped / boundary tensors). */
+ * layers.py:36-57). EXPERIMENTAL (round 5: measured 0-7 %, not adopted; the model never calls it): the only producer of pre-split views --
+ * no conv epilogue writes the format. `in` and `out` must not overlap (the layout permutes bytes across threads; checked). */
 int lssvc_presplit(const lssvc_view *in, const lssvc_view *out, int32_t in_act, float in_slope, void *stream);
 /* Zero `nbytes` of device memory / clamp n floats in place (what torch.zeros and the caller's `clamp_(0, 1)` of the
  * reconstructions, test.py:249-250, are for a caller without PyTorch; compiled frame plans record these as launches). */
@@ -466,6 +467,17 @@ int lssvc_engine_decode_pframe(void *engine, const uint8_t *bl_file, int64_t bl_
  *                                    (a second register set) instead of only during its depthwise phase (LSSVC_DWPRE_DEEP)
  *   "pointwise_blocks"         1/0   x2 bilinear resize and depthwise 3x3 compute a 2x2 output block per thread (the input
  *                                    neighbourhood is loaded once: 9 / 16 loads instead of 16 / 36) (LSSVC_POINTWISE_BLOCKS)
+ *   round 6 (conv3_f16x3p.hip, conv_mfma_kernel.h; profiles/r06_*_ab.txt hold the A/Bs):
+ *   "p3_small"                 1/0   3x3 stride-1 convs with fewer than f16x3_persist_min_tiles tiles of 24x16 pixels run on the persistent
+ *                                    kernel's small-tile instantiations (16x16 / 8x16 / 4x16 tiles, picked by a cost model); 2 / 3: with the
+ *                                    register prefetch always / never (1: from 8 phases on) (LSSVC_P3_SMALL)
+ *   "p3_narrow"                1/0   3x3 stride-1 convs with <= 16 output channels on the narrow-head instantiation (16x16 tiles, two
+ *                                    workgroups per CU; the tiled kernel's epilogue when Cout % 4 != 0) (LSSVC_P3_NARROW)
+ *   "p3_pf2"                   0/1/2 producers of the stride-2 and narrow-head instantiations: one register set (round 5) / register
+ *                                    prefetch (default) / pair loads (measured slower; stride 2 only) (LSSVC_P3_PF2)
+ *   "p3_force"                 n     experiments: force the small tiling MF * 16 + rows-per-wave (0 = the cost model) (LSSVC_P3_FORCE)
+ *   "p3_big_pair"              1/0   experiment: the 24x16 tiling with pair loads (MF = 4, no input activation; slower) (LSSVC_P3_BIG_PAIR)
+ *   "gdn_fast"                 1/0   GDN / IGDN epilogue as straight-line code where the views allow it (LSSVC_GDN_FAST_OPT)
  * Results do not depend on them (the kernels they choose between are bit-identical); tests use them to pin that. */
 int lssvc_set_option(const char *name, int32_t value);
 int lssvc_get_option(const char *name, int32_t *value);

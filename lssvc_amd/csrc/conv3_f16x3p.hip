@@ -36,9 +36,16 @@ static bool p3_pick_tiling(const ConvP &p, P3Small &c) {
     if (const int forced = option_get(OPT_P3_FORCE); forced > 0) {      // experiments: mf * 16 + rows per wave
         c.mf = (forced >> 4) & 15;
         c.rpw = forced & 15;
-        return c.mf >= 1 && c.mf <= 4 && (c.rpw == 1 || c.rpw == 2 || c.rpw == 4) && c.mf <= frags;
+        return c.mf >= 1 && c.mf <= 4 && (c.rpw == 1 || c.rpw == 2 || c.rpw == 4 || (c.rpw == 8 && c.mf >= 3)) && c.mf <= frags;
     }
-    if (big_ok) return true;      // (measured: from 256 tiles of 24x16 on no small tiling beats it -- profiles/r06_small_map_ab.txt, second table)
+    if (big_ok) {
+        // (measured: from 256 tiles of 24x16 on no SMALL tiling beats it -- profiles/r06_small_map_ab.txt, second table.) One TALLER tiling
+        // does, for the 48-channel layers of the full-resolution maps: 32x16 tiles (8 rows per wave) give an MF = 3 phase the MFMA count of
+        // the dominant MF = 4 / 24x16 kernel on a patch with a smaller halo share -- +2 ... +7 % where the map has >= 16 tiles per CU
+        // (profiles/r06_tall_tiles_ab.txt; with few tiles per CU the coarser tiling loses to its own tail, -17 % at 288x480)
+        if (option_get(OPT_P3_SMALL) == 1 && mf0 == 3 && frags == 3 && p3_tiles(p, 3, 8) >= 16LL * cus) c.rpw = 8;
+        return true;
+    }
     auto cost = [&](int mf, int rpw) {
         const long long tiles = p3_tiles(p, mf, rpw);
         const double tile_cycles = phases * (14.0 * 16.0 * mf * rpw + 900.0) + 150.0 * mf * rpw + 1500.0;
@@ -129,8 +136,10 @@ int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
         // p3_small: 1 = the register prefetch from 8 phases on (+3 ... +8 %; below that it is neutral: profiles/r06_small_map_ab.txt), 2 = always,
         // 3 = never
         const int sm = option_get(OPT_P3_SMALL);
-        const int pf = (sm == 2 || (sm == 1 && p.n_chunks16 >= 8)) ? 1 : 0;
+        int pf = (sm == 2 || (sm == 1 && p.n_chunks16 >= 8)) ? 1 : 0;
+        if (c.rpw == 8 && sm == 1) pf = p.n_chunks16 % 3 == 0 ? 1 : 0;      // 32x16 tiles: the prefetch pays with 3 or 6 phases per tile (48- / 96-channel inputs), not with 4 or 5
         snprintf(kernel_name, 96, "conv3r_f16x3p_kernel<%d, %s, rpw %d%s>", c.mf, inact ? "true" : "false", c.rpw, pf == 2 ? ", pair" : pf == 1 ? ", pf2" : "");
+        if (c.rpw == 8) return launch_p3_tall(p, c.mf, inact, c.mf == 3 ? pf : 0, st);
         return launch_p3_small(p, c.mf, c.rpw, inact, pf, st);
     }
     if (option_get(OPT_P3_BIG_PAIR) && mf == 4 && !inact && !(p.debug & 256)) {      // experiment: the 24x16 tiling with pair loads

@@ -112,7 +112,7 @@ struct P3Phase {
 // (adding the residuals, plain or pixel-shuffle store) with the NEXT fill's patch loads already in flight, and only after all
 // four have drained is the pair refilled. Same arithmetic per element as the direct epilogue: results are bit-identical.
 // SPLIT (round 5): the inputs are PRE-SPLIT tensors (lssvc_hip.h: LSSVC_PREC_SPLIT_IN) -- per pixel and 16-channel chunk 64 bytes,
-// [hi: 16 x fp16 | lo: 16 x fp16], written by the producing layer's epilogue (or lssvc_presplit) with the input activation already
+// [hi: 16 x fp16 | lo: 16 x fp16], written by lssvc_presplit (an epilogue that writes the format was not built) with the input activation already
 // applied; same bytes per element as fp32. The patch then goes global -> LDS by LDS-DMA like the weights: no patch registers, no
 // conversion, no ds_write in the producer waves; every 16-byte unit of the LDS image [plane][patch pixel][16 halfs] is fetched by
 // one lane from wherever it lives (zero padding: from a 64-byte block of zeros), so the LDS layout the consumers read is unchanged.
@@ -1110,6 +1110,7 @@ static int launch_p3r(const ConvP &p, hipStream_t st) {
 int launch_p3_small(const ConvP &p, int mf, int rpw, bool inact, int pf, hipStream_t st);      // stride 1, fused fast epilogue, 4*rpw x 16 tiles
 int launch_p3_narrow(const ConvP &p, bool inact, bool flat, int pf, hipStream_t st);                     // stride 1, <= 16 output channels, 16x16 tiles, 2 workgroups per CU
 int launch_p3s2_pf(const ConvP &p, int mf, bool inact, int pf, hipStream_t st);                  // stride 2 with the register prefetch (pf 1) / pair loads (pf 2)
-int launch_p3_big_pair(const ConvP &p, int mf, bool inact, hipStream_t st);                      // stride 1, 24x16 tiles, pair loads (experiment)                         // stride 2 with the register prefetch
+int launch_p3_big_pair(const ConvP &p, int mf, bool inact, hipStream_t st);
+int launch_p3_tall(const ConvP &p, int mf, bool inact, int pf, hipStream_t st);                  // stride 1, 32x16 tiles (experiment)                      // stride 1, 24x16 tiles, pair loads (experiment)                         // stride 2 with the register prefetch
 
 }  // namespace lssvc

@@ -38,7 +38,7 @@ struct ConvP {
     int out_vec, res_vec, gdn_vec;
     int fast_epi;    // host: Cout % 4 == 0, 16-byte addressable out / residual, no pixel shuffle, no GDN -> straight-line epilogue
     int in_split;    // every input is a PRE-SPLIT tensor (LSSVC_PREC_SPLIT_IN): [pixel][16-channel chunk][hi x16 | lo x16] fp16, activation applied
-    int out_split;   // the output is written pre-split (LSSVC_PREC_SPLIT_OUT), after out_act
+    int out_split;   // (never set: writing pre-split OUTPUTS from an epilogue was not built -- the round-5 A/B stopped at pre-split inputs made by lssvc_presplit)
     int gdn_fast;    // host: GDN / IGDN epilogue with Cout % 4 == 0, 16-byte addressable out / gdn_x / residual, no shuffle, out_scale 1 -> conv_epilogue_gdn
 };
 

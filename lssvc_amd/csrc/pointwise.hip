@@ -680,6 +680,11 @@ extern "C" int lssvc_presplit(const lssvc_view *in, const lssvc_view *out, int32
     LSSVC_CHECK(in_act == LSSVC_INACT_NONE || (in_act == LSSVC_INACT_LRELU && in_slope >= 0.0f && in_slope <= 1.0f), "presplit: in_act %d slope %g", in_act, in_slope);
     LSSVC_CHECK(out->ld % 16 == 0 && out->ld >= (out->C + 15) / 16 * 16 && (reinterpret_cast<uintptr_t>(out->ptr) & 63) == 0,
                 "presplit: the pre-split view needs a 64-byte aligned base and a pixel pitch that is a multiple of 16 and covers its padded chunks (C=%d ld=%d)", out->C, out->ld);
+    {   // the pre-split layout permutes bytes inside every 64-byte chunk across threads: in-place (or overlapping) use would corrupt data silently
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(in->ptr), a1 = a0 + (size_t)in->H * in->W * in->ld * sizeof(float);
+        const uintptr_t b0 = reinterpret_cast<uintptr_t>(out->ptr), b1 = b0 + (size_t)out->H * out->W * out->ld * sizeof(float);
+        LSSVC_CHECK(a1 <= b0 || b1 <= a0, "presplit: `in` and `out` overlap (the conversion cannot run in place)");
+    }
     const int qpp = (out->C + 15) / 16 * 4;
     const long long total = (long long)out->H * out->W * qpp;
     LSSVC_ITEMS_OK(total, "presplit");

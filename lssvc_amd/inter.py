@@ -485,7 +485,7 @@ class LSSVC_extend(_HostModel):
     # clamped to [0,1] -- what test.py:249-250 makes of the DPB before the next frame; a caller of this mode promises that clamp --
     # and leaves its four results in persistent buffers (self._stash, by frame parity) for the next call, which codes its EL only.
     STASH_KEYS = ("recon", "feature", "y_hat", "mv_hat")
-    MAX_GEOMS = 3
+    MAX_GEOMS = 3           # (intra._HostModel.MAX_PLANS is sized for this many geometries' plan sets)
 
     def _bufs(self, geom=None):
         """The look-ahead buffers of a geometry (default: the frame being issued), least recently used geometries dropped together

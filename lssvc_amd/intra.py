@@ -109,7 +109,13 @@ class _HostModel:
             return t
         return ops.copy(t, T.empty(t.H, t.W, t.C, t.device))
 
-    MAX_PLANS = 10          # I / first-P / steady-P of one size (+1; the look-ahead protocol has four P plans: first, two parities, last): a plan owns a hipGraph memory pool of several GiB at 1080p
+    # Plans kept per model. One GEOMETRY (picture size x ratio x padding x precision) needs up to 7: I | first-P, steady-P | and the
+    # look-ahead protocol's first-P, two parities, last, each as a BL and an EL plan where they differ. LSSVC_extend keeps look-ahead
+    # buffers for MAX_GEOMS geometries (inter.py), so the plan cache must hold that many sets or a harness alternating two sizes would
+    # evict plans before they replay -- each re-creation an eager first call, a device sync and a recapture (the default
+    # was 10 against 3 geometries).
+    PLANS_PER_GEOMETRY = 7
+    MAX_PLANS = 3 * PLANS_PER_GEOMETRY + 2      # = inter.LSSVC_extend.MAX_GEOMS sets + the I plans of an IntraSS used on its own
 
     def _run_planned(self, key, tensors, body):
         """body(T inputs dict) -> dict of T outputs. First call of a key: eager. Second: capture + replay. Later: replay.
@@ -161,7 +167,12 @@ class _HostModel:
 
     def _graph_pool(self, lane):
         if lane not in self._graph_pools:
-            self._graph_pools[lane] = torch.cuda.MemPool()
+            if hasattr(torch.cuda, "MemPool"):
+                self._graph_pools[lane] = torch.cuda.MemPool()
+            else:                                                      # older torch: a pool handle has the same sharing semantics
+                class _Handle:
+                    id = torch.cuda.graph_pool_handle()
+                self._graph_pools[lane] = _Handle()
         return self._graph_pools[lane]
 
     def to(self, device):

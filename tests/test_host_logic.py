@@ -355,3 +355,24 @@ def test_framing_matches_reference_fixture(tmp_path):
         assert B.decode_p(p) == s
     for c in fx["shapes"]:
         assert list(B.get_downsampled_shape(*c["args"])) == c["out"]
+
+
+def test_counted_waits_of_the_persistent_kernels_cover_their_weight_dma():
+    """the persistent 3x3 kernels' producers publish an LDS buffer after `s_waitcnt vmcnt(N)` -- N younger patch loads stay in
+    flight, the weight DMA issued before them must have landed. Correct only while the compiler emits at least N vector-memory
+    instructions between that DMA and the wait; round 5 checked the ISA by hand. tools/p3_waitcnt_check.py does it mechanically on the
+    in-tree objects (the ones that are linked into liblssvc_hip.so): every instantiation of the patch-ring schedule (round 5) and of the
+    register-prefetch schedule (round 6) must pass, and the tool must actually have found their counted waits."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objs = [os.path.join(root, "lssvc_amd", "csrc", n) for n in ("conv3_f16x3p.o", "conv3_f16x3p_r.o", "conv3_f16x3p_r2.o")]
+    if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("objects not built here (python -c 'import __graft_entry__ as g; g.build()') or no llvm-objdump")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "p3_waitcnt_check.py")] + objs, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "VIOLATION" not in p.stdout and " 0 with a counted wait that does not cover" in p.stdout
+    ring = [ln for ln in p.stdout.splitlines() if "<3, 0, 0, 0, 1, 0, 0, 0, 0, 0>" in ln]                  # 48-channel kernels: three patch buffers
+    pf = [ln for ln in p.stdout.splitlines() if "<4, 0, 0, 0, 2, 0, 0, 1, 0, 0>" in ln]                    # stride 2 with the register prefetch
+    assert ring and "(8, -8)" in ring[0], ring
+    assert pf and "(9, 9)" in pf[0], pf

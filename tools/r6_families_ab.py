@@ -117,6 +117,15 @@ def main():
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
             run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("r5 schedule", {}), ("pair loads", {"p3_big_pair": 1})], rounds, reps,
                      2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
+    elif what == "tall":
+        for cins, cout, H, W, kw in (([48], 48, 1152, 1920, {}), ([48], 48, 1152, 1920, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}), ([48, 48], 48, 1152, 1920, {}),
+                                     ([64, 16], 48, 1152, 1920, {}), ([96], 96, 288, 480, {}), ([192], 96, 288, 480, {"in_act": "lrelu", "in_slope": 0.1}), ([64], 48, 1152, 1920, {}),
+                                     ([64], 64, 1152, 1920, {}), ([64], 64, 576, 960, {})):
+            cin = sum(cins)
+            mf = 3 if cout % 48 == 0 else 4
+            call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
+            arms = [("r5: 24x16 tiles", {}), ("32x16 tiles", {"p3_force": mf * 16 + 8, "p3_small": 3})] + ([("32x16 tiles, pf2", {"p3_force": mf * 16 + 8, "p3_small": 2})] if mf == 3 else [])
+            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, arms, rounds, reps, 2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
     elif what == "gdn":
         from lssvc_amd.synth import _make
         for c, H, W, flavour, inverse, res in ((64, 576, 960, "inter", False, False), (64, 576, 960, "inter", True, False), (64, 288, 480, "inter", False, False),
