@@ -662,3 +662,31 @@ def test_round6_schedules_hand_off_is_race_free(hip, cins, cout, H, W, stride, o
     finally:
         hip.set_conv_precision("f32")
     assert bad == 0, "%d of 30 launches differ" % bad
+
+
+@pytest.mark.parametrize("cins,H,W,kw", [([48], 300, 340, {}), ([48, 48], 290, 350, {"in_act": "lrelu", "in_slope": 0.1, "act": "lrelu", "residual": True}), ([64, 16], 301, 333, {})])
+def test_tall_tiles_are_bit_identical(hip, cins, H, W, kw):
+    """Round 6: the 48-channel layers of the full-resolution maps run on 32x16-pixel tiles (8 rows per consumer wave; conv3_f16x3p.hip:
+    p3_pick_tiling) -- forced here onto maps small enough for a test, with and without the register prefetch, against the 24x16
+    tiling and the tiled kernel."""
+    launch = _conv_case(hip, cins, 48, H, W, **dict(kw))
+    with _opts(p3_small=0, p3_force=0):
+        r5, k5 = _run(hip, "f16x3", launch)
+    assert k5.startswith("conv3_f16x3p_kernel<3,"), k5
+    with _opts(f16x3_persist=0):
+        tiled, kt = _run(hip, "f16x3", launch)
+    assert kt.startswith("conv_f16x3_kernel"), kt
+    for sm in (2, 3):
+        with _opts(p3_small=sm, p3_force=3 * 16 + 8):
+            got, k = _run(hip, "f16x3", launch)
+        assert k.startswith("conv3r_f16x3p_kernel<3,") and "rpw 8" in k and (("pf2" in k) == (sm == 2)), k
+        assert torch.equal(got, r5) and torch.equal(got, tiled), k
+
+
+def test_tall_tiles_are_dispatched_for_the_full_resolution_48_channel_layers(hip):
+    launch = _conv_case(hip, [48], 48, 1152, 1920)
+    got, k = _run(hip, "f16x3", launch)
+    assert k == "conv3r_f16x3p_kernel<3, false, rpw 8, pf2>", k
+    with _opts(p3_small=0):
+        r5, k5 = _run(hip, "f16x3", launch)
+    assert k5 == "conv3_f16x3p_kernel<3, false>" and torch.equal(got, r5)
