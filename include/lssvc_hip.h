@@ -423,6 +423,23 @@ int lssvc_engine_iframe(void *engine, const float *x_bl, const float *x_el, doub
 int lssvc_engine_pframe(void *engine, const float *x_bl, const float *x_el, const float *ref_frame_bl, const float *ref_frame_el,
                         const float *ref_feature_bl, const float *ref_feature_el, double bits[2], float *recon_bl, float *feature_bl,
                         float *recon_el, float *feature_el, float *mv_hat, float *warp_frame, void *stream);
+/* Round 6 -- the look-ahead of LSSVC_extend.forward_one_frame(next_x_bl=...) (lssvc_amd/inter.py; reference loop test.py:182-250, the
+ * layers LSSVC_net.py:445-528 / dmc_net.py:421-488) for a caller without Python. A P-frame as TWO plans per frame type
+ * (plan_compiler.compile_pframe_layers): its base layer alone, and its enhancement layer given the base layer's results. The base layer
+ * of a P-frame reads the previous frame's BASE layer only, so the engine codes BL(t+1) -- from next_x_bl -- on a second stream of its
+ * own while EL(t) runs on the caller's, keeps it, and the next call codes its enhancement layer only. Contract: consecutive frames of
+ * one sequence; the x_bl of a call is the tensor named as next_x_bl in the previous one (then x_bl / ref_frame_bl / ref_feature_bl
+ * are not read again); next_x_bl NULL behind the last frame; the caller clamps the DPB's reference frames to [0, 1] between frames, as
+ * test.py:249-250 does (the base-layer plans clamp their own copy, so a base layer coded ahead sees the same values). ref_feature_bl
+ * NULL = the first P-frame after an I-frame (drops anything coded ahead); lssvc_engine_lookahead_reset does the same on demand (a seek).
+ * Same launches per layer as lssvc_engine_pframe: results are bit-identical to it (tests/test_gpu_engine.py, tests/engine_demo.c). */
+int lssvc_engine_load_inter_layers(void *engine, const char *bl_first_plan, const char *bl_steady_plan, const char *el_first_plan,
+                                   const char *el_steady_plan);
+int lssvc_engine_pframe_lookahead(void *engine, const float *x_bl, const float *x_el, const float *next_x_bl, const float *ref_frame_bl,
+                                  const float *ref_frame_el, const float *ref_feature_bl, const float *ref_feature_el, double bits[2],
+                                  float *recon_bl, float *feature_bl, float *recon_el, float *feature_el, float *mv_hat, float *warp_frame,
+                                  void *stream);
+int lssvc_engine_lookahead_reset(void *engine);
 /* which: 0 intra, 1 first-P, 2 steady-P; 3 / 4 I-frame encoder / decoder, 5 / 6 first-P, 7 / 8 steady-P (write_stream = 1 plans)
  * -> launches (host steps included), streams, arena bytes, weight bytes, H, W */
 int lssvc_engine_plan_info(void *engine, int32_t which, int64_t *out6);

@@ -139,6 +139,9 @@ SIGNATURES = {
     "lssvc_engine_set_scale": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, C.c_int32]),
     "lssvc_engine_iframe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lssvc_engine_pframe": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.POINTER(C.c_double)] + [C.c_void_p] * 7),
+    "lssvc_engine_load_inter_layers": (C.c_int, [C.c_void_p] + [C.c_char_p] * 4),
+    "lssvc_engine_pframe_lookahead": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7 + [C.POINTER(C.c_double)] + [C.c_void_p] * 7),
+    "lssvc_engine_lookahead_reset": (C.c_int, [C.c_void_p]),
     "lssvc_engine_plan_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "lssvc_engine_plan_meta": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_int64)]),
     "lssvc_engine_load_stream": (C.c_int, [C.c_void_p] + [C.c_char_p] * 6),

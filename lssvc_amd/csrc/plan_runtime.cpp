@@ -646,11 +646,24 @@ struct Engine {
     hipStream_t own = nullptr;           // frames run here when the caller passes stream NULL (the null stream cannot be captured)
     std::unique_ptr<Plan> intra, first_p, steady_p;
     std::unique_ptr<Plan> i_enc, i_dec, p1_enc, p1_dec, p_enc, p_dec;      // write_stream = 1 halves
+    // round 6: the P-frame as a base-layer plan and an enhancement-layer plan (plan_compiler.compile_pframe_layers), [0] first-P, [1] steady-P;
+    // lssvc_engine_pframe_lookahead runs EL(t) on the caller's stream and BL(t+1) on `ahead_stream`
+    std::unique_ptr<Plan> bl_plan[2], el_plan[2];
+    hipStream_t ahead_stream = nullptr;
+    hipEvent_t ev_handed = nullptr, ev_ahead = nullptr;   // BL(t) handed to the EL plan / BL(t+1) finished
+    Plan *ahead = nullptr;                                // the base-layer plan whose outputs hold the NEXT frame's base layer (coded ahead), or null
+    double ahead_bits[16] = {0};
+    double *ahead_slots_host = nullptr;                   // pinned: the look-ahead base layer's bit slots come down asynchronously
     std::unique_ptr<Checkpoint> ckpt[2];                                    // [0] IntraSS, [1] LSSVC: raw tensors + prepared device weights
     ~Engine() {
         intra.reset(), first_p.reset(), steady_p.reset();
         i_enc.reset(), i_dec.reset(), p1_enc.reset(), p1_dec.reset(), p_enc.reset(), p_dec.reset();
+        for (int i = 0; i < 2; ++i) bl_plan[i].reset(), el_plan[i].reset();
         ckpt[0].reset(), ckpt[1].reset();
+        if (ahead_slots_host) (void)hipHostFree(ahead_slots_host);
+        if (ev_handed) (void)hipEventDestroy(ev_handed);
+        if (ev_ahead) (void)hipEventDestroy(ev_ahead);
+        if (ahead_stream) (void)hipStreamDestroy(ahead_stream);
         if (own) (void)hipStreamDestroy(own);
     }
     hipStream_t stream(void *s) const { return s ? (hipStream_t)s : own; }
@@ -672,8 +685,10 @@ static int audit_verdict(Plan &p, hipStream_t st) {
 }
 
 // Run one plan: caller's inputs in, first call eager, second call capture, later calls hipGraphLaunch, outputs out.
+// no_sync (round 6, the look-ahead base layer): once the plan replays as a graph the call returns with the work queued -- `slots16` must
+// then be pinned host memory, filled when the stream gets there; the eager first call and the capturing second call stay synchronous
 int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &ins,
-             const std::vector<std::pair<const char *, void *>> &outs, double *slots16, hipStream_t st) {
+             const std::vector<std::pair<const char *, void *>> &outs, double *slots16, hipStream_t st, bool no_sync = false) {
     for (auto &kv : ins) {
         const int i = p.region_index(kv.first, REGION_INPUT);
         if (i < 0) {
@@ -720,6 +735,7 @@ int run_plan(Plan &p, const std::vector<std::pair<const char *, const void *>> &
         LSSVC_HIP(hipMemcpyAsync(kv.second, p.regions[i].ptr, p.regions[i].nbytes, hipMemcpyDefault, st));
     }
     LSSVC_HIP(hipMemcpyAsync(slots16, p.regions[p.bits_region].ptr, 16 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (no_sync && p.runs > 2) return 0;                 // (replaying: the caller waits for the stream when it needs the counts)
     LSSVC_HIP(hipStreamSynchronize(st));                 // the bit counts are host values, as in the reference (.item())
     return 0;
 }
@@ -913,11 +929,45 @@ extern "C" int lssvc_engine_load_inter(void *h, const char *first_p_plan, const 
     return load_into(e, e->steady_p, steady_p_plan, "pframe", nullptr);
 }
 
+// Round 6: the four plans of the look-ahead protocol (plan_compiler.compile_pframe_layers): base layer / enhancement layer of the first
+// P-frame after an I-frame and of a steady-state P-frame.
+extern "C" int lssvc_engine_load_inter_layers(void *h, const char *bl_first, const char *bl_steady, const char *el_first, const char *el_steady) {
+    LSSVC_CHECK(h && bl_first && bl_steady && el_first && el_steady, "engine_load_inter_layers: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    LSSVC_HIP(hipSetDevice(e->device));
+    if (int rc = load_into(e, e->bl_plan[0], bl_first, "pframe_first_bl", nullptr)) return rc;
+    if (int rc = load_into(e, e->bl_plan[1], bl_steady, "pframe_bl", nullptr)) return rc;
+    if (int rc = load_into(e, e->el_plan[0], el_first, "pframe_first_el", nullptr)) return rc;
+    if (int rc = load_into(e, e->el_plan[1], el_steady, "pframe_el", nullptr)) return rc;
+    // what the base-layer plans hand over must be what the enhancement-layer plans were compiled to read
+    for (int i = 0; i < 2; ++i)
+        for (const char *k : {"bl_recon", "bl_feature", "bl_y_hat", "bl_mv_hat"})
+            for (int j = 0; j < 2; ++j) {
+                const int a = e->bl_plan[i]->region_index(k, REGION_OUTPUT), b = e->el_plan[j]->region_index(k, REGION_INPUT);
+                LSSVC_CHECK(a >= 0 && b >= 0 && e->bl_plan[i]->regions[a].nbytes == e->el_plan[j]->regions[b].nbytes,
+                            "engine_load_inter_layers: the plans do not agree on %s (compile the four from one model at one size)", k);
+            }
+    if (!e->ahead_stream) LSSVC_HIP(hipStreamCreateWithFlags(&e->ahead_stream, hipStreamNonBlocking));
+    if (!e->ev_handed) LSSVC_HIP(hipEventCreateWithFlags(&e->ev_handed, hipEventDisableTiming));
+    if (!e->ev_ahead) LSSVC_HIP(hipEventCreateWithFlags(&e->ev_ahead, hipEventDisableTiming));
+    if (!e->ahead_slots_host) LSSVC_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->ahead_slots_host), 16 * sizeof(double), hipHostMallocDefault));
+    e->ahead = nullptr;
+    return 0;
+}
+
+extern "C" int lssvc_engine_lookahead_reset(void *h) {
+    LSSVC_CHECK(h, "engine_lookahead_reset: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    if (e->ahead_stream) LSSVC_HIP(hipStreamSynchronize(e->ahead_stream));
+    e->ahead = nullptr;
+    return 0;
+}
+
 extern "C" int lssvc_engine_set_scale(void *h, float scale, int32_t H, int32_t W) {
     LSSVC_CHECK(h, "engine_set_scale: bad arguments");
     Engine *e = static_cast<Engine *>(h);
-    Plan *const all[9] = {e->intra.get(), e->first_p.get(), e->steady_p.get(), e->i_enc.get(), e->i_dec.get(), e->p1_enc.get(), e->p1_dec.get(),
-                          e->p_enc.get(), e->p_dec.get()};
+    Plan *const all[13] = {e->intra.get(), e->first_p.get(), e->steady_p.get(), e->i_enc.get(), e->i_dec.get(), e->p1_enc.get(), e->p1_dec.get(),
+                           e->p_enc.get(), e->p_dec.get(), e->bl_plan[0].get(), e->bl_plan[1].get(), e->el_plan[0].get(), e->el_plan[1].get()};
     const Plan *first = nullptr;
     for (Plan *p : all) {
         if (!p) continue;
@@ -933,8 +983,9 @@ extern "C" int lssvc_engine_set_scale(void *h, float scale, int32_t H, int32_t W
     }
     // encoder and decoder of one model must run the same kernels (the fp16 range audit may have moved layers to the exact
     // fp32 kernel while the plans were compiled; a mismatch would give streams the other side cannot decode)
-    Plan *const groups[2][6] = {{e->i_enc.get(), e->i_dec.get(), e->intra.get(), nullptr, nullptr, nullptr},
-                                {e->p1_enc.get(), e->p1_dec.get(), e->p_enc.get(), e->p_dec.get(), e->first_p.get(), e->steady_p.get()}};
+    Plan *const groups[2][10] = {{e->i_enc.get(), e->i_dec.get(), e->intra.get(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+                                 {e->p1_enc.get(), e->p1_dec.get(), e->p_enc.get(), e->p_dec.get(), e->first_p.get(), e->steady_p.get(), e->bl_plan[0].get(),
+                                  e->bl_plan[1].get(), e->el_plan[0].get(), e->el_plan[1].get()}};
     for (auto &g : groups) {
         const Plan *ref = nullptr;
         for (Plan *p : g) {
@@ -992,6 +1043,88 @@ extern "C" int lssvc_engine_pframe(void *h, const float *x_bl, const float *x_el
         return rc;
     bits[0] = s[0] + s[1] + s[2] + s[3];                 // dmc_net.py:473
     bits[1] = s[4] + s[5] + s[6] + s[7];                 // LSSVC_net.py:508
+    return 0;
+}
+
+// Round 6: a P-frame with the NEXT frame's base layer coded beside this frame's enhancement layer (what LSSVC_extend.forward_one_frame does
+// with next_x_bl / frame_id; lssvc_amd/inter.py). The base layer of a P-frame reads the previous frame's BASE layer only, so BL(t+1) runs
+// on the engine's second stream while EL(t) runs on the caller's; its results wait in the base-layer plan's output regions for the next
+// call, which then codes its enhancement layer only. Contract (the Python protocol's): the caller codes consecutive frames of one
+// sequence, passes as x_bl the tensor it named as next_x_bl in the previous call, and clamps the DPB's reference frames to [0, 1]
+// between frames (test.py:249-250; the base-layer plan clamps its own copy of the reference, so the look-ahead sees the same values).
+// lssvc_engine_lookahead_reset() (or a call with ref_feature_bl == NULL: the first P-frame after an I-frame) drops a base layer coded
+// ahead. Same launches per layer as lssvc_engine_pframe: bit-identical results.
+extern "C" int lssvc_engine_pframe_lookahead(void *h, const float *x_bl, const float *x_el, const float *next_x_bl, const float *ref_frame_bl,
+                                             const float *ref_frame_el, const float *ref_feature_bl, const float *ref_feature_el, double bits[2],
+                                             float *recon_bl, float *feature_bl, float *recon_el, float *feature_el, float *mv_hat, float *warp_frame,
+                                             void *stream) {
+    LSSVC_CHECK(h && bits && x_el && ref_frame_el && ref_feature_el, "engine_pframe_lookahead: bad arguments");
+    Engine *e = static_cast<Engine *>(h);
+    const int steady = ref_feature_bl ? 1 : 0;
+    LSSVC_CHECK(e->bl_plan[0] && e->bl_plan[1] && e->el_plan[0] && e->el_plan[1], "engine_pframe_lookahead: load the four layer plans first (lssvc_engine_load_inter_layers)");
+    hipStream_t main = e->stream(stream), side = e->ahead_stream;
+    if (!steady) e->ahead = nullptr;                         // a new GOP: nothing coded ahead belongs to it
+    double s[16];
+    Plan *src = e->ahead;                                    // the plan whose outputs hold BL(t)
+    if (src) {
+        LSSVC_HIP(hipStreamWaitEvent(main, e->ev_ahead, 0)); // BL(t) was finished on the second stream during the previous call
+        for (int i = 0; i < 4; ++i) s[i] = e->ahead_bits[i];
+    } else {
+        LSSVC_CHECK(x_bl && ref_frame_bl, "engine_pframe_lookahead: no base layer was coded ahead for this frame: x_bl and ref_frame_bl are required");
+        src = e->bl_plan[steady].get();
+        if (int rc = run_plan(*src, {{"x_bl", x_bl}, {"ref_frame_bl", ref_frame_bl}, {"ref_feature_bl", ref_feature_bl}}, {}, s, main)) return rc;
+    }
+    e->ahead = nullptr;
+    // ---- BL(t): to the enhancement-layer plan's inputs and to the caller
+    Plan &el = *e->el_plan[steady];
+    auto out_ptr = [&](Plan &p, const char *k) -> const void * {
+        const int i = p.region_index(k, REGION_OUTPUT);
+        return i >= 0 ? p.regions[i].ptr : nullptr;
+    };
+    auto region_bytes = [&](Plan &p, const char *k) -> size_t {
+        const int i = p.region_index(k, REGION_OUTPUT);
+        return i >= 0 ? (size_t)p.regions[i].nbytes : 0;
+    };
+    if (recon_bl) LSSVC_HIP(hipMemcpyAsync(recon_bl, out_ptr(*src, "recon_bl"), region_bytes(*src, "recon_bl"), hipMemcpyDefault, main));
+    if (feature_bl) LSSVC_HIP(hipMemcpyAsync(feature_bl, out_ptr(*src, "feature_bl"), region_bytes(*src, "feature_bl"), hipMemcpyDefault, main));
+    // ---- BL(t+1) on the second stream, from BL(t)'s reconstruction and feature (its plan clamps the reference itself)
+    Plan *nxt = next_x_bl ? e->bl_plan[1].get() : nullptr;
+    if (nxt) {
+        // the steady base-layer plan reads its references from its INPUT regions; when BL(t) lives in that very plan's outputs (every frame
+        // but the first two) the two copies below are what frees the outputs for BL(t+1)
+        for (const char *k : {"ref_frame_bl", "ref_feature_bl"}) {
+            const int i = nxt->region_index(k, REGION_INPUT);
+            LSSVC_CHECK(i >= 0, "engine_pframe_lookahead: the steady base-layer plan has no input %s", k);
+            const char *from = k[4] == 'f' && k[5] == 'r' ? "recon_bl" : "feature_bl";
+            LSSVC_HIP(hipMemcpyAsync(nxt->regions[i].ptr, out_ptr(*src, from), nxt->regions[i].nbytes, hipMemcpyDefault, main));
+        }
+    }
+    // (the enhancement-layer plan's run copies the four bl_* buffers into its input regions on `main` before anything of BL(t+1) may
+    // overwrite them: run_plan's input copies come first, the hand-over event is recorded behind them)
+    std::vector<std::pair<const char *, const void *>> el_in = {{"x_el", x_el}, {"ref_frame_el", ref_frame_el}, {"ref_feature_el", ref_feature_el},
+                                                                {"bl_recon", out_ptr(*src, "bl_recon")}, {"bl_feature", out_ptr(*src, "bl_feature")},
+                                                                {"bl_y_hat", out_ptr(*src, "bl_y_hat")}, {"bl_mv_hat", out_ptr(*src, "bl_mv_hat")}};
+    for (auto &kv : el_in) {
+        const int i = el.region_index(kv.first, REGION_INPUT);
+        LSSVC_CHECK(i >= 0 && kv.second, "engine_pframe_lookahead: enhancement-layer input %s", kv.first);
+        LSSVC_HIP(hipMemcpyAsync(el.regions[i].ptr, kv.second, el.regions[i].nbytes, hipMemcpyDefault, main));
+    }
+    LSSVC_HIP(hipEventRecord(e->ev_handed, main));
+    if (nxt) {
+        LSSVC_HIP(hipStreamWaitEvent(side, e->ev_handed, 0));
+        if (int rc = run_plan(*nxt, {{"x_bl", next_x_bl}}, {}, e->ahead_slots_host, side, true)) return rc;      // (references are in place; queued, not waited for)
+        LSSVC_HIP(hipEventRecord(e->ev_ahead, side));
+    }
+    // ---- EL(t) on the caller's stream (its inputs are in place: none is passed again)
+    double t[16];
+    if (int rc = run_plan(el, {}, {{"recon_el", recon_el}, {"feature_el", feature_el}, {"mv_hat", mv_hat}, {"warp_frame", warp_frame}}, t, main)) return rc;
+    bits[0] = s[0] + s[1] + s[2] + s[3];                 // dmc_net.py:473
+    bits[1] = t[4] + t[5] + t[6] + t[7];                 // LSSVC_net.py:508
+    if (nxt) {
+        LSSVC_HIP(hipEventSynchronize(e->ev_ahead));     // (normally long done: the base layer is a fifth of the frame)
+        for (int i = 0; i < 16; ++i) e->ahead_bits[i] = e->ahead_slots_host[i];
+        e->ahead = nxt;
+    }
     return 0;
 }
 

@@ -491,6 +491,78 @@ def compile_pframe(pnet, x_bl, x_el, dpb, path, arena_gib=None):
     return info, outs
 
 
+def compile_pframe_layers(pnet, x_bl, x_el, dpb, path_bl, path_el, arena_gib=None):
+    """Round 6: a P-frame as TWO plans, so that a caller without Python gets the look-ahead of
+    LSSVC_extend.forward_one_frame(next_x_bl=...): the BASE LAYER alone (DMC.get_inter_layer_information, dmc_net.py:421-488) and the
+    ENHANCEMENT LAYER given the base layer's results (LSSVC.forward_one_frame's own part, LSSVC_net.py:456-528). The engine
+    (lssvc_engine_pframe_lookahead) runs EL(t) on the caller's stream and BL(t+1) on a second one -- the base layer of a P-frame needs
+    the previous frame's BASE layer only -- and hands BL results from plan to plan as dense NHWC buffers.
+      base-layer plan   in: x_bl, ref_frame_bl (clamped to [0, 1] inside the plan: test.py:249-250's clamp, idempotent on a DPB the
+                        caller has clamped already), ref_feature_bl (steady-P only). out: bl_recon, bl_feature, bl_y_hat, bl_mv_hat
+                        (NHWC, what the enhancement layer reads) + recon_bl, feature_bl (NCHW, the caller's DPB); bit slots 0..3
+      enhancement plan  in: x_el, ref_frame_el, ref_feature_el (NCHW) + the four bl_* buffers. out: recon_el, feature_el, mv_hat,
+                        warp_frame (NCHW); bit slots 4..7
+    Same launches in the same order inside either layer as the whole-frame plan (compile_pframe): bit-identical results
+    (tests/test_gpu_engine.py). The DPB decides first-P / steady-P as in compile_pframe. Returns (info_bl, info_el, outs_bl, outs_el)."""
+    from .hip_ops import T
+    H, W = pnet.shape_hr
+    h, w = x_bl.shape[2], x_bl.shape[3]
+    dev = pnet.device
+    first = dpb["ref_feature_bl"] is None
+    keys = pnet.STASH_KEYS
+    ins_bl = {"x_bl": x_bl.contiguous(), "ref_frame_bl": dpb["ref_frame_bl"].contiguous()}
+    if not first:
+        ins_bl["ref_feature_bl"] = dpb["ref_feature_bl"].contiguous()
+
+    def bl_body():
+        t = {k: T.from_nchw(v) for k, v in ins_bl.items()}
+        ref = t["ref_frame_bl"]
+        ref = ops.clamp_(ops.copy(ref, T.empty(ref.H, ref.W, ref.C, dev)))
+        fk = ops.Fork(dev)
+        bl = pnet._bl_codec(t["x_bl"], ref, t.get("ref_feature_bl"), fk=fk)
+        fk.close()
+        return bl
+
+    probe = bl_body()                                      # eager, once: the shapes of the four results
+    shapes = {k: (probe[k].H, probe[k].W, probe[k].C) for k in keys}
+    del probe
+    flat = lambda k: torch.empty(shapes[k][0] * shapes[k][1] * shapes[k][2], dtype=torch.float32, device=dev)
+    as_t = lambda buf, k: T(buf, shapes[k][0], shapes[k][1], shapes[k][2], shapes[k][2])
+    outs_bl = {"bl_" + k: flat(k) for k in keys}
+    outs_bl.update(recon_bl=torch.empty(1, 3, h, w, device=dev), feature_bl=torch.empty(1, shapes["feature"][2], h, w, device=dev))
+
+    def run_bl():
+        bl = bl_body()
+        for k in keys:
+            ops.copy(bl[k], as_t(outs_bl["bl_" + k], k))
+        _nchw_out(bl["recon"], outs_bl["recon_bl"])
+        _nchw_out(bl["feature"], outs_bl["feature_bl"])
+
+    meta_bl = tuple(("bl_%s_%s" % (k, d), shapes[k][i]) for k in keys for i, d in enumerate(("h", "w", "c")))
+    info_bl = _record(pnet, ins_bl, run_bl, outs_bl, path_bl, "pframe_first_bl" if first else "pframe_bl",
+                      arena_gib if arena_gib is not None else max(0.5, 8.0 * H * W / (1152.0 * 1920.0)), meta=meta_bl)
+    ins_el = {"x_el": x_el.contiguous(), "ref_frame_el": dpb["ref_frame_el"].contiguous(), "ref_feature_el": dpb["ref_feature_el"].contiguous()}
+    ins_el.update({"bl_" + k: outs_bl["bl_" + k].clone() for k in keys})
+    outs_el = {"recon_el": torch.empty(1, 3, H, W, device=dev), "feature_el": torch.empty(1, 48, H, W, device=dev),
+               "mv_hat": torch.empty(1, 2, H, W, device=dev), "warp_frame": torch.empty(1, 3, H, W, device=dev)}
+
+    def run_el():
+        xe, ref_el, feat_el = (T.from_nchw(ins_el[k]) for k in ("x_el", "ref_frame_el", "ref_feature_el"))
+        bl = {k: as_t(ins_el["bl_" + k], k) for k in keys}
+        fk, pre = pnet._fork_el_head(xe, ref_el, feat_el)
+        feature, recon_el, mv_hat, warp_frame = pnet._el_codec(xe, bl, ref_el, feat_el, fk=fk, pre=pre)
+        fk.close()
+        _nchw_out(recon_el, outs_el["recon_el"])
+        _nchw_out(feature, outs_el["feature_el"])
+        _nchw_out(mv_hat, outs_el["mv_hat"])
+        _nchw_out(warp_frame, outs_el["warp_frame"])
+
+    info_el = _record(pnet, ins_el, run_el, outs_el, path_el, "pframe_first_el" if first else "pframe_el",
+                      arena_gib if arena_gib is not None else max(0.5, 24.0 * H * W / (1152.0 * 1920.0)),
+                      meta=(("ref_feature_el_channels", ins_el["ref_feature_el"].shape[1]),) + meta_bl)
+    return info_bl, info_el, outs_bl, outs_el
+
+
 # ---- write_stream = 1: encoder and decoder plans (GPU launches + the host coder's steps between them) ------------------------
 def _nchw_out(t, dst, clamp=False):
     _lib.check(_lib.lib.lssvc_nhwc_to_nchw(t.ref, C.c_void_p(dst.data_ptr()), ops.stream_ptr()))

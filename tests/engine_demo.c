@@ -5,6 +5,11 @@
  * host or device pointers).
  *
  *   engine_demo <intra.ckpt> <inter.ckpt> <iframe.plan> <first_p.plan> <steady_p.plan> <case.bin> <out.bin>
+ *               [<bl_first.plan> <bl_steady.plan> <el_first.plan> <el_steady.plan>]
+ *
+ * With the four layer plans (round 6; plan_compiler.compile_pframe_layers) the P-frames go through lssvc_engine_pframe_lookahead: the
+ * loop has all frames at hand, as test.py's has, so it names frame t+1's base-layer input in the call of frame t and the engine codes
+ * that base layer on its second stream beside frame t's enhancement layer. Same out.bin, bit for bit.
  *
  * *.ckpt: the two RAW checkpoints (tests/ckpt_blob.h: the reference's state dicts dumped tensor by tensor, OIHW fp32, no
  *         re-layout); the engine prepares its device weights from them (lssvc_engine_load_checkpoint) and the plan files hold
@@ -39,10 +44,12 @@ static void clamp01(float *x, size_t n) {
 }
 
 int main(int argc, char **argv) {
-    if (argc != 8) {
-        fprintf(stderr, "usage: engine_demo <intra.ckpt> <inter.ckpt> <iframe.plan> <first_p.plan> <steady_p.plan> <case.bin> <out.bin>\n");
+    if (argc != 8 && argc != 12) {
+        fprintf(stderr, "usage: engine_demo <intra.ckpt> <inter.ckpt> <iframe.plan> <first_p.plan> <steady_p.plan> <case.bin> <out.bin> "
+                        "[<bl_first.plan> <bl_steady.plan> <el_first.plan> <el_steady.plan>]\n");
         return 2;
     }
+    const int lookahead = argc == 12;
     const char *ckpt_i = argv[1], *ckpt_p = argv[2];
     argv += 2;
     FILE *in = fopen(argv[4], "rb"), *out = fopen(argv[5], "wb");
@@ -72,6 +79,7 @@ int main(int argc, char **argv) {
     }
     if (lssvc_engine_load_intra(eng, argv[1])) die("load_intra");
     if (n_frames > 1 && lssvc_engine_load_inter(eng, argv[2], argv[3])) die("load_inter");
+    if (n_frames > 1 && lookahead && lssvc_engine_load_inter_layers(eng, argv[6], argv[7], argv[8], argv[9])) die("load_inter_layers");
     if (lssvc_engine_set_scale(eng, scale, H, W)) die("set_scale");
     for (int which = 0; which < (n_frames > 1 ? 3 : 1); ++which) {
         int64_t info[6];
@@ -80,12 +88,15 @@ int main(int argc, char **argv) {
                (long long)info[1], info[2] / 1e6, info[3] / 1e6, (long long)info[4], (long long)info[5]);
     }
 
-    float *x_bl = alloc_f(3 * bl), *x_el = alloc_f(3 * el);
+    float *all_bl = alloc_f((size_t)n_frames * 3 * bl), *all_el = alloc_f((size_t)n_frames * 3 * el);      /* the loop has every frame at hand, as test.py's */
+    for (int t = 0; t < n_frames; ++t)
+        if (fread(all_bl + (size_t)t * 3 * bl, 4, 3 * bl, in) != 3 * bl || fread(all_el + (size_t)t * 3 * el, 4, 3 * el, in) != 3 * el) return 2;
     float *ref_bl = alloc_f(3 * bl), *ref_el = alloc_f(3 * el), *feat_bl = alloc_f(64 * bl), *feat_el = alloc_f(64 * el);
     float *mv = alloc_f(2 * el), *warp = alloc_f(3 * el);
     int have_feat_bl = 0;
     for (int t = 0; t < n_frames; ++t) {
-        if (fread(x_bl, 4, 3 * bl, in) != 3 * bl || fread(x_el, 4, 3 * el, in) != 3 * el) return 2;
+        const float *x_bl = all_bl + (size_t)t * 3 * bl, *x_el = all_el + (size_t)t * 3 * el;
+        const float *next_bl = t + 1 < n_frames ? all_bl + (size_t)(t + 1) * 3 * bl : NULL;
         double bits[2];
         size_t cf;
         if (t == 0) {                                            /* test.py:219-227 */
@@ -94,8 +105,12 @@ int main(int argc, char **argv) {
             have_feat_bl = 0;
         } else {                                                 /* test.py:229-247: the DPB of frame t-1 goes in, the new one comes out */
             float *n_ref_bl = alloc_f(3 * bl), *n_ref_el = alloc_f(3 * el), *n_feat_bl = alloc_f(64 * bl), *n_feat_el = alloc_f(48 * el);
-            if (lssvc_engine_pframe(eng, x_bl, x_el, ref_bl, ref_el, have_feat_bl ? feat_bl : NULL, feat_el, bits, n_ref_bl, n_feat_bl,
-                                    n_ref_el, n_feat_el, mv, warp, NULL))
+            if (lookahead) {
+                if (lssvc_engine_pframe_lookahead(eng, x_bl, x_el, next_bl, ref_bl, ref_el, have_feat_bl ? feat_bl : NULL, feat_el, bits, n_ref_bl,
+                                                  n_feat_bl, n_ref_el, n_feat_el, mv, warp, NULL))
+                    die("pframe_lookahead");
+            } else if (lssvc_engine_pframe(eng, x_bl, x_el, ref_bl, ref_el, have_feat_bl ? feat_bl : NULL, feat_el, bits, n_ref_bl, n_feat_bl,
+                                           n_ref_el, n_feat_el, mv, warp, NULL))
                 die("pframe");
             memcpy(ref_bl, n_ref_bl, 3 * bl * 4);
             memcpy(ref_el, n_ref_el, 3 * el * 4);

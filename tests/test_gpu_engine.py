@@ -111,6 +111,86 @@ def test_c_program_codes_a_gop_through_compiled_plans(tmp_path):
     assert pos == raw.size
 
 
+def test_c_program_codes_a_gop_with_the_base_layer_a_frame_ahead(tmp_path):
+    """Round 6: the look-ahead of LSSVC_extend.forward_one_frame(next_x_bl=...) for a caller without Python. The
+    P-frame is compiled as a base-layer plan and an enhancement-layer plan per frame type (plan_compiler.compile_pframe_layers);
+    tests/engine_demo.c, given those four plans, codes I + 6 P through lssvc_engine_pframe_lookahead -- BL(t+1) on the engine's second
+    stream beside EL(t) -- and a second run of the same program codes the same clip through lssvc_engine_pframe. Both outputs must
+    equal the Python path's, bit for bit: every bit count, every DPB tensor, mv_hat and warp_frame of every frame (the first call of
+    a plan is eager, the second captures, later ones replay: seven frames pass through all three)."""
+    from lssvc_amd import IntraSS, LSSVC_extend, plan_compiler
+    from lssvc_amd.synth import synth_state_dict
+    z, m = load_case("x2_128_ipp")
+    H, W, h, w = m["H"], m["W"], m["h"], m["w"]
+    inet = IntraSS.from_state_dict(synth_state_dict("intra_ss", m["seed"], m["gain"])).to(DEV).eval()
+    pnet = LSSVC_extend()
+    pnet.load_dict(synth_state_dict("lssvc_extend", m["seed"], m["gain"]))
+    pnet.to(DEV).eval()
+    order = [0, 1, 2, 1, 2, 1, 2]
+    x_el = [(torch.from_numpy(z["x_el_u8"][t:t + 1]).float() / 255.0).to(DEV) for t in order]
+    x_bl = [torch.from_numpy(z["x_bl"][t:t + 1]).to(DEV) for t in order]
+    for net in (inet, pnet):
+        net.set_scale_information(m["scale"], (H, W), (0, 0, 0, 0))
+    want, dpbs, dpb = [], [], None
+    for t in range(len(order)):
+        if t == 0:
+            r = inet.encode_decode(x_bl[t], x_el[t], None, None, h, w, H, W)
+            dpb = {"ref_frame_bl": r["x_hat_bl"], "ref_frame_el": r["x_hat_el"], "ref_feature_bl": None, "ref_feature_el": r["feature_el"]}
+            extra = []
+        else:
+            r = pnet.encode_decode(x_bl[t], x_el[t], dpb, None, None, W, H, w, h)
+            dpb = r["dpb"]
+            extra = [dpb["ref_feature_bl"], r["mv_hat"], r["warp_frame"]]
+        want.append((r["bit_bl"], r["bit_el"], [v.contiguous().clone() for v in (dpb["ref_frame_bl"], dpb["ref_frame_el"], dpb["ref_feature_el"])]
+                     + [v.contiguous().clone() for v in extra]))
+        dpb["ref_frame_bl"].clamp_(0, 1)
+        dpb["ref_frame_el"].clamp_(0, 1)
+        dpbs.append({k: (None if v is None else v.contiguous().clone()) for k, v in dpb.items()})
+    plans = [str(tmp_path / n) for n in ("iframe.plan", "first_p.plan", "steady_p.plan", "bl_first.plan", "bl_steady.plan", "el_first.plan", "el_steady.plan")]
+    plan_compiler.compile_iframe(inet, x_bl[0], x_el[0], plans[0])
+    plan_compiler.compile_pframe(pnet, x_bl[1], x_el[1], dpbs[0], plans[1])
+    plan_compiler.compile_pframe(pnet, x_bl[2], x_el[2], dpbs[1], plans[2])
+    i_bl1, i_el1, _, _ = plan_compiler.compile_pframe_layers(pnet, x_bl[1], x_el[1], dpbs[0], plans[3], plans[5])
+    i_bl2, i_el2, _, _ = plan_compiler.compile_pframe_layers(pnet, x_bl[2], x_el[2], dpbs[1], plans[4], plans[6])
+    print("layer plans:", i_bl1, i_el1, i_bl2, i_el2)
+    assert i_bl2["launches"] + i_el2["launches"] > 300 and i_bl2["launches"] > 50
+    ckpts = [str(tmp_path / "intra.ckpt"), str(tmp_path / "inter.ckpt")]
+    write_checkpoint_blob(synth_state_dict("intra_ss", m["seed"], m["gain"]), ckpts[0])
+    write_checkpoint_blob(synth_state_dict("lssvc_extend", m["seed"], m["gain"]), ckpts[1])
+    case, exe = str(tmp_path / "case.bin"), str(tmp_path / "engine_demo")
+    with open(case, "wb") as f:
+        f.write(struct.pack("<5if", len(order), H, W, h, w, m["scale"]))
+        for t in range(len(order)):
+            f.write(x_bl[t].cpu().contiguous().numpy().tobytes())
+            f.write(x_el[t].cpu().contiguous().numpy().tobytes())
+    libdir = os.path.join(ROOT, "lssvc_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "engine_demo.c"),
+                           "-L", libdir, "-llssvc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    outs = {}
+    for mode, extra_plans in (("whole frames", []), ("base layer a frame ahead", plans[3:])):
+        outp = str(tmp_path / ("out_%d.bin" % len(extra_plans)))
+        res = subprocess.run([exe] + ckpts + plans[:3] + [case, outp] + extra_plans, capture_output=True, text=True, env=env, timeout=600)
+        print(mode, res.stdout[-600:], res.stderr)
+        assert res.returncode == 0, res.stderr
+        outs[mode] = np.fromfile(outp, dtype=np.uint8)
+    assert np.array_equal(outs["whole frames"], outs["base layer a frame ahead"]), "the look-ahead entry point does not reproduce lssvc_engine_pframe"
+    raw, pos = outs["base layer a frame ahead"], 0
+    for t in range(len(order)):
+        bits = raw[pos:pos + 16].view(np.float64)
+        pos += 16
+        shapes = [(1, 3, h, w), (1, 3, H, W), (1, 64 if t == 0 else 48, H, W)] + ([(1, 64, h, w), (1, 2, H, W), (1, 3, H, W)] if t else [])
+        wb, we, tens = want[t]
+        assert (float(bits[0]), float(bits[1])) == (wb, we), (t, bits, wb, we)
+        for shp, x in zip(shapes, tens):
+            n = int(np.prod(shp)) * 4
+            g = torch.from_numpy(raw[pos:pos + n].view(np.float32).reshape(shp).copy())
+            pos += n
+            assert torch.equal(g, x.cpu()), (t, shp, (g - x.cpu()).abs().max().item())
+    assert pos == raw.size
+
+
 def test_c_programs_write_and_read_real_bitstreams(tmp_path):
     """write_stream = 1 through the engine: encoder and decoder plans compiled by the front end
     (plan_compiler.compile_iframe_stream / compile_pframe_stream), then tests/engine_stream_demo.c -- plain C -- runs TWICE as
