@@ -127,12 +127,12 @@ int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
         LSSVC_P3_CASE(4) LSSVC_P3_CASE(3) LSSVC_P3_CASE(2) LSSVC_P3_CASE(1)
 #undef LSSVC_P3_CASE
     }
-    if (p3_narrow_wanted(p)) {
+    if (p3_narrow_wanted(p) && !(p.debug & 256)) {      // (the stamp build, LSSVC_CONV_DEBUG = 256, has the 24x16 kernel's schedule only)
         const int pf = option_get(OPT_P3_PF2) ? 1 : 0;      // register prefetch: +3 ... +8 % on these (profiles/r06_narrow_ab.txt); pair loads are not built for them (slower)
         snprintf(kernel_name, 96, "conv3n_f16x3p_kernel<%s, %s>%s", inact ? "true" : "false", p.fast_epi ? "fast" : "flat", pf == 1 ? " pf2" : "");
         return launch_p3_narrow(p, inact, !p.fast_epi, pf, st);
     }
-    if (P3Small c; !p.in_split && p3_pick_tiling(p, c) && c.rpw != LSSVC_P3_RPW) {
+    if (P3Small c; !p.in_split && !(p.debug & 256) && p3_pick_tiling(p, c) && c.rpw != LSSVC_P3_RPW) {
         // p3_small: 1 = the register prefetch from 8 phases on (+3 ... +8 %; below that it is neutral: profiles/r06_small_map_ab.txt), 2 = always,
         // 3 = never
         const int sm = option_get(OPT_P3_SMALL);
