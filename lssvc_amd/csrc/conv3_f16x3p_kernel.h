@@ -138,10 +138,17 @@ template <int MF, bool INACT, bool STAMP = false, bool STAGE = false, int S = 1,
 __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(const ConvP p) {
     static_assert(!(STAGE && S != 1), "the staged epilogue is laid out for stride 1");
     static_assert(!(SPLIT && INACT), "a pre-split input carries its activation already");
-    constexpr bool PF2 = PF == 1, PAIR = PF == 2;
+    constexpr bool PF2 = PF == 1, PAIR = PF == 2, ROLES = PF == 3;
     static_assert(!(PF && (STAGE || SPLIT || STAMP)), "the register prefetch / pair loads are written for the plain two-buffer schedule");
     using G = P3Geom<MF, S, RPWT>;
-    constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP, NP = G::NP;
+    constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP;
+    // ROLES (PF = 3, round 6): producer wave 3 moves ALL of a phase's weights (LDS-DMA only), waves 0-2 stage the patch (plain loads
+    // only). A wave whose instruction stream holds no LDS-DMA gets exact in-order vmcnt waits from the compiler -- with a DMA outstanding
+    // it guards every use of a loaded register with vmcnt(0), which is what kept the register prefetch (PF = 1) from ever having two
+    // fills in flight: the second step of its unrolled loop drains.
+    constexpr int PT = ROLES ? kP3ProducerThreads - 64 : kP3ProducerThreads;      // threads that stage the patch
+    constexpr int NP = (G::PATCH_ITEMS + PT - 1) / PT;                             // float4 items per staging thread and phase
+    constexpr int NDMA = ROLES ? G::W_INSTR : G::NDMA;                             // weight-DMA instructions per DMA-issuing wave and phase
     constexpr int SR = STAGE ? G::SR : 0;
     constexpr int NPB = (STAGE || PF) ? 2 : G::NPB;                                 // patch buffers (P3Geom: PATCH RING)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
         // phase k+2 is loaded while the weights of phase k+1 are staged, so the two halves are cached per tile separately.
         // SPLIT: 16-byte units of one plane / both planes of the LDS patch image, wave-level DMA instructions, per producer wave
         constexpr int UPP = G::PH * PW * 2, UT = 2 * UPP, P_INSTR = (UT + 63) / 64, NPDMA = (P_INSTR + G::NPROD - 1) / G::NPROD;
-        int ppix[NP], woff[G::NDMA], pcode[SPLIT ? NPDMA : 1];
+        int ppix[NP], woff[NDMA], pcode[SPLIT ? NPDMA : 1];
         int pgeom_it = -1, wgeom_it = -1;
         auto patch_geometry = [&](int it) {
             int oy0, ox0, m0;
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
             }
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int idx = lt + i * kP3ProducerThreads;
+                const int idx = lt + i * PT;
                 const int pix = idx >> 2;
                 const int py = pix / PW, px = pix - py * PW;
                 const int gy = oy0 * S - p.pad_t + py, gx = ox0 * S - p.pad_l + px;
@@ -281,8 +288,8 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
             int oy0, ox0, m0;
             tile_origin(it, oy0, ox0, m0);
 #pragma unroll
-            for (int t = 0; t < G::NDMA; ++t) {
-                int j = pw + G::NPROD * t;                       // wave-uniform DMA instruction index
+            for (int t = 0; t < NDMA; ++t) {
+                int j = ROLES ? t : pw + G::NPROD * t;           // wave-uniform DMA instruction index
                 if (j >= G::W_INSTR) j = G::W_INSTR - 1;         // surplus slots rewrite the last KiB with the same bytes
                 const int i = j * 64 + lane;                     // 16-byte item of the [hi plane | lo plane] image
                 const int plane = i >= G::W_ITEMS ? 1 : 0;
@@ -305,8 +312,8 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                 unsigned char *dst = reinterpret_cast<unsigned char *>(wts_buf(buf));
                 const _Float16 *src0 = w16 + (size_t)ph.k.kc * NTAP * p.M_pad * CK16;
 #pragma unroll
-                for (int t = 0; t < G::NDMA; ++t) {
-                    int j = pw + G::NPROD * t;
+                for (int t = 0; t < NDMA; ++t) {
+                    int j = ROLES ? t : pw + G::NPROD * t;
                     if (j >= G::W_INSTR) j = G::W_INSTR - 1;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + woff[t]),
                                                      (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
             _Float16 *pl_ = ph_ + G::PATCH_HALFS;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int idx = lt + i * kP3ProducerThreads;
+                const int idx = lt + i * PT;
                 const bool live = (pmask >> i) & 1u;
                 const float raw[4] = {preg[i].x, preg[i].y, preg[i].z, preg[i].w};
                 f16x4 h, l;
@@ -591,6 +598,56 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                 long long *o = reinterpret_cast<long long *>(p.gdn_x.p) + ((size_t)gridDim.x * kP3Consumers + (size_t)blockIdx.x * 4 + pw) * 8;
                 o[0] = s_dma; o[1] = s_ld; o[2] = s_wait; o[3] = s_cvt; o[4] = s_bar; o[5] = total; o[6] = s_geo; o[7] = 0;
             }
+            return;
+        }
+        if constexpr (ROLES) {
+            if (pw == G::NPROD - 1) {
+                // ---- the DMA wave: all of every phase's weights, nothing else
+                stage_weights(ph, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                           // (A)
+                for (int k = 0; k + 1 < total; ++k) {
+                    if (k >= 1) wait_for(sync_s + 4, k);   // weight buffer (k+1)&1 was read in phase k-1
+                    ph = next_phase(ph);
+                    stage_weights(ph, (k + 1) & 1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    signal(sync_s + pw, k + 1);
+                }
+                return;
+            }
+            // ---- the patch waves: two register sets, the patch of phase k+2 requested before the patch of phase k+1 is converted
+            float4 preg2[NP];
+            unsigned pmask2 = 0;
+            P3Phase php = ph;
+            load_patch_to(php, preg, pmask);
+            store_patch_from(0, preg, pmask);
+            if (total > 1) {
+                php = next_phase(php);
+                load_patch_to(php, preg, pmask);           // patch of phase 1: in flight across barrier (A)
+            }
+            __builtin_amdgcn_s_waitcnt(p3_waitcnt(63, 0)); // this wave's LDS stores of phase 0 are done (no wait for the loads)
+            __syncthreads();                               // (A)
+            auto step = [&](int k, float4 (&cur)[NP], unsigned &cmask, float4 (&nxt)[NP], unsigned &nmask, auto load) __attribute__((always_inline)) {
+                if (k >= 1) wait_for(sync_s + 4, k);       // patch buffer (k+1)&1 was read in phase k-1
+                if constexpr (decltype(load)::value) {
+                    if (k + 2 < total) php = next_phase(php);
+                    load_patch_to(php, nxt, nmask);        // (unconditional: see the PF2 schedule)
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(p3_waitcnt(NP, 15));      // the patch of phase k+1 has landed; the NP new loads stay in flight
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    __builtin_amdgcn_s_waitcnt(p3_waitcnt(0, 15));
+                }
+                store_patch_from((k + 1) & 1, cur, cmask);
+                __builtin_amdgcn_s_waitcnt(p3_waitcnt(63, 0));           // this wave's LDS stores are done
+                signal(sync_s + pw, k + 1);
+            };
+            int k = 0;
+            for (; k + 2 < total; k += 2) {
+                step(k, preg, pmask, preg2, pmask2, std::true_type{});
+                step(k + 1, preg2, pmask2, preg, pmask, std::true_type{});
+            }
+            if (k + 1 < total) step(k, preg, pmask, preg2, pmask2, std::false_type{});
             return;
         }
         if constexpr (PAIR) {

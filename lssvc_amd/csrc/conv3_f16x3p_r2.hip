@@ -10,7 +10,7 @@ int launch_p3_narrow(const ConvP &p, bool inact, bool flat, int pf, hipStream_t 
         if (flat) return inact ? launch_p3r<1, true, 1, 4, f, true, true>(p, st) : launch_p3r<1, false, 1, 4, f, true, true>(p, st);        \
         return inact ? launch_p3r<1, true, 1, 4, f, false, true>(p, st) : launch_p3r<1, false, 1, 4, f, false, true>(p, st);                \
     }
-    LSSVC_P3N_CASE(1) LSSVC_P3N_CASE(0)
+    LSSVC_P3N_CASE(3) LSSVC_P3N_CASE(1) LSSVC_P3N_CASE(0)
 #undef LSSVC_P3N_CASE
     return fail("conv2d(f16x3p narrow): prefetch mode %d", pf);
 }
@@ -18,7 +18,7 @@ int launch_p3_narrow(const ConvP &p, bool inact, bool flat, int pf, hipStream_t 
 int launch_p3s2_pf(const ConvP &p, int mf, bool inact, int pf, hipStream_t st) {
 #define LSSVC_P3S_CASE(m, f) \
     if (mf == m && pf == f) return inact ? launch_p3r<m, true, 2, 0, f, false, false>(p, st) : launch_p3r<m, false, 2, 0, f, false, false>(p, st);
-    LSSVC_P3S_CASE(4, 1) LSSVC_P3S_CASE(4, 2) LSSVC_P3S_CASE(3, 1) LSSVC_P3S_CASE(3, 2)
+    LSSVC_P3S_CASE(4, 1) LSSVC_P3S_CASE(4, 2) LSSVC_P3S_CASE(3, 1) LSSVC_P3S_CASE(3, 2) LSSVC_P3S_CASE(4, 3) LSSVC_P3S_CASE(3, 3)
 #undef LSSVC_P3S_CASE
     return fail("conv2d(f16x3p, stride 2, prefetch %d): no kernel for MF=%d", pf, mf);
 }

@@ -388,7 +388,7 @@ bool conv7_f16x3p_wanted(const ConvP &p) {
     if (!on || !p.fast_epi || p.res2.p != nullptr) return false;
     if (p.in_act == LSSVC_INACT_LRELU && !(p.in_slope >= 0.0f && p.in_slope <= 1.0f)) return false;
     const int frags = p.M_pad / 16, mf = frags >= 4 ? 4 : frags;
-    if (frags < 2) return false;       // 16 output channels: the producers' patch conversion outweighs 11 MFMAs per row; tiled kernel wins
+    if (frags < 2 && !option_get(OPT_P7_NARROW)) return false;       // 16 output channels: the producers' patch conversion outweighs 11 MFMAs per row; tiled kernel wins (round 6 re-measured: option p7_narrow)
     const long long ntiles = (long long)((p.Wout + 15) / 16) * ((p.Hout + 23) / 24) * ((frags + mf - 1) / mf);
     return ntiles >= min_tiles;
 }
@@ -399,7 +399,7 @@ int dispatch_conv7_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
     snprintf(kernel_name, 96, "conv7_f16x3p_kernel<%d, %s>", mf, inact ? "true" : "false");
 #define LSSVC_P7_CASE(m) \
     if (mf == m) return inact ? launch_p7<m, true>(p, st) : launch_p7<m, false>(p, st);
-    LSSVC_P7_CASE(4) LSSVC_P7_CASE(3) LSSVC_P7_CASE(2)
+    LSSVC_P7_CASE(4) LSSVC_P7_CASE(3) LSSVC_P7_CASE(2) LSSVC_P7_CASE(1)
 #undef LSSVC_P7_CASE
     return fail("conv2d(f16x3p 7x7): no kernel for MF=%d", mf);
 }

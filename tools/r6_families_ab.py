@@ -21,7 +21,7 @@ from lssvc_amd import hip_ops as ops  # noqa: E402
 from lssvc_amd._lib import lib, check  # noqa: E402
 from lssvc_amd.weights import WeightStore  # noqa: E402
 
-DEFAULTS = {"p3_small": 1, "p3_narrow": 1, "p3_pf2": 1, "p3_force": 0, "p3_big_pair": 0, "f16x3_persist": 1, "f16x3_persist_s2": 1, "gdn_fast": 1}
+DEFAULTS = {"p3_small": 1, "p3_narrow": 1, "p3_pf2": 1, "p3_force": 0, "p3_big_pair": 0, "f16x3_persist": 1, "f16x3_persist_s2": 1, "gdn_fast": 1, "p7_narrow": 0}
 
 
 def set_opts(**kw):
@@ -82,7 +82,7 @@ def main():
                                      ([64], 8, 576, 960, {}), ([64], 2, 576, 960, {}), ([64], 2, 288, 480, {}), ([32, 32], 16, 1152, 1920, {"act": "lrelu"})):
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
-            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("tiled / p3 rpw 6", {"p3_narrow": 0}), ("conv3n", {"p3_pf2": 0}), ("conv3n pf2", {"p3_pf2": 1})], rounds, reps,
+            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("tiled / p3 rpw 6", {"p3_narrow": 0}), ("conv3n", {"p3_pf2": 0}), ("conv3n pf2", {"p3_pf2": 1}), ("conv3n roles", {"p3_pf2": 3})], rounds, reps,
                      2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
     elif what in ("small", "small_sweep", "mid", "mid_sweep"):
         mid = (([64], 64, 288, 480, {}), ([64], 64, 288, 480, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}), ([96], 96, 288, 480, {}), ([128], 128, 288, 480, {}),
@@ -109,7 +109,7 @@ def main():
                                  ([96], 128, 288, 480), ([4, 48], 64, 1152, 1920), ([128], 128, 288, 480)):
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 2, g, dev, act="lrelu", slope=0.1)
-            run_arms("3x3 s2 %s->%d in %dx%d" % (cins, cout, H, W), call, [("one register set", {"p3_pf2": 0}), ("register prefetch", {"p3_pf2": 1}), ("pair loads", {"p3_pf2": 2}), ("tiled", {"f16x3_persist_s2": 0})],
+            run_arms("3x3 s2 %s->%d in %dx%d" % (cins, cout, H, W), call, [("one register set", {"p3_pf2": 0}), ("register prefetch", {"p3_pf2": 1}), ("pair loads", {"p3_pf2": 2}), ("split roles", {"p3_pf2": 3}), ("tiled", {"f16x3_persist_s2": 0})],
                      rounds, reps, 2.0 * (H // 2) * (W // 2) * cout * 9 * cin, 4e-6 * (H * W * cin + (H // 2) * (W // 2) * cout))
     elif what == "big":
         for cins, cout, H, W, kw in (([64], 64, 1152, 1920, {}), ([64], 64, 576, 960, {}), ([128], 64, 576, 960, {}), ([128], 192, 576, 960, {}), ([64], 64, 288, 480, {})):      # (the MF = 4, no-input-activation shapes: the one instantiation kept)
@@ -117,6 +117,14 @@ def main():
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
             run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("r5 schedule", {}), ("pair loads", {"p3_big_pair": 1})], rounds, reps,
                      2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
+    elif what == "p7n":
+        for cins, cout, H, W in (([32], 16, 1152, 1920), ([32], 16, 576, 960), ([32], 16, 288, 480), ([8], 16, 1152, 1920)):
+            cin = sum(cins)
+            w = torch.randn(cout, cin, 7, 7, generator=g) / math.sqrt(cin * 49)
+            Wt = WeightStore({"c.weight": w, "c.bias": torch.randn(cout, generator=g)}, dev)
+            xs = [ops.T(torch.randn(H * W * c, device=dev), H, W, c, c) for c in cins]
+            call = lambda out: ops.conv(Wt, "c", xs, act="relu", out=out)
+            run_arms("7x7 %s->%d @%dx%d" % (cins, cout, H, W), call, [("tiled", {}), ("persistent MF = 1", {"p7_narrow": 1})], rounds, reps, 2.0 * H * W * cout * 49 * cin, 4e-6 * H * W * (cin + cout))
     elif what == "tall":
         for cins, cout, H, W, kw in (([48], 48, 1152, 1920, {}), ([48], 48, 1152, 1920, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}), ([48, 48], 48, 1152, 1920, {}),
                                      ([64, 16], 48, 1152, 1920, {}), ([96], 96, 288, 480, {}), ([192], 96, 288, 480, {"in_act": "lrelu", "in_slope": 0.1}), ([64], 48, 1152, 1920, {}),
