@@ -490,8 +490,11 @@ int lssvc_engine_decode_pframe(void *engine, const uint8_t *bl_file, int64_t bl_
  *                                    register prefetch always / never (1: from 8 phases on) (LSSVC_P3_SMALL)
  *   "p3_narrow"                1/0   3x3 stride-1 convs with <= 16 output channels on the narrow-head instantiation (16x16 tiles, two
  *                                    workgroups per CU; the tiled kernel's epilogue when Cout % 4 != 0) (LSSVC_P3_NARROW)
- *   "p3_pf2"                   0/1/2 producers of the stride-2 and narrow-head instantiations: one register set (round 5) / register
- *                                    prefetch (default) / pair loads (measured slower; stride 2 only) (LSSVC_P3_PF2)
+ *   "p3_pf2"                   0..4  producers of the stride-2 and narrow-head instantiations: 0 one register set (round 5); 1 (default)
+ *                                    split roles -- one producer wave owns the weight DMA, three stage the patch through two register
+ *                                    sets -- up to five 16-channel phases per tile and the register prefetch from six on; 2 pair loads
+ *                                    (measured slower; stride 2 only); 3 roles always; 4 register prefetch always (LSSVC_P3_PF2)
+ *   "p7_narrow"                1/0   experiment: 7x7 persistent kernel with one 16-channel fragment for Cout <= 16 (slower) (LSSVC_P7_NARROW)
  *   "p3_force"                 n     experiments: force the small tiling MF * 16 + rows-per-wave (0 = the cost model) (LSSVC_P3_FORCE)
  *   "p3_big_pair"              1/0   experiment: the 24x16 tiling with pair loads (MF = 4, no input activation; slower) (LSSVC_P3_BIG_PAIR)
  *   "gdn_fast"                 1/0   GDN / IGDN epilogue as straight-line code where the views allow it (LSSVC_GDN_FAST_OPT)

@@ -108,9 +108,14 @@ int dispatch_conv3s2_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
         if (mf == 3) return launch_p3<3, false, 2, true>(p, st);
         return fail("conv2d(f16x3p, stride 2, split in): no kernel for MF=%d", mf);
     }
-    if (const int pf = option_get(OPT_P3_PF2); pf && !(p.debug & 256)) {    // round 6: register prefetch (1) / pair loads (2) (conv3_f16x3p_kernel.h); the stamp build has the plain schedule
+    // round 6 producer schedules (conv3_f16x3p_kernel.h), option p3_pf2: 0 = round 5's one register set; 1 (default) = split roles (one producer
+    // wave owns the weight DMA, three stage the patch through two register sets) up to five 16-channel phases per tile, the register prefetch
+    // from six on (128-channel inputs: the prefetch is +13 %, the roles +7 %; profiles/r06_roles_ab.txt); 2 = pair loads; 3 = roles always;
+    // 4 = register prefetch always. The stamp build has the plain schedule only.
+    if (const int opt = option_get(OPT_P3_PF2); opt && !(p.debug & 256)) {
+        const int pf = opt == 2 ? 2 : opt == 3 ? 3 : opt == 4 ? 1 : (p.n_chunks16 <= 5 ? 3 : 1);
         snprintf(kernel_name, 96, "conv3s2_f16x3p_kernel<%d, %s> %s", mf, inact ? "true" : "false", pf == 2 ? "pair" : pf == 3 ? "roles" : "pf2");
-        return launch_p3s2_pf(p, mf, inact, pf == 2 ? 2 : pf == 3 ? 3 : 1, st);
+        return launch_p3s2_pf(p, mf, inact, pf, st);
     }
     if (mf == 4) return inact ? launch_p3<4, true, 2>(p, st) : launch_p3<4, false, 2>(p, st);
     if (mf == 3) return inact ? launch_p3<3, true, 2>(p, st) : launch_p3<3, false, 2>(p, st);
@@ -128,7 +133,8 @@ int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
 #undef LSSVC_P3_CASE
     }
     if (p3_narrow_wanted(p) && !(p.debug & 256)) {      // (the stamp build, LSSVC_CONV_DEBUG = 256, has the 24x16 kernel's schedule only)
-        const int pf = option_get(OPT_P3_PF2) == 3 ? 3 : option_get(OPT_P3_PF2) ? 1 : 0;      // register prefetch: +3 ... +8 % on these (profiles/r06_narrow_ab.txt); pair loads are not built for them (slower)
+        const int opt = option_get(OPT_P3_PF2);
+        const int pf = !opt ? 0 : (opt == 4 || opt == 2) ? 1 : 3;      // split roles: +5 ... +8 % over the register prefetch on these (profiles/r06_roles_ab.txt); pair loads are not built for them (slower)
         snprintf(kernel_name, 96, "conv3n_f16x3p_kernel<%s, %s>%s", inact ? "true" : "false", p.fast_epi ? "fast" : "flat", pf == 3 ? " roles" : pf == 1 ? " pf2" : "");
         return launch_p3_narrow(p, inact, !p.fast_epi, pf, st);
     }

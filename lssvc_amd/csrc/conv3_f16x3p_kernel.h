@@ -89,7 +89,17 @@ struct P3Geom {
 };
 
 // s_waitcnt immediate of gfx9 / gfx950: vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8 (15 = no wait)
-constexpr int p3_waitcnt(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | (((vm >> 4) & 3) << 14); }
+// COUNTED waits (0 < vm < 63: some loads are meant to stay in flight) carry expcnt(6) instead of 7: a compute kernel has no exports, the
+// counter is always 0 and the field costs nothing, but the disassembly shows `s_waitcnt vmcnt(N) expcnt(6)` -- the mark by which
+// tools/p3_waitcnt_check.py tells the hand-written counted waits from the compiler's own and checks N against the loads in front of them.
+// Diagnostic builds only (make P3_ABLATE=n into a separate library, tools/r6_roles_ablation.sh): the split-roles schedule with one of its
+// parts switched off -- 1: no weight DMA after the first phase, 2: no MFMAs, 4: no patch loads after the first two, 8: no conversion / LDS
+// stores of the patch. Results are wrong by design; the shipped library is built with 0 and none of this exists in its code.
+#ifndef LSSVC_P3_ABLATE
+#define LSSVC_P3_ABLATE 0
+#endif
+constexpr int kP3Ablate = LSSVC_P3_ABLATE;
+constexpr int p3_waitcnt(int vm, int lgkm) { return (vm & 15) | ((vm > 0 && vm < 63 ? 6 : 7) << 4) | ((lgkm & 15) << 8) | (((vm >> 4) & 3) << 14); }
 
 struct P3Phase {
     int it;        // index into this workgroup's tile sequence
@@ -568,8 +578,8 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                 // fill(k+1) = the weights just requested + the patch of phase k+1, whose LDS stores were waited for at the end of the previous
                 // iteration: signalled as soon as the weight DMA has landed -- the NP (SPLIT: NPDMA) younger patch requests stay in flight
                 if (more) {
-                    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_INSTR % G::NPROD == 0 ? NPDMA : NPDMA - 1) : "memory");      // (some waves issue one patch DMA fewer)
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+                    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"(P_INSTR % G::NPROD == 0 ? NPDMA : NPDMA - 1) : "memory");      // (some waves issue one patch DMA fewer)
+                    else asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"(NP) : "memory");      // (expcnt(6): the counted-wait mark, see p3_waitcnt)
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                 for (int k = 0; k + 1 < total; ++k) {
                     if (k >= 1) wait_for(sync_s + 4, k);   // weight buffer (k+1)&1 was read in phase k-1
                     ph = next_phase(ph);
-                    stage_weights(ph, (k + 1) & 1);
+                    if constexpr (!(kP3Ablate & 1)) stage_weights(ph, (k + 1) & 1);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     signal(sync_s + pw, k + 1);
                 }
@@ -631,14 +641,20 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                 if (k >= 1) wait_for(sync_s + 4, k);       // patch buffer (k+1)&1 was read in phase k-1
                 if constexpr (decltype(load)::value) {
                     if (k + 2 < total) php = next_phase(php);
-                    load_patch_to(php, nxt, nmask);        // (unconditional: see the PF2 schedule)
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_waitcnt(p3_waitcnt(NP, 15));      // the patch of phase k+1 has landed; the NP new loads stay in flight
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!(kP3Ablate & 4)) {
+                        load_patch_to(php, nxt, nmask);    // (unconditional: see the PF2 schedule)
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_waitcnt(p3_waitcnt(NP, 15));      // the patch of phase k+1 has landed; the NP new loads stay in flight
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 } else {
                     __builtin_amdgcn_s_waitcnt(p3_waitcnt(0, 15));
                 }
-                store_patch_from((k + 1) & 1, cur, cmask);
+                if constexpr (!(kP3Ablate & 8)) store_patch_from((k + 1) & 1, cur, cmask);
+                else {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(cur[i].x), "v"(cur[i].y), "v"(cur[i].z), "v"(cur[i].w));      // (the loads stay alive)
+                }
                 __builtin_amdgcn_s_waitcnt(p3_waitcnt(63, 0));           // this wave's LDS stores are done
                 signal(sync_s + pw, k + 1);
             };
@@ -955,10 +971,12 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
             if (NM > MPR * NI) __builtin_amdgcn_sched_group_barrier(0x008, NM - MPR * NI, 0);
             __builtin_amdgcn_sched_barrier(0);                                                 // units do not mix
         };
+        if constexpr (!(ROLES && (kP3Ablate & 2))) {
         load_b(0, 0, fb1[0], fb2[0]);                      // B first: the first MFMA needs b1[0] and a2[0], LDS returns in order,
         load_a(0, fa1[0], fa2[0]);                         // so it can start after 6 of these 12 reads instead of 10
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... I>(std::integer_sequence<int, I...>) { (unit(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, NUNIT>{});
+        }
         if (STAMP) {
             const long long t = __builtin_amdgcn_s_memtime();
             t_comp += t - t_mark;
@@ -1023,7 +1041,8 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                     long long pixv[RPW];
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) pixv[r] = pix(r, li);
-                    conv_epilogue_flat<MF, RPW, false>(p, acc, pixv, pix, m0, lg, interior);
+                    if (!p.pixel_shuffle) conv_epilogue_plain<MF, RPW>(p, acc, pixv, m0, lg, (lds_cfloat_ptr)bias_s);
+                    else conv_epilogue_flat<MF, RPW, false>(p, acc, pixv, pix, m0, lg, interior, (lds_cfloat_ptr)bias_s);
                 }
             } else if (!(p.debug & 32)) {
                 // ONE pass over the wave's rows, straight from the accumulators: the epilogue issues row r+1's residual loads

@@ -283,7 +283,7 @@ __device__ __forceinline__ void conv_epilogue_gdn(const ConvP &p, f32x4 (&acc)[M
 
 template <int MF, int RPW, bool GDN = true, typename PIXF>
 __device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], const PIXF &pixf,
-                                                   int m0, int lg, bool interior = false) {
+                                                   int m0, int lg, bool interior = false, lds_cfloat_ptr bias_lds = nullptr) {
     // pix[r] = conv-space pixel index oy*Wout + ox of this lane's column of fragment row r, or -1 if outside; pixf(r, col) the
     // same for any column of the tile (conv_epilogue_fast_impl); interior (wave-uniform): the caller knows that no pixel of
     // the wave's rows is outside and m0 + 16 MF <= Cout
@@ -303,7 +303,13 @@ __device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[
     for (int f = 0; f < MF; ++f) {
         const int mb = m0 + f * 16 + 4 * lg;
         bb[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && mb < p.Cout) bb[f] = *reinterpret_cast<const float4 *>(p.bias + mb);  // bias is M_pad long
+        if (bias_lds) {
+            // the persistent kernels keep the bias in the LDS (zero where there is none): a GLOBAL load here queues behind the producers'
+            // patch requests in the CU's memory pipeline and the tile's epilogue waits two microseconds for sixteen bytes (round 6:
+            // profiles/r06_roles_ablation.txt -- the 2- and 3-channel heads spent 15 % of their time there)
+            const f32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>(bias_lds + mb);
+            bb[f] = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (p.bias && mb < p.Cout) bb[f] = *reinterpret_cast<const float4 *>(p.bias + mb);  // bias is M_pad long
     }
     auto gather4 = [&](const float *src, int mb, bool vec) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -392,6 +398,56 @@ __device__ __forceinline__ void conv_epilogue_flat(const ConvP &p, f32x4 (&acc)[
                     }
                 }
             }
+        }
+    }
+}
+
+// conv_epilogue_flat's plain case -- no GDN, no pixel shuffle, outputs that are not 16-byte addressable (the 2- and 3-channel heads) -- as
+// straight-line code for the persistent kernels (round 6): the same operations on every element in the same order (bias, activation,
+// residual, out_scale), scalar accesses, the bias from the LDS, every row's residuals requested before the first store. The general
+// routine compiles to ~500 instructions per row with its pixel-shuffle address arithmetic; the narrow-head kernel spent 15 % of its
+// time in it (profiles/r06_roles_ablation.txt).
+template <int MF, int RPW>
+__device__ __forceinline__ void conv_epilogue_plain(const ConvP &p, f32x4 (&acc)[MF][RPW], const long long (&pix)[RPW], int m0, int lg,
+                                                    lds_cfloat_ptr bias_lds) {
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int mb = m0 + f * 16 + 4 * lg;
+        if (mb >= p.Cout) continue;
+        const int nch = p.Cout - mb;                                   // channels of this lane's four that exist (>= 1)
+        const f32x4 bb = *reinterpret_cast<__attribute__((address_space(3))) const f32x4 *>(bias_lds + mb);      // (zero where there is no bias)
+        float rs[RPW][4];
+        if (p.res.p) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float *rp = p.res.p + (size_t)(pix[r] < 0 ? 0 : pix[r]) * p.res.ld + mb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rs[r][j] = (pix[r] >= 0 && j < nch) ? rp[j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            if (pix[r] < 0) continue;
+            float v[4] = {acc[f][r][0] + bb[0], acc[f][r][1] + bb[1], acc[f][r][2] + bb[2], acc[f][r][3] + bb[3]};
+            if (p.act == LSSVC_ACT_LRELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+            } else if (p.act == LSSVC_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            }
+            if (p.res.p) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += rs[r][j];
+            }
+            if (p.out_scale != 1.0f) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
+            }
+            float *dst = p.out.p + (size_t)pix[r] * p.out.ld + mb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nch) dst[j] = v[j];
         }
     }
 }

@@ -114,7 +114,7 @@ def test_persistent_3x3_matches_fp64(hip, cins, cout, H, W, in_act, act, residua
     inact = "true" if in_act else "false"
     want = "conv3_f16x3p_kernel<%d, %s>" % (mf, inact)
     if mf == 1:
-        want = "conv3n_f16x3p_kernel<%s, fast> pf2" % inact           # round 6: <= 16 output channels take the narrow-head instantiation
+        want = "conv3n_f16x3p_kernel<%s, fast> roles" % inact           # round 6: <= 16 output channels take the narrow-head instantiation
     assert k16 == want, k16                                           # really a persistent kernel
     assert k32.startswith("conv_mfma_kernel"), k32
     assert got16.shape == ref.shape
@@ -321,8 +321,8 @@ TILED_CASES = [
     ([64], 32, 7, 260, 520, "relu", False, "conv_f16x3_kernel<2, 4, 7, 1>"),      # conv3 (2.4 % of a P-frame each)
     ([32], 16, 7, 384, 400, "relu", False, "conv_f16x3_kernel<1, 4, 7, 1>"),      # conv4
     ([16], 2, 7, 384, 400, None, True, "conv_f16x3_kernel<1, 4, 7, 1>"),          # conv5 + flow residual
-    ([64], 2, 3, 384, 400, None, False, "conv3n_f16x3p_kernel<false, flat> pf2"),  # mv_resampler.recon_conv / weight maps (round 6: the narrow-head persistent kernel,
-    ([48], 3, 3, 384, 400, None, False, "conv3n_f16x3p_kernel<false, flat> pf2"),  # recon_conv                           test_narrow_heads_* hold it to the tiled kernel bit for bit)
+    ([64], 2, 3, 384, 400, None, False, "conv3n_f16x3p_kernel<false, flat> roles"),  # mv_resampler.recon_conv / weight maps (round 6: the narrow-head persistent kernel,
+    ([48], 3, 3, 384, 400, None, False, "conv3n_f16x3p_kernel<false, flat> roles"),  # recon_conv                         test_narrow_heads_* hold it to the tiled kernel bit for bit)
 ]
 
 
@@ -576,24 +576,31 @@ def test_narrow_heads_are_bit_identical_to_round5_kernels(hip, cins, cout, H, W,
     with _opts(p3_narrow=1, p3_pf2=1):
         new, k1 = _run(hip, "f16x3", launch)
         again, _ = _run(hip, "f16x3", launch)
-    assert k1 == "conv3n_f16x3p_kernel<%s, %s> pf2" % (inact, epi), k1
+    assert k1 == "conv3n_f16x3p_kernel<%s, %s> roles" % (inact, epi), k1
+    with _opts(p3_narrow=1, p3_pf2=4):
+        pf2, k3 = _run(hip, "f16x3", launch)
+    assert k3 == "conv3n_f16x3p_kernel<%s, %s> pf2" % (inact, epi), k3
     with _opts(p3_narrow=1, p3_pf2=0):
         plain, k2 = _run(hip, "f16x3", launch)
     assert k2 == "conv3n_f16x3p_kernel<%s, %s>" % (inact, epi), k2
-    assert torch.equal(new, old) and torch.equal(new, tiled) and torch.equal(new, again) and torch.equal(plain, old)
+    assert torch.equal(new, old) and torch.equal(new, tiled) and torch.equal(new, again) and torch.equal(plain, old) and torch.equal(pf2, old)
 
 
 @pytest.mark.parametrize("cins,cout,H,W,in_act,act,residual", P3S2_CASES)
 def test_stride2_register_prefetch_is_bit_identical(hip, cins, cout, H, W, in_act, act, residual):
-    """Round 6: the stride-2 persistent kernel with the producers' register prefetch (p3_pf2 = 1, the default), with
-    pair loads (2; measured slower, kept for the A/B) and as round 5 ran it (0): one arithmetic, three schedules."""
+    """Round 6: the stride-2 persistent kernel's producer schedules -- split roles (3: one wave owns the weight DMA,
+    three stage the patch through two register sets), register prefetch (4), pair loads (2; measured slower, kept for the A/B), round 5's
+    one register set (0) and the default (1: roles up to five phases per tile, the prefetch from six on): one arithmetic, four schedules."""
     launch = _conv_case(hip, cins, cout, H, W, stride=2, in_act=in_act, in_slope=0.1, act=act, slope=0.01, residual=residual)
     outs = {}
-    for pf in (0, 1, 2):
+    phases = sum((c + 15) // 16 for c in cins)
+    for pf in (0, 1, 2, 3, 4):
         with _opts(p3_pf2=pf):
             outs[pf], k = _run(hip, "f16x3", launch)
-        assert k.startswith("conv3s2_f16x3p_kernel<") and k.endswith({0: ">", 1: "pf2", 2: "pair"}[pf]), k
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+            again, _ = _run(hip, "f16x3", launch)
+        assert k.startswith("conv3s2_f16x3p_kernel<") and k.endswith({0: ">", 1: "roles" if phases <= 5 else "pf2", 2: "pair", 3: "roles", 4: "pf2"}[pf]), k
+        assert torch.equal(outs[pf], again), k
+    assert all(torch.equal(outs[0], outs[pf]) for pf in (1, 2, 3, 4))
 
 
 @pytest.mark.parametrize("c,H,W", [(64, 60, 100), (96, 37, 53), (128, 48, 80), (192, 20, 31), (48, 64, 64)])
@@ -628,14 +635,19 @@ def test_gdn_lean_epilogue_is_bit_identical(hip, c, H, W, flavour, inverse, resi
 
 
 @pytest.mark.parametrize("cins,cout,H,W,stride,opts,kernel", [
-    ([64], 2, 576, 960, 1, {}, "conv3n_f16x3p_kernel<true, flat> pf2"),                                  # narrow head, two workgroups per CU, register prefetch
+    ([64], 2, 576, 960, 1, {}, "conv3n_f16x3p_kernel<true, flat> roles"),                                # narrow head, two workgroups per CU, split roles
+    ([64], 2, 576, 960, 1, {"p3_pf2": 4}, "conv3n_f16x3p_kernel<true, flat> pf2"),                       # ... register prefetch
+    ([64], 8, 288, 480, 1, {}, "conv3n_f16x3p_kernel<true, fast> roles"),                                # ... fast epilogue
     ([64], 64, 144, 240, 1, {}, "conv3r_f16x3p_kernel<4, true, rpw 4>"),                                 # small tiling, plain schedule
     ([128], 128, 72, 120, 1, {}, "conv3r_f16x3p_kernel<4, true, rpw 2, pf2>"),                           # small tiling, 8 phases: register prefetch
-    ([48], 64, 576, 960, 2, {}, "conv3s2_f16x3p_kernel<4, true> pf2"),                                   # stride 2, register prefetch (3 phases per tile: odd)
+    ([48], 64, 576, 960, 2, {}, "conv3s2_f16x3p_kernel<4, true> roles"),                                 # stride 2, split roles (3 phases per tile: odd)
+    ([64], 96, 288, 480, 2, {}, "conv3s2_f16x3p_kernel<3, true> roles"),                                 # ... MF = 3, 4 phases
+    ([48], 64, 576, 960, 2, {"p3_pf2": 4}, "conv3s2_f16x3p_kernel<4, true> pf2"),                        # stride 2, register prefetch
+    ([128], 96, 288, 480, 2, {}, "conv3s2_f16x3p_kernel<3, true> pf2"),                                  # ... the default from six phases on
     ([64], 64, 576, 960, 2, {"p3_pf2": 2}, "conv3s2_f16x3p_kernel<4, true> pair"),                       # stride 2, pair loads
 ])
 def test_round6_schedules_hand_off_is_race_free(hip, cins, cout, H, W, stride, opts, kernel):
-    """The producer schedules of round 6 (register prefetch with counted waits, pair loads, two workgroups per CU) publish LDS buffers
+    """The producer schedules of round 6 (split roles and register prefetch with counted waits, pair loads, two workgroups per CU) publish LDS buffers
     through the same per-wave slots as the round-5 kernel: thirty launches each, with an input activation, must all equal the tiled
     kernel bit for bit (a hand-off that signalled a buffer before its patch had landed would show up as a launch that differs)."""
     from lssvc_amd._lib import lib

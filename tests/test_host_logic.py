@@ -362,7 +362,8 @@ def test_counted_waits_of_the_persistent_kernels_cover_their_weight_dma():
     flight, the weight DMA issued before them must have landed. Correct only while the compiler emits at least N vector-memory
     instructions between that DMA and the wait; round 5 checked the ISA by hand. tools/p3_waitcnt_check.py does it mechanically on the
     in-tree objects (the ones that are linked into liblssvc_hip.so): every instantiation of the patch-ring schedule (round 5) and of the
-    register-prefetch schedule (round 6) must pass, and the tool must actually have found their counted waits."""
+    register-prefetch and split-roles schedules (round 6) must pass, and the tool must actually have found their counted waits (the
+    hand-written ones carry an expcnt(6) mark in the ISA: conv3_f16x3p_kernel.h, p3_waitcnt)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -372,7 +373,12 @@ def test_counted_waits_of_the_persistent_kernels_cover_their_weight_dma():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "p3_waitcnt_check.py")] + objs, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "VIOLATION" not in p.stdout and " 0 with a counted wait that does not cover" in p.stdout
+    marked = lambda ln: ln.split("marked waits (N, loads in front): ")[1]
     ring = [ln for ln in p.stdout.splitlines() if "<3, 0, 0, 0, 1, 0, 0, 0, 0, 0>" in ln]                  # 48-channel kernels: three patch buffers
     pf = [ln for ln in p.stdout.splitlines() if "<4, 0, 0, 0, 2, 0, 0, 1, 0, 0>" in ln]                    # stride 2 with the register prefetch
-    assert ring and "(8, -8)" in ring[0], ring
-    assert pf and "(9, 9)" in pf[0], pf
+    roles = [ln for ln in p.stdout.splitlines() if "<4, 0, 0, 0, 2, 0, 0, 3, 0, 0>" in ln]                 # stride 2, split roles (three patch waves: 12 loads each)
+    narrow = [ln for ln in p.stdout.splitlines() if "<1, 0, 0, 0, 1, 0, 4, 3, 0, 1>" in ln]                # narrow head, split roles
+    assert ring and "(8, -8)" in ring[0] and "(8, 8)" in marked(ring[0]), ring
+    assert pf and "(9, 9)" in pf[0] and "(9, 9)" in marked(pf[0]), pf
+    assert roles and "(12, 12)" in marked(roles[0]), roles
+    assert narrow and "(" in marked(narrow[0]), narrow

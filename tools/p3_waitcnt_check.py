@@ -9,7 +9,8 @@ loads after a toolchain change) and the slot is published with the DMA possibly 
 that only by chance. This tool disassembles the device code of the given objects (llvm-objdump) and, for every kernel instantiation,
 walks the instruction stream: after a weight DMA it counts the vector-memory instructions up to the first s_waitcnt with a vmcnt field
 and requires  vmcnt <= that count  (a full drain, vmcnt(0), always passes). Pre-split-input instantiations (their patches are DMAs
-themselves, counted differently) are listed but not judged. Exit status 1 on a violation. tests/test_host_logic.py runs it on the
+themselves, counted differently) are listed but not judged. The split-roles schedule (round 6, PF = 3) keeps the DMA in a wave of its
+own (drained with vmcnt(0)); its patch waves' counted waits -- like every hand-written counted wait -- carry an expcnt(6) mark and are checked by marked_waits below. Exit status 1 on a violation. tests/test_host_logic.py runs it on the
 in-tree objects."""
 import os
 import re
@@ -103,6 +104,33 @@ def handoff_waits(body):
     return out
 
 
+def marked_waits(body):
+    """Third view, exact (round 6): the hand-written counted waits carry expcnt(6) (conv3_f16x3p_kernel.h: p3_waitcnt) -- no compiler-made
+    wait does. `s_waitcnt vmcnt(N) expcnt(6)` leaves the N youngest vector-memory requests in flight and everything older complete; what
+    the code then publishes or reads (a weight DMA, or -- split roles, PF = 3, whose patch waves issue no DMA -- the register set requested
+    before the new one) is older only if at least N vector-memory instructions lie between the previous vmcnt wait (or the loop head, or
+    the DMA) and this wait. -> list of (N, count)."""
+    out = []
+    for i, ins in enumerate(body):
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\) expcnt\(6\)", ins)
+        if not m:
+            continue
+        cnt = 0
+        for j in range(i - 1, max(-1, i - 400), -1):
+            op = body[j].split()[0] if body[j] else ""
+            if op.startswith("global_load_lds"):
+                break
+            if op.startswith(("global_load", "global_store", "buffer_load", "buffer_store")):
+                cnt += 1
+            elif op == "s_waitcnt" and "vmcnt" in body[j]:
+                break
+            elif (op.startswith("s_cbranch") or op == "s_branch") and int(body[j].split()[1]) > 32767:
+                break
+        if int(m.group(1)):                 # (a marked vmcnt(0): the compiler merged its own full drain into the counted wait of a tail step)
+            out.append((int(m.group(1)), cnt))
+    return out
+
+
 def main(objs):
     bad = judged = 0
     for obj in objs:
@@ -112,16 +140,21 @@ def main(objs):
                 continue
             res = check(body)
             hand = handoff_waits(body)
+            marked = marked_waits(body)
             split = len(args) > 5 and args[5] == 1
             counted = [r for r in res if r[0] > 0]
-            viol = [r for r in res if r[0] > r[1]] + [r for r in hand if r[0] > abs(r[1])]
+            viol = [r for r in res if r[0] > r[1]] + [r for r in hand if r[0] > abs(r[1])] + [("marked",) + r for r in marked if r[0] > r[1]]
+            stage, pf = (args[3] if len(args) > 3 else 0), (args[7] if len(args) > 7 else 0)
+            if not marked and pf in (1, 3):      # the register-prefetch and split-roles schedules are built on a counted wait: it must be there
+                viol.append(("no marked counted wait found",))
             tag = "not judged (pre-split inputs: the patches are DMAs)" if split else ("VIOLATION %s" % viol if viol else "ok")
-            print("%-22s %-42s waits behind a weight DMA: %2d, counted (N, loads since the DMA): %-12s hand-off waits (N, loads back to the DMA; negative: back to the block head): %s  %s" % (
-                os.path.basename(obj), "<" + ", ".join(str(a) for a in args) + ">", len(res), sorted(set(counted)) or "-", sorted(set(hand), key=str) or "-", tag))
+            print("%-22s %-42s waits behind a weight DMA: %2d, counted (N, loads since the DMA): %-12s hand-off waits (N, loads back to the DMA; negative: back to the block head): %-22s marked waits (N, loads in front): %s  %s" % (
+                os.path.basename(obj), "<" + ", ".join(str(a) for a in args) + ">", len(res), sorted(set(counted)) or "-", sorted(set(hand), key=str) or "-",
+                sorted(set(marked)) or "-", tag))
             if not split:
                 judged += 1
                 bad += 1 if viol else 0
-    print("%d instantiations judged, %d with a counted wait that does not cover its weight DMA" % (judged, bad))
+    print("%d instantiations judged, %d with a counted wait that does not cover what it publishes" % (judged, bad))
     return 1 if bad or not judged else 0
 
 

@@ -82,7 +82,7 @@ def main():
                                      ([64], 8, 576, 960, {}), ([64], 2, 576, 960, {}), ([64], 2, 288, 480, {}), ([32, 32], 16, 1152, 1920, {"act": "lrelu"})):
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
-            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("tiled / p3 rpw 6", {"p3_narrow": 0}), ("conv3n", {"p3_pf2": 0}), ("conv3n pf2", {"p3_pf2": 1}), ("conv3n roles", {"p3_pf2": 3})], rounds, reps,
+            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("tiled / p3 rpw 6", {"p3_narrow": 0}), ("conv3n", {"p3_pf2": 0}), ("conv3n pf2", {"p3_pf2": 4}), ("conv3n roles", {"p3_pf2": 3})], rounds, reps,
                      2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
     elif what in ("small", "small_sweep", "mid", "mid_sweep"):
         mid = (([64], 64, 288, 480, {}), ([64], 64, 288, 480, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}), ([96], 96, 288, 480, {}), ([128], 128, 288, 480, {}),
@@ -109,8 +109,15 @@ def main():
                                  ([96], 128, 288, 480), ([4, 48], 64, 1152, 1920), ([128], 128, 288, 480)):
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 2, g, dev, act="lrelu", slope=0.1)
-            run_arms("3x3 s2 %s->%d in %dx%d" % (cins, cout, H, W), call, [("one register set", {"p3_pf2": 0}), ("register prefetch", {"p3_pf2": 1}), ("pair loads", {"p3_pf2": 2}), ("split roles", {"p3_pf2": 3}), ("tiled", {"f16x3_persist_s2": 0})],
+            run_arms("3x3 s2 %s->%d in %dx%d" % (cins, cout, H, W), call, [("one register set", {"p3_pf2": 0}), ("register prefetch", {"p3_pf2": 4}), ("pair loads", {"p3_pf2": 2}), ("split roles", {"p3_pf2": 3}), ("tiled", {"f16x3_persist_s2": 0})],
                      rounds, reps, 2.0 * (H // 2) * (W // 2) * cout * 9 * cin, 4e-6 * (H * W * cin + (H // 2) * (W // 2) * cout))
+    elif what == "ablate":                 # tools/r6_roles_ablation.sh: the split-roles kernels only, whatever library LSSVC_HIP_LIB names
+        for cins, cout, H, W, stride, kw in (([64], 2, 1152, 1920, 1, {}), ([48], 3, 1152, 1920, 1, {}), ([32, 32], 16, 1152, 1920, 1, {"act": "lrelu"}),
+                                             ([48], 64, 1152, 1920, 2, {"act": "lrelu", "slope": 0.1}), ([64], 64, 576, 960, 2, {"act": "lrelu", "slope": 0.1})):
+            cin = sum(cins)
+            call = conv_case(cins, cout, H, W, stride, g, dev, **kw)
+            run_arms("3x3 s%d %s->%d in %dx%d" % (stride, cins, cout, H, W), call, [("split roles", {"p3_pf2": 3})], rounds, reps,
+                     2.0 * (H // stride) * (W // stride) * cout * 9 * cin, 4e-6 * (H * W * cin + (H // stride) * (W // stride) * cout))
     elif what == "big":
         for cins, cout, H, W, kw in (([64], 64, 1152, 1920, {}), ([64], 64, 576, 960, {}), ([128], 64, 576, 960, {}), ([128], 192, 576, 960, {}), ([64], 64, 288, 480, {})):      # (the MF = 4, no-input-activation shapes: the one instantiation kept)
             cin = sum(cins)
