@@ -145,10 +145,20 @@ int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
         int pf = (sm == 2 || (sm == 1 && p.n_chunks16 >= 8)) ? 1 : 0;
         if (c.rpw == 8 && sm == 1) pf = p.n_chunks16 % 3 == 0 ? 1 : 0;      // 32x16 tiles: the prefetch pays with 3 or 6 phases per tile (48- / 96-channel inputs), not with 4 or 5
         snprintf(kernel_name, 96, "conv3r_f16x3p_kernel<%d, %s, rpw %d%s>", c.mf, inact ? "true" : "false", c.rpw, pf == 2 ? ", pair" : pf == 1 ? ", pf2" : "");
+        // split roles on the 32x16 tiling: +1 ... +3 % on the 48 -> 48 layers (three phases per tile), -1 % with six; on the 24x16 tilings
+        // -2 ... -6 % at MF = 4 (profiles/r06_big_roles_ab.txt). p3_big_pair: 0 = this rule, 2 = roles wherever built, 3 = nowhere
+        if (const int bp = option_get(OPT_P3_BIG_PAIR); c.rpw == 8 && c.mf == 3 && (bp == 2 || (bp == 0 && p.n_chunks16 == 3 && sm == 1))) {
+            snprintf(kernel_name, 96, "conv3r_f16x3p_kernel<%d, %s, rpw %d, roles>", c.mf, inact ? "true" : "false", c.rpw);
+            return launch_p3_big_roles(p, c.mf, 8, inact, st);
+        }
         if (c.rpw == 8) return launch_p3_tall(p, c.mf, inact, c.mf == 3 ? pf : 0, st);
         return launch_p3_small(p, c.mf, c.rpw, inact, pf, st);
     }
-    if (option_get(OPT_P3_BIG_PAIR) && mf == 4 && !inact && !(p.debug & 256)) {      // experiment: the 24x16 tiling with pair loads
+    if (option_get(OPT_P3_BIG_PAIR) == 2 && mf >= 2 && !(p.debug & 256)) {      // experiment: the 24x16 tiling with split roles
+        snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s> roles", mf, inact ? "true" : "false");
+        return launch_p3_big_roles(p, mf, LSSVC_P3_RPW, inact, st);
+    }
+    if (option_get(OPT_P3_BIG_PAIR) == 1 && mf == 4 && !inact && !(p.debug & 256)) {      // experiment: the 24x16 tiling with pair loads
         snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s> pair", mf, inact ? "true" : "false");
         return launch_p3_big_pair(p, mf, inact, st);
     }

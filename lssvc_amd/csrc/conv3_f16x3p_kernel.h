@@ -1187,6 +1187,7 @@ int launch_p3_small(const ConvP &p, int mf, int rpw, bool inact, int pf, hipStre
 int launch_p3_narrow(const ConvP &p, bool inact, bool flat, int pf, hipStream_t st);                     // stride 1, <= 16 output channels, 16x16 tiles, 2 workgroups per CU
 int launch_p3s2_pf(const ConvP &p, int mf, bool inact, int pf, hipStream_t st);                  // stride 2 with the register prefetch (pf 1) / pair loads (pf 2)
 int launch_p3_big_pair(const ConvP &p, int mf, bool inact, hipStream_t st);
+int launch_p3_big_roles(const ConvP &p, int mf, int rpw, bool inact, hipStream_t st);      // conv3_f16x3p_r3.hip
 int launch_p3_tall(const ConvP &p, int mf, bool inact, int pf, hipStream_t st);                  // stride 1, 32x16 tiles (experiment)                      // stride 1, 24x16 tiles, pair loads (experiment)                         // stride 2 with the register prefetch
 
 }  // namespace lssvc

@@ -644,6 +644,8 @@ def test_gdn_lean_epilogue_is_bit_identical(hip, c, H, W, flavour, inverse, resi
     ([64], 96, 288, 480, 2, {}, "conv3s2_f16x3p_kernel<3, true> roles"),                                 # ... MF = 3, 4 phases
     ([48], 64, 576, 960, 2, {"p3_pf2": 4}, "conv3s2_f16x3p_kernel<4, true> pf2"),                        # stride 2, register prefetch
     ([128], 96, 288, 480, 2, {}, "conv3s2_f16x3p_kernel<3, true> pf2"),                                  # ... the default from six phases on
+    ([48], 48, 320, 400, 1, {"p3_force": 3 * 16 + 8}, "conv3r_f16x3p_kernel<3, true, rpw 8, roles>"),    # 32x16 tiles, split roles
+    ([64], 64, 320, 400, 1, {"p3_big_pair": 2}, "conv3_f16x3p_kernel<4, true> roles"),                   # 24x16 tiles, split roles (experiment)
     ([64], 64, 576, 960, 2, {"p3_pf2": 2}, "conv3s2_f16x3p_kernel<4, true> pair"),                       # stride 2, pair loads
 ])
 def test_round6_schedules_hand_off_is_race_free(hip, cins, cout, H, W, stride, opts, kernel):
@@ -693,12 +695,23 @@ def test_tall_tiles_are_bit_identical(hip, cins, H, W, kw):
             got, k = _run(hip, "f16x3", launch)
         assert k.startswith("conv3r_f16x3p_kernel<3,") and "rpw 8" in k and (("pf2" in k) == (sm == 2)), k
         assert torch.equal(got, r5) and torch.equal(got, tiled), k
+    for bp in (2, 0):                               # split roles on the tall tiles: forced, and by the default rule (three-phase tiles only)
+        with _opts(p3_force=3 * 16 + 8, p3_big_pair=bp):
+            got, k = _run(hip, "f16x3", launch)
+            again, _ = _run(hip, "f16x3", launch)
+        phases = sum((c + 15) // 16 for c in cins)
+        want = "roles" if bp == 2 or phases == 3 else ("pf2" if phases % 3 == 0 else "rpw 8>")
+        assert k.startswith("conv3r_f16x3p_kernel<3,") and "rpw 8" in k and want in k, (k, want)
+        assert torch.equal(got, r5) and torch.equal(got, again), k
 
 
 def test_tall_tiles_are_dispatched_for_the_full_resolution_48_channel_layers(hip):
     launch = _conv_case(hip, [48], 48, 1152, 1920)
     got, k = _run(hip, "f16x3", launch)
-    assert k == "conv3r_f16x3p_kernel<3, false, rpw 8, pf2>", k
+    assert k == "conv3r_f16x3p_kernel<3, false, rpw 8, roles>", k
+    with _opts(p3_big_pair=3):
+        pf2, k3 = _run(hip, "f16x3", launch)
+    assert k3 == "conv3r_f16x3p_kernel<3, false, rpw 8, pf2>" and torch.equal(got, pf2), k3
     with _opts(p3_small=0):
         r5, k5 = _run(hip, "f16x3", launch)
     assert k5 == "conv3_f16x3p_kernel<3, false>" and torch.equal(got, r5)

@@ -119,11 +119,15 @@ def main():
             run_arms("3x3 s%d %s->%d in %dx%d" % (stride, cins, cout, H, W), call, [("split roles", {"p3_pf2": 3})], rounds, reps,
                      2.0 * (H // stride) * (W // stride) * cout * 9 * cin, 4e-6 * (H * W * cin + (H // stride) * (W // stride) * cout))
     elif what == "big":
-        for cins, cout, H, W, kw in (([64], 64, 1152, 1920, {}), ([64], 64, 576, 960, {}), ([128], 64, 576, 960, {}), ([128], 192, 576, 960, {}), ([64], 64, 288, 480, {})):      # (the MF = 4, no-input-activation shapes: the one instantiation kept)
+        for cins, cout, H, W, kw in (([64], 64, 1152, 1920, {}), ([64], 64, 576, 960, {}), ([64], 64, 576, 960, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}), ([128], 64, 576, 960, {}),
+                                     ([128], 192, 576, 960, {}), ([64], 64, 288, 480, {}), ([48], 48, 1152, 1920, {}), ([48], 48, 1152, 1920, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}),
+                                     ([96], 48, 1152, 1920, {}), ([96], 96, 288, 480, {}), ([64], 32, 1152, 1920, {})):
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
-            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("r5 schedule", {}), ("pair loads", {"p3_big_pair": 1})], rounds, reps,
-                     2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
+            arms = [("r5 schedule", {}), ("split roles", {"p3_big_pair": 2})]
+            if cout == 64 and not kw and cin in (64, 128):
+                arms.append(("pair loads", {"p3_big_pair": 1}))      # (MF = 4, no input activation: the one instantiation kept)
+            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, arms, rounds, reps, 2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
     elif what == "p7n":
         for cins, cout, H, W in (([32], 16, 1152, 1920), ([32], 16, 576, 960), ([32], 16, 288, 480), ([8], 16, 1152, 1920)):
             cin = sum(cins)
