@@ -88,10 +88,6 @@ struct P3Geom {
     static_assert(FB >= 0 && STAGE_BYTES <= PB + WB + FB && OFF_TAIL + TAIL <= TOTAL, "staged layout");
 };
 
-// s_waitcnt immediate of gfx9 / gfx950: vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8 (15 = no wait)
-// COUNTED waits (0 < vm < 63: some loads are meant to stay in flight) carry expcnt(6) instead of 7: a compute kernel has no exports, the
-// counter is always 0 and the field costs nothing, but the disassembly shows `s_waitcnt vmcnt(N) expcnt(6)` -- the mark by which
-// tools/p3_waitcnt_check.py tells the hand-written counted waits from the compiler's own and checks N against the loads in front of them.
 // Diagnostic builds only (make P3_ABLATE=n into a separate library, tools/r6_roles_ablation.sh): the split-roles schedule with one of its
 // parts switched off -- 1: no weight DMA after the first phase, 2: no MFMAs, 4: no patch loads after the first two, 8: no conversion / LDS
 // stores of the patch. Results are wrong by design; the shipped library is built with 0 and none of this exists in its code.
@@ -99,6 +95,11 @@ struct P3Geom {
 #define LSSVC_P3_ABLATE 0
 #endif
 constexpr int kP3Ablate = LSSVC_P3_ABLATE;
+
+// s_waitcnt immediate of gfx9 / gfx950: vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8 (15 = no wait)
+// COUNTED waits (0 < vm < 63: some loads are meant to stay in flight) carry expcnt(6) instead of 7: a compute kernel has no exports, the
+// counter is always 0 and the field costs nothing, but the disassembly shows `s_waitcnt vmcnt(N) expcnt(6)` -- the mark by which
+// tools/p3_waitcnt_check.py tells the hand-written counted waits from the compiler's own and checks N against the loads in front of them.
 constexpr int p3_waitcnt(int vm, int lgkm) { return (vm & 15) | ((vm > 0 && vm < 63 ? 6 : 7) << 4) | ((lgkm & 15) << 8) | (((vm >> 4) & 3) << 14); }
 
 struct P3Phase {
@@ -160,7 +161,12 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
     constexpr int NP = (G::PATCH_ITEMS + PT - 1) / PT;                             // float4 items per staging thread and phase
     constexpr int NDMA = ROLES ? G::W_INSTR : G::NDMA;                             // weight-DMA instructions per DMA-issuing wave and phase
     constexpr int SR = STAGE ? G::SR : 0;
-    constexpr int NPB = (STAGE || PF) ? 2 : G::NPB;                                 // patch buffers (P3Geom: PATCH RING)
+    // patch buffers (P3Geom: PATCH RING). Round 6: the narrow heads' split-roles schedule runs a ring of three as well -- its patch waves fill
+    // up to two phases ahead of the consumers, whose phases take as long as a fill (profiles/r06_roles_ablation.txt); 3 x 20.3 KB of patch +
+    // 2 x 9 KB of weights + 1 KB of trash slots (one wave's worth, shared) = 79.8 of the 80 KB two workgroups per CU leave
+    constexpr bool RING3R = ROLES && WG2;
+    constexpr int NPB = STAGE ? 2 : RING3R ? 3 : PF ? 2 : G::NPB;
+    constexpr int TRASH_LANES = RING3R ? 64 : kP3ProducerThreads;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *const patch0 = reinterpret_cast<_Float16 *>(smem);                    // [buf][plane][PH*PW][16]
     _Float16 *const wts0 = STAGE ? reinterpret_cast<_Float16 *>(smem + G::OFF_W0) : patch0 + NPB * 2 * G::PATCH_HALFS;      // [buf][plane][tap][m][16]
@@ -410,8 +416,8 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                     ppos = py * PW + (px & 1) * G::PWE + (px >> 1);
                 }
                 const int o = ppos * CK16 + quad4;
-                *reinterpret_cast<f16x4 *>(in_patch ? ph_ + o : trash_s + lt * 4) = h;
-                *reinterpret_cast<f16x4 *>(in_patch ? pl_ + o : trash_s + (kP3ProducerThreads + lt) * 4) = l;
+                *reinterpret_cast<f16x4 *>(in_patch ? ph_ + o : trash_s + (lt % TRASH_LANES) * 4) = h;
+                *reinterpret_cast<f16x4 *>(in_patch ? pl_ + o : trash_s + (TRASH_LANES + lt % TRASH_LANES) * 4) = l;
             }
             if (STAMP) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                 store_patch(buf);
             }
         };
-        if constexpr (NPB == 3) {
+        if constexpr (NPB == 3 && !ROLES) {
             // ---- PATCH RING schedule: weights(k+1) and patch(k+2) while the consumers run phase k
             P3Phase php = ph;                               // the phase whose patch is filled next
             stage_weights(ph, 0);
@@ -637,8 +643,13 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
             }
             __builtin_amdgcn_s_waitcnt(p3_waitcnt(63, 0)); // this wave's LDS stores of phase 0 are done (no wait for the loads)
             __syncthreads();                               // (A)
+            int pb = 1;                                    // patch buffer of fill k+1: (k+1) & 1, or (k+1) % 3 with the ring
             auto step = [&](int k, float4 (&cur)[NP], unsigned &cmask, float4 (&nxt)[NP], unsigned &nmask, auto load) __attribute__((always_inline)) {
-                if (k >= 1) wait_for(sync_s + 4, k);       // patch buffer (k+1)&1 was read in phase k-1
+                if constexpr (NPB == 3) {
+                    if (k >= 2) wait_for(sync_s + 4, k - 1);      // ring: patch buffer (k+1) % 3 was read in phase k-2
+                } else {
+                    if (k >= 1) wait_for(sync_s + 4, k);   // patch buffer (k+1)&1 was read in phase k-1
+                }
                 if constexpr (decltype(load)::value) {
                     if (k + 2 < total) php = next_phase(php);
                     if constexpr (!(kP3Ablate & 4)) {
@@ -650,13 +661,14 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
                 } else {
                     __builtin_amdgcn_s_waitcnt(p3_waitcnt(0, 15));
                 }
-                if constexpr (!(kP3Ablate & 8)) store_patch_from((k + 1) & 1, cur, cmask);
+                if constexpr (!(kP3Ablate & 8)) store_patch_from(pb, cur, cmask);
                 else {
 #pragma unroll
                     for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(cur[i].x), "v"(cur[i].y), "v"(cur[i].z), "v"(cur[i].w));      // (the loads stay alive)
                 }
                 __builtin_amdgcn_s_waitcnt(p3_waitcnt(63, 0));           // this wave's LDS stores are done
                 signal(sync_s + pw, k + 1);
+                pb = pb + 1 == NPB ? 0 : pb + 1;
             };
             int k = 0;
             for (; k + 2 < total; k += 2) {
@@ -1167,7 +1179,10 @@ static int launch_p3r(const ConvP &p, hipStream_t st) {
     q.tiles_x = (p.Wout + 15) / 16;
     q.tiles_y = (p.Hout + G::TH - 1) / G::TH;
     q.m_tiles = (p.M_pad / 16 + MF - 1) / MF;
-    const size_t lds = (size_t)G::LDS_BYTES_RING + (size_t)q.m_tiles * G::TM * sizeof(float) + 32 + 2 * kP3ProducerThreads * 8;      // + bias vector + hand-off slots + trash slots
+    constexpr bool RING3R = PF == 3 && WG2;             // (the kernel's RING3R: three patch buffers, one wave's worth of trash slots)
+    constexpr int NPB = RING3R ? 3 : PF ? 2 : G::NPB;
+    const size_t lds = (size_t)(NPB * 2 * G::PATCH_HALFS + 2 * 2 * G::W_HALFS) * 2 + (size_t)q.m_tiles * G::TM * sizeof(float) + 32 +
+                       2 * (RING3R ? 64 : kP3ProducerThreads) * 8;      // + bias vector + hand-off slots + trash slots
     if (lds > (WG2 ? 80 : 160) * 1024) return fail("conv2d(f16x3p r): %zu bytes of LDS", lds);
     auto kern = conv3_f16x3p_kernel<MF, INACT, false, false, S, false, RPWT, PF, FLAT, WG2>;
     static LdsGrant grant;

@@ -367,7 +367,7 @@ def test_counted_waits_of_the_persistent_kernels_cover_their_weight_dma():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    objs = [os.path.join(root, "lssvc_amd", "csrc", n) for n in ("conv3_f16x3p.o", "conv3_f16x3p_r.o", "conv3_f16x3p_r2.o")]
+    objs = [os.path.join(root, "lssvc_amd", "csrc", n) for n in ("conv3_f16x3p.o", "conv3_f16x3p_r.o", "conv3_f16x3p_r2.o", "conv3_f16x3p_r3.o")]
     if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("objects not built here (python -c 'import __graft_entry__ as g; g.build()') or no llvm-objdump")
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "p3_waitcnt_check.py")] + objs, capture_output=True, text=True, timeout=600)

@@ -160,4 +160,4 @@ def main(objs):
 
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.exit(main(sys.argv[1:] or [os.path.join(root, "lssvc_amd", "csrc", n) for n in ("conv3_f16x3p.o", "conv3_f16x3p_r.o", "conv3_f16x3p_r2.o")]))
+    sys.exit(main(sys.argv[1:] or [os.path.join(root, "lssvc_amd", "csrc", n) for n in ("conv3_f16x3p.o", "conv3_f16x3p_r.o", "conv3_f16x3p_r2.o", "conv3_f16x3p_r3.o")]))
