@@ -556,6 +556,9 @@ NARROW_CASES = [
     ([64], 8, 300, 340, {"act": "lrelu"}, "fast"),
     ([32, 32], 16, 300, 340, {"act": "relu", "residual": True}, "fast"),     # two inputs, 16 channels, float4 residual
     ([16], 12, 290, 330, {}, "fast"),                                        # Cout % 4 == 0 but not a whole fragment
+    ([48], 3, 301, 333, {"act": "relu", "residual": True, "out_scale": 0.5}, "flat"),        # every branch of the straight-line flat epilogue (conv_epilogue_plain)
+    ([64], 2, 290, 350, {"act": "lrelu", "residual": True, "out_scale": 20.0}, "flat"),      # a flow head's form: activation, residual flow, scale
+    ([64], 6, 300, 340, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}, "flat"),     # two lane groups, the second with two of its four channels
 ]
 
 

@@ -29,3 +29,7 @@ timeout -k 10 200 python tools/plan_histogram.py > profiles/r06_plan_histogram.t
 timeout -k 10 120 tools/probes/clock_probe.bin 2.5 > profiles/r06_clock_probe.txt 2>&1 || exit 1
 cp profiles/r06_p3_stamps.json profiles/r06_p3_stamps.txt profiles/r06_bench_signatures.txt profiles/r06_plan_histogram.txt profiles/r06_clock_probe.txt profiles/r06_overlap_bench_single_stream.txt $OUT/ 2>/dev/null
 cat profiles/r06_p3_stamps.txt; head -5 profiles/r06_bench_signatures.txt; tail -5 profiles/r06_plan_histogram.txt
+# the driver's command on the SAME box (live HIP events: roofline.avg_launch_us is held against r06_bench_kernel_stats.csv's average for the same kernel)
+timeout -k 10 500 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.log || exit 1
+tail -1 $OUT/bench_default.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('bench: %.2f frames/s; %s: %d launches, %.1f us on average (live events), frac %.4f' % (d['value'], r['kernel'], r['launches'], r['avg_launch_us'], r['frac']))"
+grep -m1 "conv3_f16x3p_kernel<4, false, false, false, 1, false, 0, 0" profiles/r06_bench_kernel_stats.csv
