@@ -496,9 +496,10 @@ int lssvc_engine_decode_pframe(void *engine, const uint8_t *bl_file, int64_t bl_
  *                                    (measured slower; stride 2 only); 3 roles always; 4 register prefetch always (LSSVC_P3_PF2)
  *   "p7_narrow"                1/0   experiment: 7x7 persistent kernel with one 16-channel fragment for Cout <= 16 (slower) (LSSVC_P7_NARROW)
  *   "p3_force"                 n     experiments: force the small tiling MF * 16 + rows-per-wave (0 = the cost model) (LSSVC_P3_FORCE)
- *   "p3_big_pair"              0..3  producers of the big tilings: 0 (default) split roles on the 32x16 tiling's three-phase tiles (48 -> 48
- *                                    layers: +1 ... +3 %), round 5's schedule elsewhere; 1 experiment: 24x16 with pair loads (MF = 4, no input
- *                                    activation; slower); 2 split roles wherever built (24x16: slower at MF = 4); 3 nowhere (LSSVC_P3_BIG_PAIR)
+ *   "p3_big_pair"              0..4  producers of the big tilings: 0 (default) on the 32x16 tiling split roles for three-phase tiles (48 -> 48
+ *                                    layers: +1 ... +3 %) and late loads for six-phase tiles without an input activation (96 -> 48: +3 ... +4 %),
+ *                                    round 5's schedule elsewhere; 1 experiment: 24x16 with pair loads (slower); 2 split roles wherever built
+ *                                    (24x16: slower at MF = 4); 3 neither anywhere; 4 late loads wherever built (LSSVC_P3_BIG_PAIR)
  *   "gdn_fast"                 1/0   GDN / IGDN epilogue as straight-line code where the views allow it (LSSVC_GDN_FAST_OPT)
  * Results do not depend on them (the kernels they choose between are bit-identical); tests use them to pin that. */
 int lssvc_set_option(const char *name, int32_t value);

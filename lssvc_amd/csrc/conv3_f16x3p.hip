@@ -151,8 +151,18 @@ int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
             snprintf(kernel_name, 96, "conv3r_f16x3p_kernel<%d, %s, rpw %d, roles>", c.mf, inact ? "true" : "false", c.rpw);
             return launch_p3_big_roles(p, c.mf, 8, inact, st);
         }
+        if (const int bp = option_get(OPT_P3_BIG_PAIR); c.rpw == 8 && c.mf == 3 && (bp == 4 || (bp == 0 && p.n_chunks16 == 6 && !inact && sm == 1))) {      // (96 -> 48: +4 %)
+            snprintf(kernel_name, 96, "conv3r_f16x3p_kernel<%d, %s, rpw %d, late>", c.mf, inact ? "true" : "false", c.rpw);
+            return launch_p3_big_late(p, c.mf, 8, inact, st);
+        }
         if (c.rpw == 8) return launch_p3_tall(p, c.mf, inact, c.mf == 3 ? pf : 0, st);
         return launch_p3_small(p, c.mf, c.rpw, inact, pf, st);
+    }
+    // experiment: late loads (conv3_f16x3p_kernel.h, PF = 4) on the 24x16 tiling: -2 ... +3 % at MF = 4 without an input activation (two boxes:
+    // +1 % on average, inside the noise on the 576x960 layers), -5 % with one (profiles/r06_late_loads_ab.txt): not a default here
+    if (option_get(OPT_P3_BIG_PAIR) == 4 && mf >= 2 && !(p.debug & 256)) {
+        snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s> late", mf, inact ? "true" : "false");
+        return launch_p3_big_late(p, mf, LSSVC_P3_RPW, inact, st);
     }
     if (option_get(OPT_P3_BIG_PAIR) == 2 && mf >= 2 && !(p.debug & 256)) {      // experiment: the 24x16 tiling with split roles
         snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s> roles", mf, inact ? "true" : "false");

@@ -149,7 +149,7 @@ template <int MF, bool INACT, bool STAMP = false, bool STAGE = false, int S = 1,
 __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(const ConvP p) {
     static_assert(!(STAGE && S != 1), "the staged epilogue is laid out for stride 1");
     static_assert(!(SPLIT && INACT), "a pre-split input carries its activation already");
-    constexpr bool PF2 = PF == 1, PAIR = PF == 2, ROLES = PF == 3;
+    constexpr bool PF2 = PF == 1, PAIR = PF == 2, ROLES = PF == 3, LATE = PF == 4;
     static_assert(!(PF && (STAGE || SPLIT || STAMP)), "the register prefetch / pair loads are written for the plain two-buffer schedule");
     using G = P3Geom<MF, S, RPWT>;
     constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP;
@@ -715,6 +715,34 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
             }
             return;
         }
+        if constexpr (LATE) {
+            // ---- LATE-LOADS schedule (PF = 4, round 6; for the MFMA-bound tilings). The plain schedule below starts a fill when the consumers
+            // release its buffer and then REQUESTS the patch: weight-DMA issue + patch-load issue + memory latency + conversion = 4.9 k cycles
+            // (stamps) in front of the signal, against a consumer phase of 6.0 k -- the consumers waited 11.7 % of their cycles for fills. Here
+            // the patch of phase k+1 is requested right AFTER fill(k) has been signalled and sits in registers while the consumers run phase
+            // k-1's successor; once they release the buffer only the conversion, the weight DMA and its latency are in front of the signal.
+            // One register set; no LDS-DMA is ever outstanding while a loaded register is used (the DMA is issued after the patch stores and
+            // drained before the signal), so the compiler's own waits are the exact ones.
+            P3Phase php = ph;
+            stage_weights(ph, 0);
+            fill_patch(ph, 0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (total > 1) php = next_phase(php);
+            load_patch_to(php, preg, pmask);               // patch of phase 1 (a one-phase launch: phase 0 once more, to registers nobody reads)
+            __syncthreads();                               // (A) phase 0 is in buffer 0
+            for (int k = 0; k + 1 < total; ++k) {
+                if (k >= 1) wait_for(sync_s + 4, k);       // buffer (k+1)&1 was read in phase k-1: every consumer has left it
+                ph = next_phase(ph);
+                __builtin_amdgcn_s_waitcnt(p3_waitcnt(0, 15));            // the patch of phase k+1, requested an iteration ago, has landed
+                store_patch_from((k + 1) & 1, preg, pmask);
+                stage_weights(ph, (k + 1) & 1);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMA has landed, its LDS stores are done
+                signal(sync_s + pw, k + 1);
+                if (k + 2 < total) php = next_phase(php);
+                load_patch_to(php, preg, pmask);           // (unconditional: one definition of the register set per iteration, see the PF2 schedule)
+            }
+            return;
+        }
         if constexpr (PF2) {
             // ---- REGISTER PREFETCH schedule (see the kernel's PF2 note): while the consumers run phase k, fill(k+1) = weights by DMA + the
             // patch that has been in flight in one register set since the previous iteration; the loads of phase k+2 are requested into the
@@ -1203,6 +1231,7 @@ int launch_p3_narrow(const ConvP &p, bool inact, bool flat, int pf, hipStream_t 
 int launch_p3s2_pf(const ConvP &p, int mf, bool inact, int pf, hipStream_t st);                  // stride 2 with the register prefetch (pf 1) / pair loads (pf 2)
 int launch_p3_big_pair(const ConvP &p, int mf, bool inact, hipStream_t st);
 int launch_p3_big_roles(const ConvP &p, int mf, int rpw, bool inact, hipStream_t st);      // conv3_f16x3p_r3.hip
+int launch_p3_big_late(const ConvP &p, int mf, int rpw, bool inact, hipStream_t st);       // conv3_f16x3p_r3.hip
 int launch_p3_tall(const ConvP &p, int mf, bool inact, int pf, hipStream_t st);                  // stride 1, 32x16 tiles (experiment)                      // stride 1, 24x16 tiles, pair loads (experiment)                         // stride 2 with the register prefetch
 
 }  // namespace lssvc

@@ -13,4 +13,13 @@ int launch_p3_big_roles(const ConvP &p, int mf, int rpw, bool inact, hipStream_t
     return fail("conv2d(f16x3p, split roles): no kernel for MF=%d, %d rows per wave", mf, rpw);
 }
 
+// the late-loads schedule (PF = 4: the next patch requested right after a fill is signalled, conv3_f16x3p_kernel.h) on the same tilings
+int launch_p3_big_late(const ConvP &p, int mf, int rpw, bool inact, hipStream_t st) {
+#define LSSVC_P3L_CASE(m, r) \
+    if (mf == m && rpw == (r ? r : LSSVC_P3_RPW)) return inact ? launch_p3r<m, true, 1, r, 4, false, false>(p, st) : launch_p3r<m, false, 1, r, 4, false, false>(p, st);
+    LSSVC_P3L_CASE(4, 0) LSSVC_P3L_CASE(3, 0) LSSVC_P3L_CASE(2, 0) LSSVC_P3L_CASE(3, 8)
+#undef LSSVC_P3L_CASE
+    return fail("conv2d(f16x3p, late loads): no kernel for MF=%d, %d rows per wave", mf, rpw);
+}
+
 }  // namespace lssvc

@@ -649,6 +649,8 @@ def test_gdn_lean_epilogue_is_bit_identical(hip, c, H, W, flavour, inverse, resi
     ([128], 96, 288, 480, 2, {}, "conv3s2_f16x3p_kernel<3, true> pf2"),                                  # ... the default from six phases on
     ([48], 48, 320, 400, 1, {"p3_force": 3 * 16 + 8}, "conv3r_f16x3p_kernel<3, true, rpw 8, roles>"),    # 32x16 tiles, split roles
     ([64], 64, 320, 400, 1, {"p3_big_pair": 2}, "conv3_f16x3p_kernel<4, true> roles"),                   # 24x16 tiles, split roles (experiment)
+    ([64], 64, 320, 400, 1, {"p3_big_pair": 4}, "conv3_f16x3p_kernel<4, true> late"),                    # 24x16 tiles, late loads (experiment)
+    ([96], 48, 320, 400, 1, {"p3_force": 3 * 16 + 8, "p3_big_pair": 4}, "conv3r_f16x3p_kernel<3, true, rpw 8, late>"),      # 32x16 tiles, late loads
     ([64], 64, 576, 960, 2, {"p3_pf2": 2}, "conv3s2_f16x3p_kernel<4, true> pair"),                       # stride 2, pair loads
 ])
 def test_round6_schedules_hand_off_is_race_free(hip, cins, cout, H, W, stride, opts, kernel):
@@ -681,7 +683,8 @@ def test_round6_schedules_hand_off_is_race_free(hip, cins, cout, H, W, stride, o
     assert bad == 0, "%d of 30 launches differ" % bad
 
 
-@pytest.mark.parametrize("cins,H,W,kw", [([48], 300, 340, {}), ([48, 48], 290, 350, {"in_act": "lrelu", "in_slope": 0.1, "act": "lrelu", "residual": True}), ([64, 16], 301, 333, {})])
+@pytest.mark.parametrize("cins,H,W,kw", [([48], 300, 340, {}), ([48, 48], 290, 350, {"in_act": "lrelu", "in_slope": 0.1, "act": "lrelu", "residual": True}), ([64, 16], 301, 333, {}),
+                                         ([96], 300, 340, {"act": "lrelu"})])
 def test_tall_tiles_are_bit_identical(hip, cins, H, W, kw):
     """Round 6: the 48-channel layers of the full-resolution maps run on 32x16-pixel tiles (8 rows per consumer wave; conv3_f16x3p.hip:
     p3_pick_tiling) -- forced here onto maps small enough for a test, with and without the register prefetch, against the 24x16
@@ -698,12 +701,13 @@ def test_tall_tiles_are_bit_identical(hip, cins, H, W, kw):
             got, k = _run(hip, "f16x3", launch)
         assert k.startswith("conv3r_f16x3p_kernel<3,") and "rpw 8" in k and (("pf2" in k) == (sm == 2)), k
         assert torch.equal(got, r5) and torch.equal(got, tiled), k
-    for bp in (2, 0):                               # split roles on the tall tiles: forced, and by the default rule (three-phase tiles only)
+    for bp in (2, 4, 0):                            # split roles / late loads on the tall tiles: forced, and by the default rules
         with _opts(p3_force=3 * 16 + 8, p3_big_pair=bp):
             got, k = _run(hip, "f16x3", launch)
             again, _ = _run(hip, "f16x3", launch)
         phases = sum((c + 15) // 16 for c in cins)
-        want = "roles" if bp == 2 or phases == 3 else ("pf2" if phases % 3 == 0 else "rpw 8>")
+        late = bp == 0 and phases == 6 and not kw.get("in_act")       # the default rule: late loads for six-phase tiles without an input activation
+        want = "roles" if bp == 2 or (bp == 0 and phases == 3) else "late" if (bp == 4 or late) else ("pf2" if phases % 3 == 0 else "rpw 8>")
         assert k.startswith("conv3r_f16x3p_kernel<3,") and "rpw 8" in k and want in k, (k, want)
         assert torch.equal(got, r5) and torch.equal(got, again), k
 

@@ -124,7 +124,7 @@ def main():
                                      ([96], 48, 1152, 1920, {}), ([96], 96, 288, 480, {}), ([64], 32, 1152, 1920, {})):
             cin = sum(cins)
             call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
-            arms = [("r5 schedule", {}), ("split roles", {"p3_big_pair": 2})]
+            arms = [("r5 schedule", {"p3_big_pair": 3}), ("split roles", {"p3_big_pair": 2}), ("late loads", {"p3_big_pair": 4}), ("default", {})]
             if cout == 64 and not kw and cin in (64, 128):
                 arms.append(("pair loads", {"p3_big_pair": 1}))      # (MF = 4, no input activation: the one instantiation kept)
             run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, arms, rounds, reps, 2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
