@@ -160,6 +160,10 @@ int dispatch_conv3_f16x3p(const ConvP &p, hipStream_t st, char *kernel_name) {
     }
     // experiment: late loads (conv3_f16x3p_kernel.h, PF = 4) on the 24x16 tiling: -2 ... +3 % at MF = 4 without an input activation (two boxes:
     // +1 % on average, inside the noise on the 576x960 layers), -5 % with one (profiles/r06_late_loads_ab.txt): not a default here
+    if (option_get(OPT_P3_BIG_PAIR) == 4 && mf == 4 && !inact && (p.debug & 256)) {      // the stamp build of the late-loads schedule
+        snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s> late, stamps", mf, inact ? "true" : "false");
+        return launch_p3_late_stamps(p, st);
+    }
     if (option_get(OPT_P3_BIG_PAIR) == 4 && mf >= 2 && !(p.debug & 256)) {
         snprintf(kernel_name, 96, "conv3_f16x3p_kernel<%d, %s> late", mf, inact ? "true" : "false");
         return launch_p3_big_late(p, mf, LSSVC_P3_RPW, inact, st);

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
     static_assert(!(STAGE && S != 1), "the staged epilogue is laid out for stride 1");
     static_assert(!(SPLIT && INACT), "a pre-split input carries its activation already");
     constexpr bool PF2 = PF == 1, PAIR = PF == 2, ROLES = PF == 3, LATE = PF == 4;
-    static_assert(!(PF && (STAGE || SPLIT || STAMP)), "the register prefetch / pair loads are written for the plain two-buffer schedule");
+    static_assert(!(PF && (STAGE || SPLIT || (STAMP && PF != 4))), "the register prefetch / pair loads are written for the plain two-buffer schedule");
     using G = P3Geom<MF, S, RPWT>;
     constexpr int RPW = G::RPW, TM = G::TM, PW = G::PW, NTAP = G::NTAP, NSTEP = G::NSTEP;
     // ROLES (PF = 3, round 6): producer wave 3 moves ALL of a phase's weights (LDS-DMA only), waves 0-2 stage the patch (plain loads
@@ -731,15 +731,25 @@ __global__ __launch_bounds__(kP3Threads, WG2 ? 4 : 1) void conv3_f16x3p_kernel(c
             load_patch_to(php, preg, pmask);               // patch of phase 1 (a one-phase launch: phase 0 once more, to registers nobody reads)
             __syncthreads();                               // (A) phase 0 is in buffer 0
             for (int k = 0; k + 1 < total; ++k) {
+                long long tb = 0;
+                if (STAMP) tb = __builtin_amdgcn_s_memtime();
                 if (k >= 1) wait_for(sync_s + 4, k);       // buffer (k+1)&1 was read in phase k-1: every consumer has left it
+                if (STAMP) s_bar += __builtin_amdgcn_s_memtime() - tb;
                 ph = next_phase(ph);
                 __builtin_amdgcn_s_waitcnt(p3_waitcnt(0, 15));            // the patch of phase k+1, requested an iteration ago, has landed
                 store_patch_from((k + 1) & 1, preg, pmask);
                 stage_weights(ph, (k + 1) & 1);
+                long long tw = 0;
+                if (STAMP) tw = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMA has landed, its LDS stores are done
+                if (STAMP) s_wait += __builtin_amdgcn_s_memtime() - tw;       // (stamps: the weight DMA's latency)
                 signal(sync_s + pw, k + 1);
                 if (k + 2 < total) php = next_phase(php);
                 load_patch_to(php, preg, pmask);           // (unconditional: one definition of the register set per iteration, see the PF2 schedule)
+            }
+            if (STAMP && lane == 0 && p.gdn_x.p) {
+                long long *o = reinterpret_cast<long long *>(p.gdn_x.p) + ((size_t)gridDim.x * kP3Consumers + (size_t)blockIdx.x * 4 + pw) * 8;
+                o[0] = s_dma; o[1] = s_ld; o[2] = s_wait; o[3] = s_cvt; o[4] = s_bar; o[5] = total; o[6] = s_geo; o[7] = 0;
             }
             return;
         }
@@ -1199,7 +1209,7 @@ static int launch_p3(const ConvP &p, hipStream_t st) {
 
 // Round 6: the instantiations with their own tile height (RPWT), the register prefetch (PF2), the tiled kernel's epilogue (FLAT) and two
 // workgroups per CU (WG2); conv3_f16x3p_r.hip. No STAGE / SPLIT / STAMP forms.
-template <int MF, bool INACT, int S, int RPWT, int PF, bool FLAT, bool WG2>
+template <int MF, bool INACT, int S, int RPWT, int PF, bool FLAT, bool WG2, bool STAMPK = false>
 static int launch_p3r(const ConvP &p, hipStream_t st) {
     using G = P3Geom<MF, S, RPWT>;
     const int cus = device_cus();
@@ -1212,7 +1222,7 @@ static int launch_p3r(const ConvP &p, hipStream_t st) {
     const size_t lds = (size_t)(NPB * 2 * G::PATCH_HALFS + 2 * 2 * G::W_HALFS) * 2 + (size_t)q.m_tiles * G::TM * sizeof(float) + 32 +
                        2 * (RING3R ? 64 : kP3ProducerThreads) * 8;      // + bias vector + hand-off slots + trash slots
     if (lds > (WG2 ? 80 : 160) * 1024) return fail("conv2d(f16x3p r): %zu bytes of LDS", lds);
-    auto kern = conv3_f16x3p_kernel<MF, INACT, false, false, S, false, RPWT, PF, FLAT, WG2>;
+    auto kern = conv3_f16x3p_kernel<MF, INACT, STAMPK, false, S, false, RPWT, PF, FLAT, WG2>;
     static LdsGrant grant;
     if (grant.ensure(reinterpret_cast<const void *>(kern), lds)) return 1;
     const long long ntiles = (long long)q.tiles_x * q.tiles_y * q.m_tiles;
@@ -1232,6 +1242,7 @@ int launch_p3s2_pf(const ConvP &p, int mf, bool inact, int pf, hipStream_t st); 
 int launch_p3_big_pair(const ConvP &p, int mf, bool inact, hipStream_t st);
 int launch_p3_big_roles(const ConvP &p, int mf, int rpw, bool inact, hipStream_t st);      // conv3_f16x3p_r3.hip
 int launch_p3_big_late(const ConvP &p, int mf, int rpw, bool inact, hipStream_t st);       // conv3_f16x3p_r3.hip
+int launch_p3_late_stamps(const ConvP &p, hipStream_t st);                                   // conv3_f16x3p_r3.hip: MF = 4, no input activation, in-kernel stamps
 int launch_p3_tall(const ConvP &p, int mf, bool inact, int pf, hipStream_t st);                  // stride 1, 32x16 tiles (experiment)                      // stride 1, 24x16 tiles, pair loads (experiment)                         // stride 2 with the register prefetch
 
 }  // namespace lssvc

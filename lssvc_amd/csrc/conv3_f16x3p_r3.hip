@@ -22,4 +22,7 @@ int launch_p3_big_late(const ConvP &p, int mf, int rpw, bool inact, hipStream_t 
     return fail("conv2d(f16x3p, late loads): no kernel for MF=%d, %d rows per wave", mf, rpw);
 }
 
+// diagnostic (LSSVC_CONV_DEBUG = 256 with p3_big_pair = 4; tools/p3_stamps.py): the late-loads schedule with in-kernel stamps
+int launch_p3_late_stamps(const ConvP &p, hipStream_t st) { return launch_p3r<4, false, 1, 0, 4, false, false, true>(p, st); }
+
 }  // namespace lssvc

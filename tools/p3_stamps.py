@@ -24,6 +24,9 @@ def main():
     stride = int(os.environ.get("P3_STRIDE", "1"))            # 2: the stride-2 form (round 6; MF = 4 shapes only)
     if stride == 2:
         shapes = (("s2 48->64 in 1152x1920", 48, 64, 1152, 1920), ("s2 64->64 in 576x960", 64, 64, 576, 960), ("s2 128->128 in 288x480", 128, 128, 288, 480))
+    if os.environ.get("P3_LATE", "0") == "1":                 # the late-loads schedule's stamp build (round 6; MF = 4 without an input activation only)
+        _lib.check(_lib.lib.lssvc_set_option(b"p3_big_pair", 4))
+        shapes = (("64->64 @1152x1920", 64, 64, 1152, 1920), ("128->64 @576x960", 128, 64, 576, 960), ("64->64 @576x960", 64, 64, 576, 960))
     for name, cin, cout, H, W in shapes:
         w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
         b = torch.randn(cout, generator=g)
@@ -77,8 +80,9 @@ def main():
         if pr.shape[0]:
             dma, ld, wait, cvt, pbar, pph, geo = (pr[:, i].median().item() for i in range(7))
             print("   producer wave, cycles per phase: weight-DMA issue %.0f, patch-load issue %.0f, convert + LDS stores %.0f, "
-                  "barrier wait %.0f, tile geometry %.0f; staged build: boundary fill (consumers done -> fill signalled) %.0f cycles per tile" % (
-                      dma / pph, ld / pph, cvt / pph, pbar / pph, geo / pph, wait / max(tiles, 1)))
+                  "barrier wait %.0f, tile geometry %.0f; staged build: boundary fill (consumers done -> fill signalled) %.0f cycles per tile%s" % (
+                      dma / pph, ld / pph, cvt / pph, pbar / pph, geo / pph, wait / max(tiles, 1),
+                      "; late-loads build: wait for the weight DMA %.0f cycles per phase" % (wait / pph) if os.environ.get("P3_LATE", "0") == "1" else ""))
     if "--json" in sys.argv:
         _write_json(records)
 

@@ -128,6 +128,15 @@ def main():
             if cout == 64 and not kw and cin in (64, 128):
                 arms.append(("pair loads", {"p3_big_pair": 1}))      # (MF = 4, no input activation: the one instantiation kept)
             run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, arms, rounds, reps, 2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
+    elif what == "late":                   # which epilogue / input forms the late-loads schedule suits (MF = 4, 24x16 tiles)
+        for cins, cout, H, W, kw in (([64], 64, 576, 960, {}), ([64], 64, 576, 960, {"in_act": "lrelu", "in_slope": 0.1}), ([64], 64, 576, 960, {"residual": True}),
+                                     ([64], 64, 576, 960, {"act": "lrelu"}), ([64], 64, 576, 960, {"in_act": "lrelu", "in_slope": 0.1, "residual": True}),
+                                     ([64], 64, 1152, 1920, {"residual": True}), ([64], 64, 1152, 1920, {"in_act": "lrelu", "in_slope": 0.1}), ([64], 64, 384, 640, {}), ([64], 64, 288, 480, {}),
+                                     ([128], 128, 288, 480, {}), ([64], 128, 576, 960, {}), ([96], 64, 1152, 1920, {}), ([64], 256, 288, 480, {"pixel_shuffle": True})):
+            cin = sum(cins)
+            call = conv_case(cins, cout, H, W, 1, g, dev, **kw)
+            run_arms("3x3 %s->%d @%dx%d %s" % (cins, cout, H, W, kw), call, [("r5 schedule", {"p3_big_pair": 3}), ("late loads", {"p3_big_pair": 4})], rounds, reps,
+                     2.0 * H * W * cout * 9 * cin, 4e-6 * H * W * (cin + cout))
     elif what == "p7n":
         for cins, cout, H, W in (([32], 16, 1152, 1920), ([32], 16, 576, 960), ([32], 16, 288, 480), ([8], 16, 1152, 1920)):
             cin = sum(cins)
