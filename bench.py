@@ -24,6 +24,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (lssvc_amd/__init__.py: before the HIP runtime initialises; +1.8 %, profiles/r06_hw_queues_ab.txt)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
