@@ -24,7 +24,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (lssvc_amd/__init__.py: before the HIP runtime initialises; +1.8 %, profiles/r06_hw_queues_ab.txt)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (lssvc_amd/__init__.py: before the HIP runtime initialises; +0.6 ... 1.8 %, profiles/r06_hw_queues_ab.txt)
 
 import torch
 
