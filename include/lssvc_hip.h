@@ -501,6 +501,8 @@ int lssvc_engine_decode_pframe(void *engine, const uint8_t *bl_file, int64_t bl_
  *                                    round 5's schedule elsewhere; 1 experiment: 24x16 with pair loads (slower); 2 split roles wherever built
  *                                    (24x16: slower at MF = 4); 3 neither anywhere; 4 late loads wherever built (LSSVC_P3_BIG_PAIR)
  *   "gdn_fast"                 1/0   GDN / IGDN epilogue as straight-line code where the views allow it (LSSVC_GDN_FAST_OPT)
+ *   "resample_rows"            1/0   lssvc_resample2d evaluates the vertical pass once per source column and output row (a workgroup per
+ *                                    256 outputs of a row, column sums in the LDS) instead of once per output (LSSVC_RESAMPLE_ROWS)
  * Results do not depend on them (the kernels they choose between are bit-identical); tests use them to pin that. */
 int lssvc_set_option(const char *name, int32_t value);
 int lssvc_get_option(const char *name, int32_t *value);

@@ -92,6 +92,6 @@ struct LdsGrant {
 // runtime tuning switches (lssvc_set_option / environment), see conv_mfma.hip
 int option_get(int which);
 enum { OPT_P3_ON = 0, OPT_P3_MIN_TILES = 1, OPT_P7_ON = 2, OPT_POINTWISE_BLOCKS = 3, OPT_DWPRE_DEEP = 4, OPT_P3_BLOCKS = 5, OPT_P3_STAGE = 6, OPT_P3_S2 = 7,
-       OPT_P3_SMALL = 8, OPT_P3_NARROW = 9, OPT_P3_PF2 = 10, OPT_P3_FORCE = 11, OPT_GDN_FAST = 12, OPT_P3_BIG_PAIR = 13, OPT_P7_NARROW = 14, OPT_COUNT = 15 };
+       OPT_P3_SMALL = 8, OPT_P3_NARROW = 9, OPT_P3_PF2 = 10, OPT_P3_FORCE = 11, OPT_GDN_FAST = 12, OPT_P3_BIG_PAIR = 13, OPT_P7_NARROW = 14, OPT_RESAMPLE_ROWS = 15, OPT_COUNT = 16 };
 
 }  // namespace lssvc

@@ -27,10 +27,10 @@ namespace lssvc {
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<bool> g_opt_set[OPT_COUNT];
 static const char *const kOptEnv[OPT_COUNT] = {"LSSVC_F16X3_PERSIST", "LSSVC_F16X3_PERSIST_MIN_TILES", "LSSVC_F16X3_PERSIST7", "LSSVC_POINTWISE_BLOCKS", "LSSVC_DWPRE_DEEP", "LSSVC_P3_BLOCKS", "LSSVC_P3_STAGE", "LSSVC_F16X3_PERSIST_S2",
-                                              "LSSVC_P3_SMALL", "LSSVC_P3_NARROW", "LSSVC_P3_PF2", "LSSVC_P3_FORCE", "LSSVC_GDN_FAST_OPT", "LSSVC_P3_BIG_PAIR", "LSSVC_P7_NARROW"};
+                                              "LSSVC_P3_SMALL", "LSSVC_P3_NARROW", "LSSVC_P3_PF2", "LSSVC_P3_FORCE", "LSSVC_GDN_FAST_OPT", "LSSVC_P3_BIG_PAIR", "LSSVC_P7_NARROW", "LSSVC_RESAMPLE_ROWS"};
 static const char *const kOptName[OPT_COUNT] = {"f16x3_persist", "f16x3_persist_min_tiles", "f16x3_persist7", "pointwise_blocks", "dwpre_deep", "p3_blocks", "p3_stage", "f16x3_persist_s2",
-                                               "p3_small", "p3_narrow", "p3_pf2", "p3_force", "gdn_fast", "p3_big_pair", "p7_narrow"};
-static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, 1, 0, 0};      // p3_stage: off (measured slower); kept for the record and its test
+                                               "p3_small", "p3_narrow", "p3_pf2", "p3_force", "gdn_fast", "p3_big_pair", "p7_narrow", "resample_rows"};
+static const int kOptDefault[OPT_COUNT] = {1, 256, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, 1, 0, 0, 1};      // p3_stage: off (measured slower); kept for the record and its test
 int option_get(int which) {
     if (!g_opt_set[which].load(std::memory_order_acquire)) {
         const char *e = getenv(kOptEnv[which]);

@@ -122,6 +122,64 @@ __global__ void resample2d_kernel(V in, V out, const float *__restrict__ wv, con
     out.p[(size_t)pix * out.ld + c] = fminf(fmaxf(acc, lo), hi);
 }
 
+// The same sums, separably (round 6): a workgroup owns kRsTx output pixels of one output row; it first evaluates the VERTICAL pass once per
+// source column its outputs touch (col[sx][c] = sum_ky wv[y][ky] * in[iv[y][ky]][sx][c], taps in index order, coalesced along sx and c) into
+// the LDS, then every output sums its horizontal taps over those columns in index order -- the operations of resample2d_kernel on every
+// element in the same order (bit-identical: tests/test_gpu_prepost.py), an eighth of its loads at 1080p -> 540p (237 -> ~25 us; the
+// bench's per-frame pre-processing sits in the clock since round 6). Source-column ranges that do not fit the LDS budget (a down-scale
+// beyond ~x15) are evaluated per output as before.
+constexpr int kRsTx = 256, kRsCap = 12288;      // outputs per workgroup; floats of LDS for the column sums (48 KB)
+__global__ void resample2d_rows_kernel(V in, V out, const float *__restrict__ wv, const int32_t *__restrict__ iv, int Kv,
+                                       const float *__restrict__ wh, const int32_t *__restrict__ ih, int Kh, float lo, float hi) {
+    extern __shared__ float rs_cols[];
+    __shared__ int s_min, s_max;
+    const int y = blockIdx.y, x0 = blockIdx.x * kRsTx, C = out.C;
+    const int nx = out.W - x0 < kRsTx ? out.W - x0 : kRsTx;
+    if (threadIdx.x == 0) {
+        s_min = 0x7fffffff;
+        s_max = -1;
+    }
+    __syncthreads();
+    int mn = 0x7fffffff, mx = -1;
+    for (int i = threadIdx.x; i < nx * Kh; i += blockDim.x) {
+        const int sx = ih[(size_t)x0 * Kh + i];
+        mn = sx < mn ? sx : mn;
+        mx = sx > mx ? sx : mx;
+    }
+    atomicMin(&s_min, mn);
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    const int s0 = s_min, n = s_max - s0 + 1;
+    const float *wvy = wv + (size_t)y * Kv;
+    const int32_t *ivy = iv + (size_t)y * Kv;
+    const bool staged = (long long)n * C <= kRsCap;
+    if (staged) {
+        for (int i = threadIdx.x; i < n * C; i += blockDim.x) {
+            const int sx = s0 + i / C, c = i % C;
+            float col = 0.f;
+            for (int ky = 0; ky < Kv; ++ky) col += wvy[ky] * in.p[((size_t)ivy[ky] * in.W + sx) * in.ld + c];
+            rs_cols[i] = col;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nx * C; i += blockDim.x) {
+        const int x = x0 + i / C, c = i % C;
+        float acc = 0.f;
+        for (int kx = 0; kx < Kh; ++kx) {
+            const int sx = ih[(size_t)x * Kh + kx];
+            float col;
+            if (staged) {
+                col = rs_cols[(sx - s0) * C + c];
+            } else {
+                col = 0.f;
+                for (int ky = 0; ky < Kv; ++ky) col += wvy[ky] * in.p[((size_t)ivy[ky] * in.W + sx) * in.ld + c];
+            }
+            acc += wh[(size_t)x * Kh + kx] * col;
+        }
+        out.p[((size_t)y * out.W + x) * out.ld + c] = fminf(fmaxf(acc, lo), hi);
+    }
+}
+
 // rgb_to_ycbcr420 of the top-left h x w crop (h, w even): one thread per 2x2 block
 __global__ void rgb_to_yuv420_kernel(V rgb, int h, int w, int clamp01, float *__restrict__ yo, float *__restrict__ uo,
                                      float *__restrict__ vo, long long total) {
@@ -214,6 +272,11 @@ extern "C" int lssvc_resample2d(const lssvc_view *in, const lssvc_view *out, con
     LSSVC_CHECK(view_ok(in) && view_ok(out) && in->C == out->C && w_v && idx_v && w_h && idx_h && k_v > 0 && k_h > 0,
                 "resample2d: bad arguments");
     const long long total = (long long)out->H * out->W * out->C;
+    if (option_get(OPT_RESAMPLE_ROWS) && out->H <= 65535 && (long long)kRsTx * out->C <= 65536) {
+        hipLaunchKernelGGL(resample2d_rows_kernel, dim3((out->W + kRsTx - 1) / kRsTx, out->H), dim3(256), kRsCap * sizeof(float), (hipStream_t)stream,
+                           mk(in), mk(out), w_v, idx_v, k_v, w_h, idx_h, k_h, clamp_lo, clamp_hi);
+        return launch_status("resample2d(rows)");
+    }
     hipLaunchKernelGGL(resample2d_kernel, dim3(pp_blocks(total)), dim3(256), 0, (hipStream_t)stream, mk(in), mk(out), w_v, idx_v, k_v,
                        w_h, idx_h, k_h, clamp_lo, clamp_hi, total);
     return launch_status("resample2d");

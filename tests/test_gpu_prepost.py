@@ -33,6 +33,23 @@ def test_rgb8_frame_and_bicubic_base_layer(prep, H, W, ratio):
     assert x_bl.min().item() >= 0.0 and x_bl.max().item() <= 1.0
 
 
+@pytest.mark.parametrize("H,W,ratio", [(1080, 1920, 2.0), (360, 640, 1.5), (270, 482, 2.0), (720, 1280, 4.0)])
+def test_bicubic_row_kernel_is_bit_identical_to_the_per_output_kernel(prep, H, W, ratio):
+    """Round 6: lssvc_resample2d as a separable pass (vertical sums once per source column, in the LDS) against the per-output kernel it
+    replaces (option resample_rows = 0): the same operations on every element in the same order."""
+    from lssvc_amd._lib import lib, check
+    from lssvc_amd.synth import synth_clip
+    u8 = synth_clip(1, H, W, seed=W)[0].to(DEV)
+    outs = []
+    for rows in (1, 0, 1):
+        check(lib.lssvc_set_option(b"resample_rows", rows))
+        try:
+            outs.append(prep.make_layers_rgb8(u8, ratio)[0].clone())
+        finally:
+            check(lib.lssvc_set_option(b"resample_rows", 1))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_bicubic_matches_reference_fixture(prep):
     """x_bl of the golden cases was produced by the reference's own imresize (tests/golden/make_golden.py)."""
     from lssvc_amd.hip_ops import T
